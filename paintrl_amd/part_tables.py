@@ -1,0 +1,617 @@
+"""Mesh -> static simulator tables for one paint part.
+
+This is the setup-time half of the simulator: everything
+``bullet_paint_wrapper.load_part`` (``PaintRLEnv/bullet_paint_wrapper.py:1327-1335``)
+derives once per part, restated as flat float64/int arrays that the HIP step
+kernel reads.  Each stage names the reference code whose arithmetic (including
+its order-dependent quirks) it follows:
+
+  stage                          reference (bullet_paint_wrapper.py)
+  -----------------------------  ------------------------------------------
+  triangle records               BarycentricInterpolator.__init__ 123-146,
+                                 calculate_normal_from_abc 256-263, _get_side 1219-1229
+  UV rasterisation -> samples    get_uv_pixels 192-212, Part.preprocess 622-648
+  per-side vertex set            Part._build_kd_tree 599-620
+  ranges / anchor start points   _get_corner_points_ranges 1256-1286, set_start_points 740-747
+  grid rows (ray walks)          _set_grid_dict 922-963, _get_exact_boundary 906-920
+  hull normal correction         ConvHull 61-104, _correct_bary_normals_with_conv_hull 650-660
+  neighbour smoothing            _smooth_bary_normals_with_neighbors 662-698
+  grid-observation cells         GridObservation._set_pixels_in_grid 1072-1101
+  start points 'all'/'edge'      get_start_points 749-809
+  density / cone beams           get_density 834-839, robot.py:14-35
+
+Only the painted side (front) is built.  Sample order is canonical (ascending
+``j*W + i``), not CPython set order: every consumer is order independent.
+"""
+import math
+
+import numpy as np
+
+from . import geometry as geo
+from . import obj_io
+
+PAINT_RADIUS = 0.051          # PaintToolProfile.PAINT_RADIUS (bpw:42)
+STEP_SIZE = PAINT_RADIUS      # PaintToolProfile.STEP_SIZE (bpw:43)
+HOOK_DISTANCE_TO_PART = 0.1   # Part.HOOK_DISTANCE_TO_PART (bpw:443)
+IRRELEVANT = 10.0             # Part.IRRELEVANT_POSE component (bpw:445)
+GRID_GRANULARITY = 100        # Part.GRID_GRANULARITY (bpw:447)
+MIN_AREA = 1e-4               # BarycentricInterpolator.MIN_AREA (bpw:121)
+SIDE_FRONT, SIDE_BACK, SIDE_OTHER = 1, 2, 3
+
+
+class PartTables(object):
+    """Plain attribute bag; see ``build_part_tables`` for the fields."""
+
+    def summary(self):
+        return {'P': int(self.sample_pos.shape[0]), 'T': int(self.tri_side.shape[0]),
+                'T_front': int((self.tri_side == SIDE_FRONT).sum()),
+                'V': int(self.vertices.shape[0]), 'V_front': int(self.vertex_is_side.sum()),
+                'collision_triangles': int(self.col_v0.shape[0]),
+                'start_anchor': len(self.anchor_points), 'start_all': len(self.all_points),
+                'density': float(self.density), 'beams': int(self.beams.shape[0])}
+
+
+# ----------------------------------------------------------------------------
+# small restatements of reference helpers
+# ----------------------------------------------------------------------------
+def normalize_tuple(v, tolerance=0.00001):
+    """bpw.normalize (32-37): renormalise only when | |v|^2 - 1 | > tolerance."""
+    mag2 = sum(n * n for n in v)
+    if abs(mag2 - 1.0) > tolerance:
+        mag = np.sqrt(mag2)
+        v = tuple(n / mag for n in v)
+    return v
+
+
+def included_angle(a, b):
+    """bpw._get_included_angle (1207-1216) without the list-identity shortcut."""
+    d = np.dot(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    if d > 1:
+        d = 1
+    elif d < -1:
+        d = -1
+    return np.arccos(d)
+
+
+def pose_orn_quaternion(orn):
+    """robot.get_pose_orn (rob:93-100): shortest-arc quaternion z -> orn, xyzw."""
+    xyz = [0.0 * orn[2] - 1.0 * orn[1], 1.0 * orn[0] - 0.0 * orn[2], 0.0 * orn[1] - 0.0 * orn[0]]
+    w = float(1 + (0.0 * orn[0] + 0.0 * orn[1] + 1.0 * orn[2]))
+    xyz.append(w)
+    return tuple(float(c) for c in normalize_tuple(xyz))
+
+
+def bary_coords(P, A, V0, V1, D00, D01, D11, INV):
+    """BarycentricInterpolator._get_bary_coordinate (154-163), row-wise."""
+    v2 = P - A
+    d20 = geo.dot_fma(v2, V0)
+    d21 = geo.dot_fma(v2, V1)
+    v = (D11 * d20 - D01 * d21) * INV
+    w = (D00 * d21 - D01 * d20) * INV
+    u = 1.0 - v - w
+    deg = (INV == 0)
+    if np.ndim(deg) == 0:
+        if deg:
+            return -1.0, -1.0, -1.0
+        return u, v, w
+    u = np.where(deg, -1.0, u)
+    v = np.where(deg, -1.0, v)
+    w = np.where(deg, -1.0, w)
+    return u, v, w
+
+
+def _bary_setup(a, b, c):
+    v0 = b - a
+    v1 = c - a
+    d00 = geo.dot_fma(v0, v0)
+    d01 = geo.dot_fma(v0, v1)
+    d11 = geo.dot_fma(v1, v1)
+    denom = d00 * d11 - d01 * d01
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = np.where(denom != 0, 1.0 / np.where(denom != 0, denom, 1.0), 0.0)
+    return v0, v1, d00, d01, d11, inv
+
+
+def _side_of_normals(vn, a0):
+    """_get_side (1219-1229) applied as set_side does: included angle of vn to +/-front <= pi/3."""
+    n0 = vn[:, a0]
+    lim = np.pi / 3
+    with np.errstate(invalid='ignore'):
+        ang_f = np.arccos(np.clip(n0, -1.0, 1.0))
+        ang_b = np.arccos(np.clip(-n0, -1.0, 1.0))
+        front = ang_f <= lim
+        back = (~front) & (ang_b <= lim)
+    side = np.full(vn.shape[0], SIDE_OTHER, dtype=np.int8)
+    side[back] = SIDE_BACK
+    side[front] = SIDE_FRONT
+    return side
+
+
+# ----------------------------------------------------------------------------
+# the builder
+# ----------------------------------------------------------------------------
+def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, collision_mode='hull',
+                      base_position=obj_io.PART_BASE_POSITION, name=None, verbose=False):
+    """Build the static tables of one part for painting its FRONT side.
+
+    Either ``urdf_path`` (resolved like the reference does) or ``mesh``
+    (an ``obj_io.MeshData``) plus ``tex_size`` must be given.
+    """
+    if mesh is None:
+        obj_path, tex_path = obj_io.resolve_part_files(urdf_path)
+        mesh = obj_io.read_obj(obj_path)
+        if tex_size is None:
+            tex_size = obj_io.texture_size(tex_path)
+        if name is None:
+            name = urdf_path
+    W, H = int(tex_size[0]), int(tex_size[1])
+    t = PartTables()
+    t.name = name or 'part'
+    t.tex_w, t.tex_h = W, H
+    t.collision_mode = collision_mode
+    t.obs_grad = int(obs_grad)
+
+    # -- global frame, axes (bpw:1176-1182, 1294-1300, 498-500) ----------------
+    V = np.asarray(base_position, dtype=np.float64)[None, :] + mesh.vertices
+    (a1, a2), a0 = obj_io.principal_axes(V)
+    t.vertices = V
+    t.a0, t.a1, t.a2 = a0, a1, a2
+    front_normal = np.array([1.0 if k == a0 else 0.0 for k in range(3)])
+    F = mesh.faces_v
+    T = F.shape[0]
+
+    # -- per-triangle records --------------------------------------------------
+    A, B, C = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+    v0, v1, d00, d01, d11, inv = _bary_setup(A, B, C)
+    crs = geo.cross3(v0, v1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        nrm = np.sqrt(geo.dot_fma(crs, crs))
+        area = nrm / 2
+        vn = crs / nrm[:, None]
+    center = ((A + B) + C) / 3
+    side = _side_of_normals(vn, a0)
+    t.tri_vidx = F.astype(np.int32)
+    t.tri_side = side
+    t.tri_area = area
+    t.tri_area_valid = area >= MIN_AREA
+    t.tri_center = center
+    t.tri_a, t.tri_v0, t.tri_v1 = A, v0, v1
+    t.tri_d00, t.tri_d01, t.tri_d11, t.tri_inv = d00, d01, d11, inv
+    normals = [tuple(row) for row in vn]        # mutable per-triangle normals, reference style
+    front_ids = np.nonzero(side == SIDE_FRONT)[0]
+
+    # -- UV rasterisation -> samples (front) ------------------------------------
+    t.sample_pix, t.sample_pos = _rasterise_side(mesh, V, F, front_ids, W, H)
+    if verbose:
+        print('samples', t.sample_pix.shape[0])
+
+    # -- per-side vertex set (bpw:599-620) ---------------------------------------
+    has_front = np.zeros(V.shape[0], dtype=bool)
+    has_front[F[front_ids].ravel()] = True
+    in_face = np.zeros(V.shape[0], dtype=bool)
+    in_face[F.ravel()] = True
+    side_data = V.copy()
+    side_data[in_face & ~has_front] = IRRELEVANT
+    relevant = side_data[:, 0] != IRRELEVANT
+    relevant &= in_face      # a vertex in no face has no triangle to hook onto
+    t.vertex_is_side = relevant
+    # vertex -> incident front triangles in file order (uv_map restricted to the side)
+    adj = [[] for _ in range(V.shape[0])]
+    for ti in front_ids:
+        for vi in F[ti]:
+            adj[vi].append(int(ti))
+    t.vertex_adj = adj
+
+    # -- ranges, anchor start points (uncorrected normals!) ----------------------
+    t.ranges = _ranges(V, a1, a2)
+    corner_points = _corner_points(V, a1, a2)
+    t._side_data = side_data
+    t._normals = normals
+    t.anchor_points = []
+    for cp in corner_points:
+        hp = hook_point(t, cp)
+        if hp is not None:
+            t.anchor_points.append(hp)
+
+    # -- collision set + grid rows -----------------------------------------------
+    tri = geo.collision_triangles(V, F, collision_mode, (a1, a2))
+    t.col_v0, t.col_e1, t.col_e2 = geo.pack_collision_triangles(tri)
+    t.lwr = (t.ranges[0][1] - t.ranges[0][0]) / (t.ranges[1][1] - t.ranges[1][0])
+    t.grid_lo, t.grid_hi, t.vertices_mutated = _grid_rows(t)
+    t.grid_range = t.grid_hi - t.grid_lo
+    t.max_grid_size = float(t.grid_range.max())
+
+    # -- normal correction + smoothing -------------------------------------------
+    t.n_hull_corrected = _correct_with_hull(t, front_ids, front_normal)
+    t.n_smoothed = _smooth_with_neighbours(t, front_ids)
+    t.tri_normal = np.array([[float(c) for c in n] for n in normals], dtype=np.float64)
+
+    # -- observation cells, start points, density, beams --------------------------
+    t.sample_cell = grid_observation_cells(t, obs_grad)
+    t.all_points = _all_start_points(t, front_ids)
+    t.edge_points = _edge_start_points(t, t.all_points)
+    step = (t.ranges[1][1] - t.ranges[1][0]) / GRID_GRANULARITY
+    area_size = 0
+    for gx in t.grid_range:
+        area_size += step * gx
+    t.density = t.sample_pos.shape[0] / area_size
+    t.beams = cone_beams(t.density)
+    t.front_ids = front_ids
+    return t
+
+
+def _rasterise_side(mesh, V, F, tri_ids, W, H):
+    """Walk the side's triangles in file order; the last triangle covering a
+    pixel defines that pixel's 3-D position (bpw:622-645, 192-212)."""
+    pos_map = np.zeros((H * W, 3), dtype=np.float64)
+    have = np.zeros(H * W, dtype=bool)
+    uvs = mesh.uvs
+    FT = mesh.faces_vt
+    for ti in tri_ids:
+        uv = uvs[FT[ti]]                                   # (3,2) float UVs, v already flipped
+        pi = np.minimum(np.rint(W * uv[:, 0]).astype(np.int64), W - 1)   # round-half-even
+        pj = np.minimum(np.rint(H * uv[:, 1]).astype(np.int64), H - 1)
+        if pi.min() < 0 or pj.min() < 0:
+            raise NotImplementedError('negative texel coordinate (UV outside [0,1]) is not supported')
+        P3 = V[F[ti]]
+        for k in range(3):                                 # corner pixels, c over b over a
+            idx = pi[k] + pj[k] * W
+            pos_map[idx] = P3[k]
+            have[idx] = True
+        b0, b1, e00, e01, e11, einv = _bary_setup(uv[0], uv[1], uv[2])
+        if einv == 0:
+            continue
+        us = np.arange(pi.min(), pi.max() + 1)
+        vs = np.arange(pj.min(), pj.max() + 1)
+        uu, vv = np.meshgrid(us, vs, indexing='ij')
+        uu = uu.ravel()
+        vv = vv.ravel()
+        rel = np.stack([uu / W, vv / H], axis=1)
+        bu, bv, bw = bary_coords(rel, uv[0][None, :], b0[None, :], b1[None, :], e00, e01, e11, einv)
+        inside = (bu >= 0) & (bu <= 1) & (bv >= 0) & (bv <= 1) & (bw >= 0) & (bw <= 1)
+        if not inside.any():
+            continue
+        bu, bv, bw = bu[inside], bv[inside], bw[inside]
+        p = (bu[:, None] * P3[0][None, :] + bv[:, None] * P3[1][None, :]) + bw[:, None] * P3[2][None, :]
+        idx = uu[inside] + vv[inside] * W
+        pos_map[idx] = p
+        have[idx] = True
+    if have[H * W - 1]:
+        raise NotImplementedError('texel (W-1,H-1) in the profile hits the reference get_texel clamp (bpw:505-506)')
+    lin = np.nonzero(have)[0]
+    pix = np.stack([lin % W, lin // W], axis=1).astype(np.int32)
+    return pix, pos_map[lin].copy()
+
+
+def _ranges(V, a1, a2):
+    return [[float(V[:, a1].min()), float(V[:, a1].max())], [float(V[:, a2].min()), float(V[:, a2].max())]]
+
+
+def _corner_points(V, a1, a2):
+    """_get_corner_points_ranges (1256-1286): stable-sort extremes of a1+a2 and a1-a2."""
+    shrink = PAINT_RADIUS / 2
+    s = V[:, a1] + V[:, a2]
+    d = V[:, a1] - V[:, a2]
+    first_min = lambda k: int(np.argmin(k))                       # noqa: E731
+    last_max = lambda k: int(len(k) - 1 - np.argmax(k[::-1]))     # noqa: E731
+    out = []
+    for idx, (s1, s2) in ((first_min(s), (+1, +1)), (last_max(s), (-1, -1)),
+                          (first_min(d), (+1, -1)), (last_max(d), (-1, +1))):
+        p = [float(c) for c in V[idx]]
+        p[a1] += s1 * shrink
+        p[a2] += s2 * shrink
+        out.append(p)
+    return out
+
+
+def nearest_side_vertex(t, point):
+    """cKDTree.query(k=1) over the side's vertex set (bpw:526): exact Euclidean NN."""
+    d = t._side_data[t.vertex_is_side] - np.asarray(point, dtype=np.float64)[None, :]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    return int(np.nonzero(t.vertex_is_side)[0][int(np.argmin(d2))])
+
+
+def closest_triangle(t, point, vertex):
+    """Part._get_closest_bary (508-523) over the vertex's same-side triangles."""
+    best = None
+    best_uvw = -1
+    point = np.asarray(point, dtype=np.float64)
+    for ti in t.vertex_adj[vertex]:
+        u, v, w = bary_coords(point, t.tri_a[ti], t.tri_v0[ti], t.tri_v1[ti],
+                              t.tri_d00[ti], t.tri_d01[ti], t.tri_d11[ti], t.tri_inv[ti])
+        if 0 <= u <= 1 and 0 <= v <= 1 and 0 <= w <= 1:
+            return ti
+        if best is None:
+            best = ti
+        m = min(u, v, w)
+        if m >= best_uvw:
+            best_uvw = m
+            best = ti
+    return best
+
+
+def hook_point(t, point):
+    """Part._get_hook_point (525-534): [pose, orn] or None."""
+    vtx = nearest_side_vertex(t, point)
+    ti = closest_triangle(t, point, vtx)
+    if ti is None:
+        return None
+    n = t._normals[ti]
+    pose = [a + b for a, b in zip(point, [i * HOOK_DISTANCE_TO_PART for i in n])]
+    orn = [-i for i in n]
+    return [[float(c) for c in pose], [float(c) for c in orn]]
+
+
+def grid_index_2(t, val_axis_2):
+    """Part._get_grid_index_2 (844-851)."""
+    rel = (val_axis_2 - t.ranges[1][0]) / (t.ranges[1][1] - t.ranges[1][0])
+    gi = int(rel * GRID_GRANULARITY)
+    if gi < 0:
+        return 0
+    if gi > GRID_GRANULARITY - 1:
+        return GRID_GRANULARITY - 1
+    return gi
+
+
+def normalized_pose(t, pose):
+    """Part.get_normalized_pose (965-978)."""
+    r = PAINT_RADIUS
+    x1 = pose[t.a1]
+    x2 = pose[t.a2]
+    in2 = (x2 - t.ranges[1][0] + r) / (t.ranges[1][1] - t.ranges[1][0] + 2 * r)
+    gi = grid_index_2(t, x2)
+    lo, hi = t.grid_lo[gi], t.grid_hi[gi]
+    if hi - lo == 0:
+        in1 = 0
+    else:
+        in1 = (x1 - lo + r) / (hi - lo + 2 * r)
+    clip = lambda v: 0.0 if v < 0 else (1.0 if v > 1 else float(v))   # noqa: E731
+    return clip(in1), clip(in2)
+
+
+def _exact_boundary(t, point, is_min):
+    """Part._get_exact_boundary (906-920): walk outward in 1e-3 steps until the
+    first ray (along the non-principal axis, growing by 1 per step at both ends) misses."""
+    step = -1e-3 if is_min else 1e-3
+    n_steps = int((t.ranges[0][1] - t.ranges[0][0]) / abs(step))
+    base = [float(c) for c in point]
+    lo_c = base[t.a0]
+    hi_c = base[t.a0]
+    chunk = 16
+    i = 0
+    while i < n_steps:
+        m = min(chunk, n_steps - i)
+        org = np.tile(np.asarray(base), (m, 1))
+        dst = org.copy()
+        cur = np.empty(m)
+        for k in range(m):
+            cur[k] = base[t.a1] + (i + k) * step
+            lo_c -= 1
+            hi_c += 1
+            org[k, t.a0] = lo_c
+            dst[k, t.a0] = hi_c
+        org[:, t.a1] = cur
+        dst[:, t.a1] = cur
+        idx, _, _ = geo.ray_closest_hit(t.col_v0, t.col_e1, t.col_e2, org, dst)
+        miss = np.nonzero(idx < 0)[0]
+        if miss.size:
+            return float(cur[miss[0]])
+        i += m
+        chunk = min(chunk * 2, 256)
+    return None
+
+
+def _grid_rows(t):
+    """Part._set_grid_dict (922-963), including the in-place mutation of the
+    side's vertex array on sparse rows."""
+    a1, a2 = t.a1, t.a2
+    data = t._side_data                     # mutated in place, like cKDTree.data in the reference
+    ids = np.nonzero(data[:, 0] != IRRELEVANT)[0]
+    order = list(ids[np.argsort(data[ids, a2], kind='stable')])
+    axis2_range = t.ranges[1][1] - t.ranges[1][0]
+    step = axis2_range / GRID_GRANULARITY
+    grid = {}
+    traverse = 0
+    left = right = order[0]
+    mutated = set()
+    for i in range(GRID_GRANULARITY):
+        cur = traverse
+        step_max = t.ranges[1][0] + (i + 1) * step
+        for index in range(cur, len(order)):
+            if data[order[index], a2] >= step_max:
+                if index - cur <= 1:
+                    new_a2 = step_max + 0.5 * step
+                    if (i - 1) not in grid:
+                        new_a1 = data[order[index], a1]
+                    else:
+                        new_a1 = (grid[i - 1][0] + grid[i - 1][1]) / 2
+                    data[left, a2] = new_a2
+                    data[right, a2] = new_a2
+                    data[left, a1] = new_a1
+                    data[right, a1] = new_a1
+                    mutated.update((int(left), int(right)))
+                else:
+                    target = order[cur:index]
+                    keys = np.array([data[v, a1] for v in target])
+                    srt = np.argsort(keys, kind='stable')
+                    left = target[srt[0]]
+                    right = target[srt[-1]]
+                rmin = _exact_boundary(t, data[left], True)
+                rmax = _exact_boundary(t, data[right], False)
+                if rmin is None or rmax is None:
+                    raise RuntimeError('grid row %d: boundary walk never left the part' % i)
+                grid[i] = (rmin, rmax)
+                traverse = index + 1
+                break
+        else:
+            grid[i] = (0.0, 0.0)
+    lo = np.array([grid[i][0] for i in range(GRID_GRANULARITY)], dtype=np.float64)
+    hi = np.array([grid[i][1] for i in range(GRID_GRANULARITY)], dtype=np.float64)
+    return lo, hi, sorted(mutated)
+
+
+def _correct_with_hull(t, front_ids, front_normal):
+    """ConvHull.separate_by_side + correct_bary_normal for the front side (bpw:61-104, 650-660)."""
+    from scipy.spatial import ConvexHull
+    V = t.vertices
+    a0, a1, a2 = t.a0, t.a1, t.a2
+    simplices = ConvexHull(V).simplices
+    keep = (t._side_data[simplices][:, :, 0] != IRRELEVANT).sum(axis=1) >= 2
+    S = simplices[keep]
+    if S.shape[0] == 0:
+        return 0
+    HA, HB, HC = V[S[:, 0]], V[S[:, 1]], V[S[:, 2]]
+    hcr = geo.cross3(HB - HA, HC - HA)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        hn = hcr / np.sqrt(geo.dot_fma(hcr, hcr))[:, None]
+    hside = _side_of_normals(hn, a0)
+    hn = np.where((hside != SIDE_FRONT)[:, None], -hn, hn)
+    ax = [a1, a2]
+    h2a = HA[:, ax]
+    h2v0, h2v1, h00, h01, h11, hinv = _bary_setup(HA[:, ax], HB[:, ax], HC[:, ax])
+    count = 0
+    normals = t._normals
+    for ti in front_ids:
+        c = t.tri_center[ti]
+        rel = normalized_pose(t, c)
+        if rel[0] <= 0.01 or rel[0] >= 0.99 or rel[1] <= 0.01 or rel[1] >= 0.99:
+            continue
+        p2 = np.array([c[a1], c[a2]])[None, :]
+        u, v, w = bary_coords(p2, h2a, h2v0, h2v1, h00, h01, h11, hinv)
+        inside = (u >= 0) & (u <= 1) & (v >= 0) & (v <= 1) & (w >= 0) & (w <= 1)
+        hit = np.nonzero(inside)[0]
+        if hit.size == 0:
+            continue
+        k = int(hit[0])
+        fn = [float(x) for x in hn[k]]
+        if included_angle(normals[ti], fn) > np.pi / 6:
+            normals[ti] = tuple(fn)
+            count += 1
+    return count
+
+
+def _smooth_with_neighbours(t, front_ids):
+    """_smooth_bary_normals_with_neighbors / _smooth_normal (bpw:662-698):
+    sequential and in place, later triangles see earlier replacements."""
+    from scipy.spatial import cKDTree
+    T = t.tri_side.shape[0]
+    centers = np.full((T, 3), IRRELEVANT, dtype=np.float64)
+    centers[front_ids] = t.tri_center[front_ids]
+    tree = cKDTree(centers)
+    normals = t._normals
+    count = 0
+    k = min(5, T)
+    for ti in front_ids:
+        nb = np.atleast_1d(tree.query(t.tri_center[ti], k=k)[1])
+        for b in nb:
+            if b == ti or b >= T:
+                continue
+            ang = included_angle(normals[b], normals[ti])
+            if abs(ang) > np.pi / 18:
+                near = tree.query_ball_point(t.tri_center[ti], PAINT_RADIUS)
+                weighted = []
+                for bi in near:
+                    if bi != ti:
+                        weighted.append([t.tri_area[bi] * c for c in normals[bi]])
+                if weighted:
+                    avg = np.average(weighted, 0)
+                    new = normalize_tuple(avg)
+                    normals[ti] = tuple(float(c) for c in new)
+                    count += 1
+                break
+    return count
+
+
+def grid_observation_cells(t, h):
+    """GridObservation cell of every sample as v_target*h + h_grid (bpw:1072-1101)."""
+    a1, a2 = t.a1, t.a2
+    step2 = (t.ranges[1][1] - t.ranges[1][0]) / GRID_GRANULARITY
+    v_interval = int(GRID_GRANULARITY / h)
+    cells = np.zeros(t.sample_pos.shape[0], dtype=np.int32)
+    for s, p in enumerate(t.sample_pos):
+        y_grid = min(GRID_GRANULARITY - 1, int((p[a2] - t.ranges[1][0]) / step2))
+        gr = t.grid_range[y_grid]
+        if gr == 0:
+            x_grid = 0
+        else:
+            x_step = gr / h
+            x_grid = min(h - 1, int((p[a1] - t.grid_lo[y_grid]) / x_step))
+        v_target = y_grid // v_interval
+        if not (0 <= x_grid < h and 0 <= v_target < h):
+            raise KeyError('sample %d falls outside the %dx%d observation grid (reference raises KeyError)'
+                           % (s, h, h))
+        cells[s] = v_target * h + x_grid
+    return cells
+
+
+def _all_start_points(t, front_ids):
+    """The 'all' candidates of Part.get_start_points (749-773), file order, corrected normals."""
+    shrink = PAINT_RADIUS / 2
+    a1, a2 = t.a1, t.a2
+    ax2 = [p[0][a2] for p in t.anchor_points]
+    ax2_max, ax2_min = max(ax2), min(ax2)
+    out = []
+    for ti in front_ids:
+        if not t.tri_area_valid[ti]:
+            continue
+        c = t.tri_center[ti]
+        n = t._normals[ti]
+        gi = grid_index_2(t, c[a2])
+        lo, hi = t.grid_lo[gi], t.grid_hi[gi]
+        if c[a1] - lo >= shrink and hi - c[a1] >= shrink and ax2_min <= c[a2] <= ax2_max:
+            hook = [a + b for a, b in zip(c, [i * HOOK_DISTANCE_TO_PART for i in n])]
+            out.append([[float(x) for x in hook], [float(-i) for i in n]])
+    return out
+
+
+def _edge_start_points(t, points):
+    """Part._get_edge_start_points (785-809)."""
+    if not points:
+        return []
+    a1, a2 = t.a1, t.a2
+    rows = {}
+    for p, o in points:
+        rows.setdefault(grid_index_2(t, p[a2]), []).append([p, o])
+    mx, mn = max(rows), min(rows)
+    out = []
+    for gi, lst in rows.items():
+        if gi in (mx, mn):
+            out.extend(lst)
+        else:
+            srt = sorted(lst, key=lambda v: v[0][a1])
+            if (srt[0][0][a1] - t.grid_lo[gi]) / t.grid_range[gi] < 0.15:
+                out.append(srt[0])
+            if (t.grid_hi[gi] - srt[-1][0][a1]) / t.grid_range[gi] < 0.15:
+                out.append(srt[-1])
+    return out
+
+
+def start_points(t, mode='anchor'):
+    """Part.get_start_points (749-783): list of [pose, orn]."""
+    if mode == 'fixed':
+        return [t.anchor_points[0]]
+    if mode == 'anchor':
+        return list(t.anchor_points)
+    if mode == 'edge':
+        return list(t.anchor_points) + list(t.edge_points)
+    if mode == 'all':
+        return list(t.anchor_points) + list(t.all_points)
+    raise ValueError('unknown START_POINT_MODE %r' % (mode,))
+
+
+def cone_beams(density):
+    """robot._get_uniformed_plain (rob:23-35): beam end points in the tool frame."""
+    ratio = 0.2 / 0.5
+    radius = 0.25 * ratio
+    resolution = 1.8 / math.sqrt(density)
+    plane = 0.2
+    out = []
+    i = j = -radius
+    while i <= radius:
+        while j <= radius:
+            if math.sqrt(math.pow(i, 2) + math.pow(j, 2)) <= radius:
+                out.append((i, j, plane))
+            j += resolution
+        i += resolution
+        j = -radius
+    return np.asarray(out, dtype=np.float64).reshape(-1, 3)
