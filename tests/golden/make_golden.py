@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Development container only (needs /root/reference).  The reference's Python is
+imported against tests/golden/refstubs (pybullet/gym/termcolor stand-ins, see
+refstubs/pybullet.py for the two calls that carry arithmetic) and driven on the
+synthetic parts written by paintrl_amd.synth_parts.  What is stored is data
+only: action sequences, start indices, per-step (obs, reward, done, info),
+painted-texel snapshots, final pose/return, static-table digests (SURVEY.md §8c
+G0-G6).  No reference source is stored.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from paintrl_amd import synth_parts  # noqa: E402
+
+SNAP_EVERY = 25
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class RefDriver(object):
+    """One constructed reference env (START_POINT_MODE='all'), re-configured in place per episode."""
+
+    def __init__(self, root, part_no):
+        t0 = time.time()
+        self.env, self.part = ref_import.make_env(root, part_no=part_no, obs_mode='section', obs_grad=4,
+                                                  extra={'START_POINT_MODE': 'all'})
+        self.construct_s = time.time() - t0
+        self.bpw = sys.modules['bullet_paint_wrapper']
+        self.rob = sys.modules['robot']
+        self.rge = sys.modules['robot_gym_env']
+        self.all_points = list(self.env._start_points)
+        self.F = self.bpw.Side.front
+        W = self.part.texture_width
+        self.pix = sorted(self.part.profile[self.F], key=lambda p: p[1] * W + p[0])
+        self.part_no = part_no
+
+    def configure(self, obs_mode='section', obs_grad=4, start_mode='anchor', overlap=False, turning=False,
+                  termination='late', paint_method='fast', action=('discrete', 1, 4), max_len=245, rollout=False):
+        env, part, bpw = self.env, self.part, self.bpw
+        cls = self.rge.PaintGymEnv
+        cls.OBS_MODE, cls.OBS_GRAD = obs_mode, obs_grad
+        mode, shape, gran = action
+        cls.change_action_mode(shape, mode, gran)
+        if obs_mode in ('section', 'discrete'):
+            part._obs_handler = bpw.SectionObservation(part, obs_grad)
+        elif obs_mode == 'grid':
+            part._obs_handler = bpw.GridObservation(part, obs_grad)
+        else:
+            part._obs_handler = bpw.NoObservation(part)
+        n = {'fixed': 1, 'anchor': 4, 'all': len(self.all_points)}[start_mode]
+        env._start_points = self.all_points[:n]
+        env.OVERLAP_PENALTY, env.TURNING_PENALTY = overlap, turning
+        env.TERMINATION_MODE = termination
+        env.EPISODE_MAX_LENGTH = max_len
+        env._rollout = rollout
+        self.rob.Robot.PAINT_METHOD = paint_method
+        self.cfg = dict(obs_mode=obs_mode, obs_grad=obs_grad, start_mode=start_mode, overlap_penalty=overlap,
+                        turning_penalty=turning, termination_mode=termination, paint_method=paint_method,
+                        action_mode=mode, action_dim=shape, n_discrete=gran, max_episode_len=max_len,
+                        expected_episode_len=env.Expected_Episode_Length, switch_threshold=env.SWITCH_THRESHOLD,
+                        max_possible_point=env._max_possible_point, part_no=self.part_no)
+
+    def reset(self, seed):
+        random.seed(seed)
+        obs = self.env.reset()
+        pose = tuple(self.env.robot._pose)
+        idx = [tuple(p[0]) for p in self.env._start_points].index(pose)
+        return np.asarray(obs, dtype=np.float64), idx
+
+    def painted_bits(self):
+        return np.packbits(np.array([bool(self.part.get_pixel_status(p)) for p in self.pix]), bitorder='little')
+
+    def episode(self, seed, policy, max_steps=400, want_idx=None):
+        obs0, idx = self.reset(seed)
+        while want_idx is not None and idx != want_idx:      # walk seeds until the wanted start comes up
+            seed += 1000
+            obs0, idx = self.reset(seed)
+        rec = dict(actions=[], obs=[], reward=[], done=[], info=[], snaps=[], snap_steps=[])
+        obs, done, k = obs0, False, 0
+        t_step = 0.0
+        with contextlib.redirect_stdout(io.StringIO()):
+            while not done and k < max_steps:
+                a = policy(k, obs)
+                rec['actions'].append(list(a) if isinstance(a, list) else a)   # step() clips lists in place
+                t0 = time.perf_counter()
+                o, r, done, info = self.env.step(a)
+                t_step += time.perf_counter() - t0
+                obs = np.asarray(o, dtype=np.float64)
+                rec['obs'].append(obs)
+                rec['reward'].append(r)
+                rec['done'].append(done)
+                rec['info'].append([info['reward'], info['penalty']])
+                k += 1
+                if k % SNAP_EVERY == 0 or done:
+                    rec['snaps'].append(self.painted_bits())
+                    rec['snap_steps'].append(k)
+        if not rec['snap_steps'] or rec['snap_steps'][-1] != k:
+            rec['snaps'].append(self.painted_bits())
+            rec['snap_steps'].append(k)
+        out = dict(start_idx=np.int32(idx), obs0=obs0, actions=np.asarray(rec['actions']),
+                   obs=np.asarray(rec['obs']), reward=np.asarray(rec['reward'], dtype=np.float64),
+                   done=np.asarray(rec['done'], dtype=bool), info=np.asarray(rec['info'], dtype=np.float64),
+                   snaps=np.asarray(rec['snaps']), snap_steps=np.asarray(rec['snap_steps'], dtype=np.int32),
+                   final_pose=np.asarray(self.env.robot._pose, dtype=np.float64),
+                   final_quat=np.asarray(self.env.robot._orn, dtype=np.float64),
+                   total_return=np.float64(self.env._total_return), ms_per_step=np.float64(1e3 * t_step / max(k, 1)),
+                   cfg=json.dumps(self.cfg))
+        return out
+
+
+# ---- policies (this project's own drivers; zigzag follows the idea of zigzag.py:77-101) ----
+def random_policy(seed, n=4):
+    rng = np.random.RandomState(seed)
+    seq = rng.randint(0, n, size=1000)
+    return lambda k, obs: int(seq[k])
+
+
+def zigzag_policy(pos_index=-1, cols=2):
+    st = {'up': True, 'h': 0}
+
+    def pol(k, obs):
+        y = obs[pos_index]
+        while True:
+            if st['up']:
+                if y < 0.95:
+                    return 1
+                if st['h'] < cols:
+                    st['h'] += 1
+                    return 0
+                st['h'], st['up'] = 0, False
+            else:
+                if y > 0.05:
+                    return 3
+                if st['h'] < cols:
+                    st['h'] += 1
+                    return 0
+                st['h'], st['up'] = 0, True
+    return pol
+
+
+def continuous_policy(seed, dim):
+    rng = np.random.RandomState(seed)
+    seq = rng.uniform(-1.2, 1.2, size=(1000, dim))
+    if dim == 2:
+        seq[5] = 0.0
+    return lambda k, obs: [float(v) for v in seq[k]]
+
+
+def table_digest(drv):
+    """G0: digests + small slices of the reference's static tables for one part."""
+    part, env, F = drv.part, drv.env, drv.F
+    pos = np.array([part.profile_dicts[F][p] for p in drv.pix], dtype=np.float64)
+    pix = np.array(drv.pix, dtype=np.int32)
+    side_map = {drv.bpw.Side.front: 1, drv.bpw.Side.back: 2, drv.bpw.Side.other: 3}
+    sides = np.array([side_map[b.get_side()] for b in part.bary_list], dtype=np.int8)
+    normals = np.array([[float(c) for c in b.get_normal()] for b in part.bary_list], dtype=np.float64)
+    fn = normals[sides == 1]
+    lo = np.array([part.grid_dict[F][i][0] for i in range(100)], dtype=np.float64)
+    hi = np.array([part.grid_dict[F][i][1] for i in range(100)], dtype=np.float64)
+    sp = np.array(drv.all_points, dtype=np.float64)
+    kd = np.asarray(part.vertices_kd_tree[F].data, dtype=np.float64)
+    gp = drv.bpw.GridObservation(part, 4)._grid_pixels[F]
+    cell = {}
+    for i in gp:
+        for j in gp[i]:
+            for p in gp[i][j]:
+                cell[(int(p[0]), int(p[1]))] = i * 4 + j
+    cells = np.array([cell[(int(p[0]), int(p[1]))] for p in drv.pix], dtype=np.int32)
+    return dict(P=np.int32(len(drv.pix)), P_back=np.int32(len(part.profile[drv.bpw.Side.back])),
+                T=np.int32(len(part.bary_list)), V=np.int32(len(part.vertices)),
+                side_counts=np.array([(sides == k).sum() for k in (1, 2, 3)], dtype=np.int32),
+                axes=np.array(list(part.principal_axes) + [part.non_principal_axis], dtype=np.int32),
+                ranges=np.array(part.ranges, dtype=np.float64), lwr=np.float64(part._length_width_ratio),
+                grid_lo=lo, grid_hi=hi, density=np.float64(part.get_density()),
+                beams=np.array(env.robot._paint_plain, dtype=np.float64),
+                n_start_all=np.int32(len(drv.all_points)), start_points_head=sp[:40], start_points_tail=sp[-40:],
+                sha_pix=sha(pix), sha_pos=sha(pos), sha_sides=sha(sides), sha_front_normals=sha(fn),
+                sha_start_points=sha(sp), sha_side_vertices=sha(kd), sha_cells4=sha(cells),
+                pix_head=pix[:32], pix_tail=pix[-32:], pos_head=pos[:32], pos_tail=pos[-32:],
+                normals_head=fn[:32], normals_tail=fn[-32:], construct_s=np.float64(drv.construct_s))
+
+
+def param_test_golden(pte):
+    """G1: ParamTestEnv trajectories under this project's zigzag / spiral drivers."""
+    out = {}
+
+    def run(size, policy_name):
+        env = pte.ParamTestEnv(size, train_mode=True)
+        obs = env.reset()
+        acts, O, R, D = [], [obs], [], []
+        done = False
+        st = {'up': True, 'h': 0, 'direction': 0, 'strait': size - 3, 'cur': size - 3, 'use': 3}
+        while not done:
+            if policy_name == 'zigzag':
+                cur = round(size * obs[-1])
+                a = None
+                while a is None:
+                    if st['up']:
+                        if cur % size != size - 2:
+                            a = 1
+                        elif st['h'] < 1:
+                            a, st['h'] = 0, st['h'] + 1
+                        else:
+                            st['h'], st['up'] = 0, False
+                    else:
+                        if cur % size != 1:
+                            a = 3
+                        elif st['h'] < 1:
+                            a, st['h'] = 0, st['h'] + 1
+                        else:
+                            st['h'], st['up'] = 0, True
+            else:
+                st['cur'] -= 1
+                a = st['direction'] % 4
+            obs, r, done, info = env.step(a)
+            if policy_name == 'spiral' and st['cur'] == 0:
+                st['direction'] += 1
+                st['use'] -= 1
+                if st['use'] <= 0:
+                    st['use'] = 2
+                    st['strait'] -= 1
+                st['cur'] = st['strait']
+            acts.append(a)
+            O.append(obs)
+            R.append(r)
+            D.append(done)
+        return dict(actions=np.asarray(acts, dtype=np.int32), obs=np.asarray(O, dtype=np.float64),
+                    reward=np.asarray(R, dtype=np.float64), done=np.asarray(D, dtype=bool))
+
+    for size, pol in ((22, 'zigzag'), (20, 'spiral'), (14, 'zigzag')):
+        r = run(size, pol)
+        for k, v in r.items():
+            out['%s%d_%s' % (pol, size, k)] = v
+    return out
+
+
+def main():
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    rge, bpw, rob, pte, stub = ref_import.load_reference('hull')
+    meta = {'stub_version': stub.STUB_VERSION, 'collision_mode': stub.COLLISION_MODE,
+            'numpy': np.__version__, 'generated_by': 'tests/golden/make_golden.py'}
+    np.savez_compressed(os.path.join(HERE, 'g1_param_test.npz'), **param_test_golden(pte))
+
+    timings = {}
+    # ---------------- door ----------------
+    door = RefDriver(root, 0)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_door.npz'), **table_digest(door))
+    eps = {}
+    door.configure('section', 4, 'anchor')
+    for s in range(4):                       # G3: seeded random episodes, anchor starts
+        eps['g3_random_%d' % s] = door.episode(100 + s, random_policy(10 + s))
+    eps['g3_sweep'] = door.episode(7, zigzag_policy(-1, 2), max_steps=245, want_idx=0)
+    eps['g3_serpentine'] = door.episode(8, zigzag_policy_grid(), max_steps=245, want_idx=0)
+    timings['door_section_ms_per_step'] = float(eps['g3_serpentine']['ms_per_step'])
+    door.configure('grid', 4, 'anchor', overlap=True)
+    eps['g4_grid_overlap'] = door.episode(21, zigzag_policy_grid(), max_steps=120, want_idx=0)
+    timings['door_grid_ms_per_step'] = float(eps['g4_grid_overlap']['ms_per_step'])
+    door.configure('grid', 4, 'anchor', overlap=True, turning=True)
+    eps['g4_grid_overlap_turning'] = door.episode(22, zigzag_policy_grid(), max_steps=60, want_idx=3)
+    door.configure('section', 4, 'all')
+    for s in range(6):                       # G5: 'all' starts, includes off-part terminations
+        eps['g5_all_%d' % s] = door.episode(200 + s, random_policy(40 + s), max_steps=245)
+    door.configure('simple', 4, 'anchor', action=('continuous', 1, 4))
+    eps['g7_cont1'] = door.episode(300, continuous_policy(50, 1), max_steps=40, want_idx=0)
+    door.configure('section', 4, 'anchor', action=('continuous', 2, 4), turning=True)
+    eps['g7_cont2'] = door.episode(301, continuous_policy(51, 2), max_steps=40, want_idx=0)
+    door.configure('discrete', 4, 'anchor', termination='early')
+    eps['g8_early'] = door.episode(302, zigzag_policy_discrete(), max_steps=80, want_idx=0)
+    door.configure('section', 4, 'anchor', termination='hybrid', action=('discrete', 1, 8))
+    eps['g8_hybrid_gran8'] = door.episode(303, random_policy(60, 8), max_steps=80, want_idx=0)
+    door.configure('section', 4, 'anchor', paint_method='normal')
+    eps['g6_normal_door'] = door.episode(304, zigzag_policy(-1, 2), max_steps=12, want_idx=0)
+    save_episodes('door', eps)
+
+    # ---------------- sheet ----------------
+    door.env.close()          # one part per physics client: drop the door's collision body
+    sheet = RefDriver(root, 1)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_sheet.npz'), **table_digest(sheet))
+    eps = {}
+    sheet.configure('simple', 4, 'fixed', rollout=True)
+    eps['g2_zigzag'] = sheet.episode(0, zigzag_policy(1, 2), max_steps=300)   # zigzag.py:77-101 idea
+    timings['sheet_simple_ms_per_step'] = float(eps['g2_zigzag']['ms_per_step'])
+    sheet.configure('section', 4, 'all')
+    for s in range(2):
+        eps['g5_all_%d' % s] = sheet.episode(400 + s, random_policy(70 + s), max_steps=245)
+    sheet.configure('section', 4, 'fixed', paint_method='normal', rollout=True)
+    eps['g6_normal'] = sheet.episode(0, zigzag_policy(-1, 2), max_steps=20)
+    save_episodes('sheet', eps)
+
+    meta['timings'] = timings
+    meta['ray_seconds_total'] = float(stub.RAY_SECONDS[0])
+    with open(os.path.join(HERE, 'MANIFEST.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta, indent=1))
+
+
+def zigzag_policy_grid():
+    """Grid obs carries no pose: a fixed on-part serpentine (up 12, right 2, down 12, right 2 ...)."""
+    seq = ([1] * 12 + [0] * 2 + [3] * 12 + [0] * 2) * 10
+    return lambda k, obs: seq[k]
+
+
+def zigzag_policy_discrete():
+    seq = ([1] * 14 + [0] * 2 + [3] * 14 + [0] * 2) * 10
+    return lambda k, obs: seq[k]
+
+
+def save_episodes(tag, eps):
+    flat = {}
+    for name, ep in eps.items():
+        for k, v in ep.items():
+            flat['%s/%s' % (name, k)] = v
+    flat['episodes'] = json.dumps(sorted(eps))
+    np.savez_compressed(os.path.join(HERE, 'episodes_%s.npz' % tag), **flat)
+    for name, ep in sorted(eps.items()):
+        print('%-6s %-26s steps %3d  return %8.3f  done %s  painted %d' % (
+            tag, name, len(ep['actions']), float(ep['total_return']), bool(ep['done'][-1]),
+            int(np.unpackbits(ep['snaps'][-1], bitorder='little').sum())))
+
+
+if __name__ == '__main__':
+    main()

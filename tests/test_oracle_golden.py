@@ -1,0 +1,56 @@
+"""Pins the CPU oracle to the golden vectors recorded from the reference itself
+(tests/golden/make_golden.py): every episode must replay exactly."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import env_kwargs_from_cfg, load_episodes, start_points_for, synthetic_tables
+
+CASES = [('door', n) for n in sorted(load_episodes('door'))] + [('sheet', n) for n in sorted(load_episodes('sheet'))]
+PART = {'door': 'door_test', 'sheet': 'square'}
+
+
+def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
+    obs0 = backend_reset(int(ep['start_idx']))
+    if exact:
+        assert np.array_equal(obs0, ep['obs0'])
+    else:
+        np.testing.assert_allclose(obs0, ep['obs0'], rtol=0, atol=atol)
+    snaps = dict(zip(ep['snap_steps'].tolist(), ep['snaps']))
+    for k, a in enumerate(ep['actions']):
+        obs, rew, done, info, bits = backend_step(a, (k + 1) in snaps)
+        if exact:
+            assert np.array_equal(obs, ep['obs'][k]), 'obs differs at step %d' % k
+            assert rew == ep['reward'][k] and info[0] == ep['info'][k, 0] and info[1] == ep['info'][k, 1], k
+        else:
+            np.testing.assert_allclose(obs, ep['obs'][k], rtol=0, atol=atol)
+            np.testing.assert_allclose([rew, info[0], info[1]],
+                                       [ep['reward'][k], ep['info'][k, 0], ep['info'][k, 1]], rtol=0, atol=atol)
+        assert bool(done) == bool(ep['done'][k]), 'done differs at step %d' % k
+        if (k + 1) in snaps:
+            want = np.unpackbits(snaps[k + 1], bitorder='little')[:bits.size].astype(bool)
+            assert np.array_equal(bits, want), 'painted texel set differs at step %d' % (k + 1)
+
+
+@pytest.mark.parametrize('tag,name', CASES)
+def test_oracle_replays_reference_episode(tag, name):
+    ep = load_episodes(tag)[name]
+    cfg = ep['cfg']
+    tables = synthetic_tables(PART[tag])
+    orc = oracle.Oracle(tables, 1, start_points=start_points_for(tables, cfg['start_mode']),
+                        **env_kwargs_from_cfg(cfg))
+    continuous = cfg['action_mode'] == 'continuous'
+
+    def reset(idx):
+        return orc.reset([idx])[0]
+
+    def step(a, want_bits):
+        obs, rew, done, info = orc.step([a])
+        return obs[0], rew[0], done[0], info[0], orc.painted_bits(0)
+
+    # continuous actions go through libm sin/cos/atan2 on both sides: tolerance, not bit-exact
+    replay(step, reset, ep, exact=not continuous, atol=1e-9)
+    st = orc.state(0)
+    if not continuous:
+        assert np.array_equal(st['pose'], ep['final_pose']) and np.array_equal(st['quat'], ep['final_quat'])
+        assert st['total_return'] == float(ep['total_return'])
