@@ -1,0 +1,166 @@
+/*
+ * paintrl.h -- C ABI of the MI355X batched paint-coverage simulator.
+ *
+ * The reference (translearn/PaintRL) is pure Python and has no FFI layer; its
+ * boundary for this path is the module-level simulator API of
+ * PaintRLEnv/bullet_paint_wrapper.py:1327-1400 (load_part, fast_paint, paint,
+ * get_guided_point, get_observation, get_normalized_pose, reset_part,
+ * get_job_status ...) as driven by Robot.apply_action (PaintRLEnv/robot.py:383-433)
+ * and PaintGymEnv.step/reset (PaintRLEnv/robot_gym_env.py:349-387).  Each entry
+ * point below names the reference interface it replaces.  A maintainer binds
+ * these with ctypes; paintrl_amd/_lib.py is that binding.
+ *
+ * Conventions: every function returns 0 on success and a negative PRL_E* code
+ * on failure (never throws); prl_last_error() gives the text.  The caller owns
+ * all buffers; device buffers are plain device pointers (e.g. torch
+ * tensor.data_ptr()).  The library owns only the opaque handles.  All launches
+ * go on the caller's HIP stream (`stream` is a hipStream_t passed as void*,
+ * NULL = the default stream).  A handle is not thread-safe; distinct handles are
+ * independent.  All floating point is float64, like the reference.
+ */
+#ifndef PAINTRL_H
+#define PAINTRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRL_ABI_VERSION 1
+
+enum { PRL_OK = 0, PRL_E_INVALID = -1, PRL_E_HIP = -2, PRL_E_UNSUPPORTED = -3, PRL_E_NOMEM = -4 };
+enum { PRL_OBS_SECTION = 0, PRL_OBS_GRID = 1, PRL_OBS_SIMPLE = 2, PRL_OBS_DISCRETE = 3 };   /* rge:166-173 */
+enum { PRL_ACT_DISCRETE = 0, PRL_ACT_CONTINUOUS = 1 };                                     /* rge:159-165 */
+enum { PRL_TERM_LATE = 0, PRL_TERM_EARLY = 1, PRL_TERM_HYBRID = 2 };                       /* rge:142-147 */
+enum { PRL_PAINT_FAST = 0, PRL_PAINT_NORMAL = 1 };                                         /* rob:171-172 */
+
+#define PRL_STATE_DOUBLES 16     /* per-env scalar state record, see prl_batch_get_state */
+#define PRL_MAX_DISCRETE 64
+
+typedef struct PrlPart PrlPart;     /* static tables of one part, resident in HBM */
+typedef struct PrlBatch PrlBatch;   /* N environments: coverage masks + scalar state in HBM */
+
+/*
+ * Host-side static tables of one part, produced by paintrl_amd.device_tables
+ * from paintrl_amd.part_tables (the restatement of bpw.load_part, bpw:1327-1335).
+ * All arrays are host pointers, copied by prl_part_create.
+ */
+typedef struct {
+    /* coverage samples in device order (sorted by sample-grid cell), padded to a multiple of 64 */
+    int32_t n_samples;            /* real samples (bpw Part.get_job_limit) */
+    int32_t n_samples_pad;
+    const double *sample_xyz[3];  /* world x, y, z, [n_samples_pad]; pads are far away */
+    const double *word_bbox;      /* [n_samples_pad/64][4]: min/max on axis a1, min/max on axis a2 */
+    const uint64_t *word_valid;   /* [n_samples_pad/64] bit set = real sample */
+    /* uniform grid over the principal plane that orders the samples */
+    double sgrid_origin[2], sgrid_inv_cell;
+    int32_t sgrid_nx, sgrid_ny;
+    const int32_t *sgrid_start;   /* [nx*ny+1] */
+    /* grid observation (bpw GridObservation): one sample bitmask per observation cell */
+    int32_t n_obs_cells;
+    const uint64_t *obs_cell_mask;   /* [n_obs_cells][n_samples_pad/64] */
+    const int32_t *obs_cell_count;   /* [n_obs_cells] */
+    /* same-side vertices (bpw vertices_kd_tree[side]) sorted by vertex-grid cell */
+    int32_t n_vertices;
+    const double *vertex_xyz[3];
+    const int32_t *vertex_rank;      /* original order, the nearest-vertex tie break */
+    const int32_t *vertex_adj_off;   /* [n_vertices+1] CSR into vertex_adj_tri (bpw uv_map) */
+    const int32_t *vertex_adj_tri;
+    double vgrid_origin[2], vgrid_inv_cell, vgrid_accept_d2;
+    int32_t vgrid_nx, vgrid_ny;
+    const int32_t *vgrid_start;      /* [nx*ny+1] */
+    /* same-side triangle records (bpw BarycentricInterpolator), 16 doubles each:
+       a[3] v0[3] v1[3] d00 d01 d11 inv_denom normal[3] */
+    int32_t n_triangles;
+    const double *tri_records;
+    /* collision triangle set (what pybullet.rayTestBatch hits), padded to a multiple of 64 */
+    int32_t n_collision;
+    int32_t n_collision_pad;
+    const double *col_v0e1e2[9];     /* v0.xyz e1.xyz e2.xyz, [n_collision_pad] each */
+    const float *col_bbox;           /* [n_collision_pad][4] outward-rounded principal-plane box */
+    /* grid rows (bpw grid_dict), extents, axes */
+    const double *grid_lo, *grid_hi; /* [100] */
+    double range1[2], range2[2], length_width_ratio;
+    int32_t axis0, axis1, axis2;
+    /* start points (bpw _start_points) with the quaternion of rob:93-100 */
+    int32_t n_start;
+    const double *start_pos;         /* [n_start][3] */
+    const double *start_quat;        /* [n_start][4] */
+    /* cone beams for PAINT_METHOD='normal' (rob:23-35) */
+    int32_t n_beams;
+    const double *beams;             /* [n_beams][3] */
+} PrlPartTables;
+
+/* PaintGymEnv configuration (rge:127-157) as a POD. */
+typedef struct {
+    int32_t obs_mode, obs_grad;
+    int32_t action_mode, action_dim, n_discrete;
+    int32_t termination_mode;
+    int32_t turning_penalty, overlap_penalty;
+    int32_t paint_method;
+    int32_t max_episode_len, expected_episode_len;
+    int32_t auto_reset;              /* 1: a finished env is reset inside the step kernel */
+    double switch_threshold;
+    double max_possible_point[8];    /* Part_Dict[...][1] per part id (rge:106-117) */
+    uint64_t seed;                   /* start-point RNG for auto_reset / reset without indices */
+    /* discrete action -> (delta_axis1, delta_axis2, turning angle), evaluated on the host with the
+       reference's own numpy calls (rge:342-347, rob:151-153, 396-397, 352-356) */
+    double act_delta1[PRL_MAX_DISCRETE], act_delta2[PRL_MAX_DISCRETE], act_angle[PRL_MAX_DISCRETE];
+} PrlConfig;
+
+int prl_abi_version(void);
+const char *prl_last_error(void);
+int prl_obs_dim(const PrlConfig *cfg);                       /* rge:166-173 */
+/* sizeof(PrlConfig) / sizeof(PrlPartTables) as compiled, so a binding can check its struct layout */
+int prl_struct_sizes(int *config_bytes, int *part_tables_bytes);
+
+/* Replaces bullet_paint_wrapper.load_part (bpw:1327-1335): upload one part's tables to `device`. */
+int prl_part_create(const PrlPartTables *host_tables, int device, PrlPart **out);
+void prl_part_destroy(PrlPart *part);
+int prl_part_mask_words(const PrlPart *part);                /* 64-bit words of one env's coverage mask */
+
+/* Replaces PaintGymEnv.__init__ (rge:207-229) for N envs; env i paints parts[env_part_id[i]]
+ * (env_part_id host pointer, NULL = all part 0).  Allocates coverage masks and scalar state. */
+int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part_id, int n_envs,
+                     const PrlConfig *cfg, PrlBatch **out);
+void prl_batch_destroy(PrlBatch *batch);
+int prl_batch_mask_stride(const PrlBatch *batch);            /* 64-bit words per env in get_mask */
+
+/* Replaces PaintGymEnv.reset + reset_part + Robot.reset (rge:370-387, bpw:706-712, rob:366-372).
+ * reset_mask: device u8[N] or NULL (= all).  start_idx: device i32[N] or NULL (= library RNG).
+ * obs: device f64[N][obs_dim] or NULL; rows of envs that are not reset are left untouched. */
+int prl_batch_reset(PrlBatch *batch, const uint8_t *reset_mask, const int32_t *start_idx, double *obs, void *stream);
+
+/* Replaces PaintGymEnv.step (rge:349-368) and everything under it for all N envs in ONE kernel.
+ * actions: device i32[N] (discrete) or f64[N][action_dim] (continuous).
+ * obs f64[N][obs_dim], reward f64[N] (= reward - penalty), done u8[N], info f64[N][2] (reward, penalty).
+ * With cfg.auto_reset the obs row of a finished env is its post-reset observation and, if
+ * final_obs != NULL, the terminal observation goes to final_obs f64[N][obs_dim].
+ * start_idx: device i32[N] start points for auto-reset, or NULL (= library RNG). */
+int prl_batch_step(PrlBatch *batch, const void *actions, double *obs, double *reward, uint8_t *done, double *info,
+                   double *final_obs, const int32_t *start_idx, void *stream);
+
+/* Replaces get_job_status / get_texture_image style read-back (bpw:727-738): coverage bits in
+ * device sample order, u64[N][mask_stride]. */
+int prl_batch_get_mask(PrlBatch *batch, uint64_t *painted, void *stream);
+/* Per-env scalar state f64[N][PRL_STATE_DOUBLES]: pose[3] quat[4] last_turning_angle total_reward
+ * total_return {i32 terminate, terminate_counter} {i32 last_on_part, step_counter} episode_count(u64)
+ * last_episode_return last_episode_reward {i32 last_episode_len, last_episode_painted}. */
+int prl_batch_get_state(PrlBatch *batch, double *state, void *stream);
+/* Episode returns (rge:359-360 _total_return of the last finished episode) -- the RCCL gather payload. */
+int prl_batch_get_returns(PrlBatch *batch, double *episode_return, void *stream);
+
+/* Replaces pybullet.rayTestBatch (bpw:873,918; rob:282) against a part's collision triangles:
+ * from/to f64[n][3] -> tri i32[n] (-1 = miss), frac f64[n], pos f64[n][3]; all device pointers. */
+int prl_ray_batch(PrlPart *part, int n, const double *from, const double *to, int32_t *tri, double *frac,
+                  double *pos, void *stream);
+
+/* Wall-clock-free kernel timing for bench.py: HIP events recorded around every step launch on its stream. */
+int prl_batch_timing_enable(PrlBatch *batch, int enable);
+int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);   /* synchronises; resets counters */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAINTRL_H */

@@ -1,0 +1,43 @@
+"""Builds the HIP shared library in-tree (paintrl_amd/libpaintrl_hip.so) with hipcc for gfx950.
+
+-ffp-contract=off is part of the numerical contract: the only fused multiply-adds
+are the explicit ones that restate numpy.dot (see csrc/paintrl_hip.hip header).
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+SOURCE = os.path.join(_HERE, 'csrc', 'paintrl_hip.hip')
+HEADER = os.path.join(_REPO, 'include', 'paintrl.h')
+LIBRARY = os.path.join(_HERE, 'libpaintrl_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17']
+
+
+def hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(exe):
+        raise RuntimeError('hipcc not found; the paint simulator has no CPU fallback')
+    return exe
+
+
+def is_stale():
+    if not os.path.isfile(LIBRARY):
+        return True
+    built = os.path.getmtime(LIBRARY)
+    return any(os.path.getmtime(p) > built for p in (SOURCE, HEADER))
+
+
+def build_library(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIBRARY
+    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), SOURCE, '-o', LIBRARY]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIBRARY
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

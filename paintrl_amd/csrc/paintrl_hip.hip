@@ -1,0 +1,1224 @@
+// paintrl_hip.hip -- MI355X (gfx950) batched paint-coverage simulator: kernels + C ABI.
+//
+// One wavefront (64 lanes) advances one environment by one PaintGymEnv.step()
+// (PaintRLEnv/robot_gym_env.py:349-368): five dependent sub-shots (tool move ->
+// ray onto the collision triangles -> nearest vertex -> closest incident triangle
+// -> hook pose -> ball paint) and then the observation, all in ONE kernel.
+//
+//  * the env's coverage state (painted mask, last-shot mask, this-shot mask,
+//    union-of-valid mask) lives in registers for the whole step: 64-bit word w
+//    of a mask is owned by lane (w & 63), slot (w >> 6); HBM traffic per env-step
+//    is one coalesced read and one coalesced write of the two persistent masks
+//    plus a 128-byte scalar record;
+//  * static part tables are shared by all envs and stay L2-resident; samples and
+//    vertices are sorted by uniform-grid cell so a sub-shot touches 3 short
+//    contiguous ranges (coalesced 512-B loads, one sample per lane, hit mask by
+//    ballot);
+//  * collision triangles are culled with a 16-byte box per lane-triangle before
+//    the float64 Moller-Trumbore test; closest hit by wave min-reduction;
+//  * section / grid observations are popcounts over mask words; only words whose
+//    bounding box straddles the tool position are classified per sample.
+//
+// All arithmetic is float64 in the reference's operation order (see
+// oracle/paint_oracle.c for the scalar statement; numpy.dot -> explicit fma chain,
+// everything else unfused: this file must be compiled with -ffp-contract=off).
+// No MFMA: this is gather / scan / bit work.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "paintrl.h"
+
+namespace {
+
+constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples
+constexpr double PAINT_RADIUS = 0.051;          // bpw:42
+constexpr double STEP_SIZE = 0.051;             // bpw:43
+constexpr double HOOK_DISTANCE = 0.1;           // bpw:443
+constexpr int GRID_GRANULARITY = 100;           // bpw:447
+constexpr int PAINT_PER_ACTION = 5;             // rob:165
+constexpr int NOT_ON_PART_TERMINATE = 1000;     // rob:167
+constexpr double RAY_EPS_DET = 1e-12;
+constexpr double RAY_EPS_BARY = 1e-9;
+constexpr double PI = 3.141592653589793;
+
+struct PartDev {
+    int n_samples, n_samples_pad, n_words;
+    const double *samp[3];
+    const double *word_bbox;
+    const uint64_t *word_valid;
+    double sg_o1, sg_o2, sg_inv;
+    int sg_nx, sg_ny;
+    const int *sg_start;
+    int n_obs_cells;
+    const uint64_t *cell_mask;
+    const int *cell_count;
+    int n_vertices;
+    const double *vert[3];
+    const int *vert_rank;
+    const int *vadj_off;
+    const int *vadj_tri;
+    double vg_o1, vg_o2, vg_inv, vg_accept_d2;
+    int vg_nx, vg_ny;
+    const int *vg_start;
+    int n_triangles;
+    const double *tri_rec;
+    int n_col, n_col_pad;
+    const double *col[9];
+    const float *col_bbox;
+    const double *grid_lo, *grid_hi;
+    double r1min, r1max, r2min, r2max, lwr;
+    int a0, a1, a2;
+    int n_start;
+    const double *start_pos, *start_quat;
+    int n_beams;
+    const double *beams;
+};
+
+struct StepArgs {
+    const PartDev *parts;
+    const PrlConfig *cfg;
+    const int *env_part;          // device, or nullptr
+    int n_envs, mask_stride;
+    uint64_t *painted, *last;
+    double *state;
+    const void *actions;
+    double *obs, *reward, *info, *final_obs;
+    uint8_t *done;
+    const int *start_idx;
+    const uint8_t *reset_mask;
+};
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    src = rfl(src);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
+    src = rfl(src);
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        double x = __shfl_xor(v, o);
+        v = x < v ? x : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        double x = __shfl_xor(v, o);
+        v = x > v ? x : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        int x = __shfl_xor(v, o);
+        v = x < v ? x : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o);
+    return v;
+}
+
+__device__ __forceinline__ double sel3(double x, double y, double z, int axis) {
+    return axis == 0 ? x : (axis == 1 ? y : z);
+}
+
+// ---------------------------------------------------------------- reference arithmetic
+// numpy.dot on 3-vectors = OpenBLAS ddot = fused chain (oracle/paint_oracle.c dot3_np)
+__device__ __forceinline__ double dot3_np(double a0, double a1, double a2, double b0, double b1, double b2) {
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+
+// this project's multiplyTransforms rotation (paintrl_amd/geometry.py quat_rotate)
+__device__ __forceinline__ void quat_rotate(const double q[4], double v0, double v1, double v2, double o[3]) {
+    double t0 = 2.0 * (q[1] * v2 - q[2] * v1);
+    double t1 = 2.0 * (q[2] * v0 - q[0] * v2);
+    double t2 = 2.0 * (q[0] * v1 - q[1] * v0);
+    o[0] = (v0 + q[3] * t0) + (q[1] * t2 - q[2] * t1);
+    o[1] = (v1 + q[3] * t1) + (q[2] * t0 - q[0] * t2);
+    o[2] = (v2 + q[3] * t2) + (q[0] * t1 - q[1] * t0);
+}
+
+__device__ __forceinline__ void transform_point(const double pos[3], const double q[4], double v0, double v1,
+                                                double v2, double o[3]) {
+    double r[3];
+    quat_rotate(q, v0, v1, v2, r);
+    o[0] = pos[0] + r[0];
+    o[1] = pos[1] + r[1];
+    o[2] = pos[2] + r[2];
+}
+
+// rob:93-100 get_pose_orn + bpw:32-37 normalize
+__device__ __forceinline__ void pose_orn_quat(const double orn[3], double q[4]) {
+    double x = 0.0 * orn[2] - 1.0 * orn[1];
+    double y = 1.0 * orn[0] - 0.0 * orn[2];
+    double z = 0.0 * orn[1] - 0.0 * orn[0];
+    double w = 1.0 + __builtin_fma(1.0, orn[2], __builtin_fma(0.0, orn[1], 0.0 * orn[0]));
+    double mag2 = (((0.0 + x * x) + y * y) + z * z) + w * w;
+    if (fabs(mag2 - 1.0) > 0.00001) {
+        double mag = sqrt(mag2);
+        x /= mag;
+        y /= mag;
+        z /= mag;
+        w /= mag;
+    }
+    q[0] = x;
+    q[1] = y;
+    q[2] = z;
+    q[3] = w;
+}
+
+// rob:266-271 _get_tcp_orn_norm
+__device__ __forceinline__ void tcp_orn_norm(const double pose[3], const double quat[4], double n[3]) {
+    double along[3];
+    transform_point(pose, quat, 0.0, 0.0, 1.0, along);
+    double v0 = along[0] - pose[0], v1 = along[1] - pose[1], v2 = along[2] - pose[2];
+    double norm = sqrt(dot3_np(v0, v1, v2, v0, v1, v2));
+    n[0] = v0 / norm;
+    n[1] = v1 / norm;
+    n[2] = v2 / norm;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {
+    double f = floor((x - origin) * inv);
+    f = f < -2.0 ? -2.0 : f;                       // NaN stays NaN -> comparison below sends it out of range
+    f = f > (double)(n + 1) ? (double)(n + 1) : f;
+    return (f == f) ? (int)f : -2;
+}
+
+// ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
+__device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
+                                double hit[3]) {
+    const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
+    const int a1 = P.a1, a2 = P.a2;
+    const double o1 = sel3(o[0], o[1], o[2], a1), o2 = sel3(o[0], o[1], o[2], a2);
+    const double e1p = sel3(e[0], e[1], e[2], a1), e2p = sel3(e[0], e[1], e[2], a2);
+    // segment box in the principal plane, one float ulp wider than the doubles
+    const float s1lo = nextafterf((float)fmin(o1, e1p), -INFINITY), s1hi = nextafterf((float)fmax(o1, e1p), INFINITY);
+    const float s2lo = nextafterf((float)fmin(o2, e2p), -INFINITY), s2hi = nextafterf((float)fmax(o2, e2p), INFINITY);
+    double best_t = INFINITY;
+    int best_i = 0x7fffffff;
+    const float4 *boxes = reinterpret_cast<const float4 *>(P.col_bbox);
+    for (int base = 0; base < P.n_col_pad; base += 64) {
+        const int i = base + lane;
+        const float4 b = boxes[i];                                   // pads carry an empty box
+        const bool cand = (s1lo <= b.y) && (s1hi >= b.x) && (s2lo <= b.w) && (s2hi >= b.z);
+        if (__ballot(cand) == 0) continue;
+        if (cand) {
+            const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
+            const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
+            const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
+            const double p0 = d1 * e22 - d2 * e21;
+            const double p1 = d2 * e20 - d0 * e22;
+            const double p2 = d0 * e21 - d1 * e20;
+            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+            if (fabs(det) >= RAY_EPS_DET) {
+                const double inv = 1.0 / det;
+                const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+                const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+                const double q0 = s1 * e12 - s2 * e11;
+                const double q1 = s2 * e10 - s0 * e12;
+                const double q2 = s0 * e11 - s1 * e10;
+                const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+                const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+                if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
+                    t <= 1.0 && t < best_t) {
+                    best_t = t;
+                    best_i = i;
+                }
+            }
+        }
+    }
+    const double tmin = wave_min_d(best_t);
+    if (!(tmin < INFINITY)) {
+        t_out = INFINITY;
+        return -1;
+    }
+    const int imin = wave_min_i(best_t == tmin ? best_i : 0x7fffffff);   // equal t: lowest triangle index
+    t_out = tmin;
+    hit[0] = o[0] + tmin * d0;
+    hit[1] = o[1] + tmin * d1;
+    hit[2] = o[2] + tmin * d2;
+    return imin;
+}
+
+// ---------------------------------------------------------------- bpw:526 nearest same-side vertex
+__device__ __forceinline__ void nv_scan(const PartDev &P, int begin, int end, const double pt[3], int lane,
+                                        double &best_d, int &best_rank, int &best_idx) {
+    for (int b = begin; b < end; b += 64) {
+        const int v = b + lane;
+        if (v < end) {
+            const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            const int rk = P.vert_rank[v];
+            if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                best_d = dd;
+                best_rank = rk;
+                best_idx = v;
+            }
+        }
+    }
+}
+
+__device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lane) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
+    double best_d = INFINITY;
+    int best_rank = 0x7fffffff, best_idx = -1;
+    for (int cy = icy - 1; cy <= icy + 1; ++cy) {
+        if (cy < 0 || cy >= P.vg_ny) continue;
+        const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > P.vg_nx - 1 ? P.vg_nx - 1 : icx + 1;
+        if (cx0 > cx1) continue;
+        nv_scan(P, P.vg_start[cy * P.vg_nx + cx0], P.vg_start[cy * P.vg_nx + cx1 + 1], pt, lane, best_d, best_rank,
+                best_idx);
+    }
+    double dmin = wave_min_d(best_d);
+    if (!(dmin <= P.vg_accept_d2)) {   // a vertex outside the 3x3 block could be nearer: exact scan of all vertices
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
+        dmin = wave_min_d(best_d);
+    }
+    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
+    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
+    if (win == 0) return -1;                                        // NaN query point
+    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
+}
+
+// ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
+__device__ bool hook_point_wave(const PartDev &P, const double pt[3], int lane, double pose[3], double orn[3]) {
+    const int vidx = nearest_vertex_wave(P, pt, lane);
+    if (vidx < 0) return false;
+    const int k0 = P.vadj_off[vidx], cnt = P.vadj_off[vidx + 1] - k0;     // <= 64, checked at upload
+    if (cnt <= 0) return false;
+    bool inside = false, ok = false;
+    double m = -INFINITY, n0 = 0, n1 = 0, n2 = 0;
+    if (lane < cnt) {
+        const double *r = P.tri_rec + (size_t)P.vadj_tri[k0 + lane] * 16;
+        const double2 *r2 = reinterpret_cast<const double2 *>(r);
+        const double2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
+        // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
+        const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
+        const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
+        const double d21 = dot3_np(x0, x1, x2, q3.x, q3.y, q4.x);
+        const double inv = q6.x;
+        double v = (q5.y * d20 - q5.x * d21) * inv;
+        double w = (q4.y * d21 - q5.x * d20) * inv;
+        double u = 1.0 - v - w;
+        if (inv == 0) {
+            u = -1;
+            v = -1;
+            w = -1;
+        }
+        inside = 0 <= u && u <= 1 && 0 <= v && v <= 1 && 0 <= w && w <= 1;
+        m = v < u ? v : u;
+        m = w < m ? w : m;
+        ok = m >= -1.0;
+        n0 = q6.y;
+        n1 = q7.x;
+        n2 = q7.y;
+    }
+    int j;
+    const uint64_t in_mask = __ballot(inside);
+    if (in_mask) {
+        j = __builtin_ctzll(in_mask);                               // first triangle containing the point
+    } else {
+        const uint64_t ok_mask = __ballot(ok);
+        if (ok_mask == 0) {
+            j = 0;                                                   // nothing beat -1: the first candidate stays
+        } else {
+            const double mx = wave_max_d(ok ? m : -INFINITY);
+            j = 63 - __builtin_clzll(__ballot(ok && m == mx));       // last one reaching the maximum
+        }
+    }
+    n0 = bcast_d(n0, j);
+    n1 = bcast_d(n1, j);
+    n2 = bcast_d(n2, j);
+    pose[0] = pt[0] + n0 * HOOK_DISTANCE;
+    pose[1] = pt[1] + n1 * HOOK_DISTANCE;
+    pose[2] = pt[2] + n2 * HOOK_DISTANCE;
+    orn[0] = -n0;
+    orn[1] = -n1;
+    orn[2] = -n2;
+    return true;
+}
+
+// ---------------------------------------------------------------- bpw:568-570 fast_paint (ball query)
+template <int KW>
+__device__ void ball_query_wave(const PartDev &P, const double c[3], int lane, uint64_t cur[KW_MAX]) {
+    const double r2 = PAINT_RADIUS * PAINT_RADIUS;
+    const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
+    const int icx = cell_coord(c1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(c2, P.sg_o2, P.sg_inv, P.sg_ny);
+    for (int cy = icy - 1; cy <= icy + 1; ++cy) {
+        if (cy < 0 || cy >= P.sg_ny) continue;
+        const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : icx + 1;
+        if (cx0 > cx1) continue;
+        const int begin = P.sg_start[cy * P.sg_nx + cx0], end = P.sg_start[cy * P.sg_nx + cx1 + 1];
+        if (begin >= end) continue;
+        for (int w = begin >> 6; w <= (end - 1) >> 6; ++w) {
+            const int s = (w << 6) + lane;
+            const double dx = P.samp[0][s] - c[0], dy = P.samp[1][s] - c[1], dz = P.samp[2][s] - c[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            const uint64_t b = __ballot(s >= begin && s < end && dd <= r2);
+            if (b) {
+                const int owner = w & 63, slot = w >> 6;
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+                    if (k == slot && lane == owner) cur[k] |= b;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- observation (rge:306-319)
+__device__ __forceinline__ int grid_index_2(const PartDev &P, double val) {
+    const double rel = (val - P.r2min) / (P.r2max - P.r2min);
+    const double g = rel * GRID_GRANULARITY;
+    int gi;
+    if (!(g > -2147483648.0 && g < 2147483648.0)) gi = g > 0 ? GRID_GRANULARITY - 1 : 0;
+    else gi = (int)g;
+    return gi < 0 ? 0 : (gi > GRID_GRANULARITY - 1 ? GRID_GRANULARITY - 1 : gi);
+}
+
+__device__ __forceinline__ double clip01(double v) { return v < 0 ? 0.0 : (v > 1 ? 1.0 : v); }
+
+__device__ __forceinline__ int handle_pos(double v) {        // rge:92-98
+    if (v == 0) return 0;
+    if (v == 1) return 21;
+    return (int)(v * 20) + 1;
+}
+
+template <int KW>
+__device__ void observation_wave(const PartDev &P, const PrlConfig &C, const double pose[3],
+                                 const uint64_t painted[KW_MAX], int lane, double *out) {
+    // bpw:965-978 get_normalized_pose
+    const double r = PAINT_RADIUS;
+    const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
+    const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
+    const int gi = grid_index_2(P, x2);
+    const double lo = P.grid_lo[gi], hi = P.grid_hi[gi];
+    double in1;
+    if (hi - lo == 0) in1 = 0;
+    else in1 = (x1 - lo + r) / (hi - lo + 2 * r);
+    const double np0 = clip01(in1), np1 = clip01(in2);
+    const int mode = C.obs_mode;
+    if (mode == PRL_OBS_SIMPLE) {
+        if (lane == 0) {
+            out[0] = np0;
+            out[1] = np1;
+        }
+        return;
+    }
+    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
+        const int cells = P.n_obs_cells;
+        for (int c0 = 0; c0 < cells; c0 += 4) {
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int w = lane + 64 * k;
+                if (w < P.n_words) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < cells)
+                            acc += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + q) * P.n_words + w])
+                                   << (16 * q);
+                }
+            }
+            acc = wave_sum_u64(acc);
+            if (lane == 0) {
+                for (int q = 0; q < 4 && c0 + q < cells; ++q) {
+                    const int num = P.cell_count[c0 + q];
+                    const int dn = (int)((acc >> (16 * q)) & 0xffff);
+                    out[c0 + q] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
+                }
+            }
+        }
+        return;
+    }
+    // section / discrete, 4-sector rule bpw:1034-1043 (only obs_grad == 4 reaches the device)
+    const double *sx = P.samp[P.a1], *sy = P.samp[P.a2];
+    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane
+    uint32_t tot_u[4] = {0, 0, 0, 0}, und_u[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        bool straddle = false;
+        if (w < P.n_words) {
+            const double4 bb = reinterpret_cast<const double4 *>(P.word_bbox)[w];
+            const uint64_t valid = P.word_valid[w];
+            const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
+            if ((xg || xl) && (yg || yl)) {
+                const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
+                tot_l += (uint64_t)__popcll(valid) << (16 * idx);
+                und_l += (uint64_t)__popcll(valid & ~painted[k]) << (16 * idx);
+            } else {
+                straddle = valid != 0;
+            }
+        }
+        uint64_t sm = __ballot(straddle);
+        while (sm) {                                // wave-uniform loop over the words that straddle the tool
+            const int L = __builtin_ctzll(sm);
+            sm &= sm - 1;
+            const int w2 = L + 64 * k;
+            const uint64_t pw = bcast_u64(painted[k], L);
+            const uint64_t vw = P.word_valid[w2];
+            const int s = (w2 << 6) + lane;
+            const double x = sx[s], y = sy[s];
+            const uint64_t m0 = __ballot(x > x1 && y > x2) & vw;
+            const uint64_t m1 = __ballot(x < x1 && y > x2) & vw;
+            const uint64_t m2 = __ballot(x < x1 && y < x2) & vw;
+            const uint64_t skip = __ballot(x == x1 && y == x2);
+            const uint64_t m3 = vw & ~(m0 | m1 | m2 | skip);
+            tot_u[0] += __popcll(m0);
+            tot_u[1] += __popcll(m1);
+            tot_u[2] += __popcll(m2);
+            tot_u[3] += __popcll(m3);
+            und_u[0] += __popcll(m0 & ~pw);
+            und_u[1] += __popcll(m1 & ~pw);
+            und_u[2] += __popcll(m2 & ~pw);
+            und_u[3] += __popcll(m3 & ~pw);
+        }
+    }
+    tot_l = wave_sum_u64(tot_l);
+    und_l = wave_sum_u64(und_l);
+    if (lane == 0) {
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff) + tot_u[q];
+            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff) + und_u[q];
+            out[q] = t == 0 ? 0.0 : (double)u / (double)t;
+        }
+        if (mode == PRL_OBS_SECTION) {
+            out[4] = np0;
+            out[5] = np1;
+        } else {
+            const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
+            out[4] = 1.0 / (double)position;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- start-point RNG
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ int draw_start(uint64_t seed, int env, uint64_t episode, int n_start) {
+    const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)env << 1) | 1) ^ (episode * 0xD1342543DE82EF95ull));
+    return (int)(((h >> 32) * (uint64_t)n_start) >> 32);
+}
+
+struct EnvState {                 // PRL_STATE_DOUBLES record
+    double pose[3], quat[4];
+    double last_angle, total_reward, total_return;
+    int terminate, terminate_counter, last_on_part, step_counter;
+    uint64_t episode;
+    double last_ep_return, last_ep_reward;
+    int last_ep_len, last_ep_painted;
+};
+static_assert(sizeof(EnvState) == PRL_STATE_DOUBLES * 8, "state record layout");
+
+__device__ __forceinline__ void reset_state(const PartDev &P, EnvState &S, int start) {   // rge:370-387, rob:366-372
+    S.pose[0] = P.start_pos[3 * start];
+    S.pose[1] = P.start_pos[3 * start + 1];
+    S.pose[2] = P.start_pos[3 * start + 2];
+    S.quat[0] = P.start_quat[4 * start];
+    S.quat[1] = P.start_quat[4 * start + 1];
+    S.quat[2] = P.start_quat[4 * start + 2];
+    S.quat[3] = P.start_quat[4 * start + 3];
+    S.last_angle = 0;
+    S.total_reward = 0;
+    S.total_return = 0;
+    S.terminate = 0;
+    S.terminate_counter = 0;
+    S.last_on_part = 1;
+    S.step_counter = 0;
+    S.episode += 1;
+}
+
+template <int KW>
+__device__ __forceinline__ void load_masks(const StepArgs &a, int env, int n_words, int lane, uint64_t painted[KW_MAX],
+                                           uint64_t last[KW_MAX]) {
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        const bool in = w < n_words;
+        painted[k] = in ? a.painted[(size_t)env * a.mask_stride + w] : 0;
+        last[k] = in ? a.last[(size_t)env * a.mask_stride + w] : 0;
+    }
+}
+
+template <int KW>
+__device__ __forceinline__ void store_masks(const StepArgs &a, int env, int n_words, int lane,
+                                            const uint64_t painted[KW_MAX], const uint64_t last[KW_MAX]) {
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        if (w < n_words) {
+            a.painted[(size_t)env * a.mask_stride + w] = painted[k];
+            a.last[(size_t)env * a.mask_stride + w] = last[k];
+        }
+    }
+}
+
+__host__ __device__ inline int obs_dim_of(const PrlConfig &c) {          // rge:166-173
+    switch (c.obs_mode) {
+    case PRL_OBS_SECTION: return c.obs_grad + 2;
+    case PRL_OBS_GRID: return c.obs_grad * c.obs_grad;
+    case PRL_OBS_SIMPLE: return 2;
+    default: return c.obs_grad + 1;
+    }
+}
+
+// ---------------------------------------------------------------- reset kernel (rge:370-387)
+template <int KW>
+__global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    if (a.reset_mask && !a.reset_mask[env]) return;
+    const PartDev &P = a.parts[a.env_part ? a.env_part[env] : 0];
+    const PrlConfig &C = *a.cfg;
+    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
+    start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
+    reset_state(P, S, start);
+    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    store_masks<KW>(a, env, P.n_words, lane, painted, last);
+    if (lane == 0) *reinterpret_cast<EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES) = S;
+    if (a.obs) observation_wave<KW>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C));
+}
+
+// ---------------------------------------------------------------- step kernel (rge:349-368)
+template <int KW>
+__global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    const PartDev &P = a.parts[part_id];
+    const PrlConfig &C = *a.cfg;
+    const int od = obs_dim_of(C);
+    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    uint64_t cur[KW_MAX] = {0, 0, 0, 0}, uni[KW_MAX] = {0, 0, 0, 0};
+    load_masks<KW>(a, env, P.n_words, lane, painted, last);
+
+    // ---- action -> (delta1, delta2, turning angle)   rge:342-347, rob:390-398, 352-358
+    double delta1, delta2, new_angle;
+    if (C.action_mode == PRL_ACT_DISCRETE) {
+        int act = reinterpret_cast<const int *>(a.actions)[env];
+        act = act < 0 ? 0 : (act >= C.n_discrete ? C.n_discrete - 1 : act);
+        delta1 = C.act_delta1[act];
+        delta2 = C.act_delta2[act];
+        new_angle = C.act_angle[act];
+    } else {
+        const double *av = reinterpret_cast<const double *>(a.actions) + (size_t)env * C.action_dim;
+        double a0 = av[0], a1 = C.action_dim > 1 ? av[1] : 0.0;
+        if (!(-1 <= a0 && a0 <= 1)) a0 = a0 < -1 ? -1 : (a0 > 1 ? 1 : a0);
+        if (!(-1 <= a1 && a1 <= 1)) a1 = a1 < -1 ? -1 : (a1 > 1 ? 1 : a1);
+        double dx, dy;
+        if (C.action_dim == 1) {                       // rob:152-153
+            const double phi = (a0 + 1) * PI;
+            dx = 1 * cos(phi);
+            dy = 1 * sin(phi);
+        } else {                                       // rob:154-160
+            const double phi = atan2(a1, a0);
+            const double ax = fabs(a0), ay = fabs(a1);
+            if (ax == 0 && ay == 0) {
+                dx = ax;
+                dy = ay;
+            } else {
+                const double mx = ax > ay ? ax : ay;
+                dx = mx * cos(phi);
+                dy = mx * sin(phi);
+            }
+        }
+        delta1 = dx * STEP_SIZE;
+        delta2 = dy * STEP_SIZE;
+        new_angle = delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2;
+    }
+    const double angle_diff = fabs(new_angle - S.last_angle);
+    S.last_angle = new_angle;
+    const int counter_before = S.terminate_counter;
+
+    // ---- five chained sub-shots   rob:302-329 + 403-424
+    double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
+    tcp_orn_norm(S.pose, S.quat, cur_norm);
+    const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
+    uint32_t succeeded_l = 0;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        // bpw:865-880 get_guided_point
+        double pt[3] = {cur_pose[0], cur_pose[1], cur_pose[2]};
+        const double delta_2 = d2 * P.lwr;
+        if (P.a1 == 0) pt[0] += d1; else if (P.a1 == 1) pt[1] += d1; else pt[2] += d1;
+        if (P.a2 == 0) pt[0] += delta_2; else if (P.a2 == 1) pt[1] += delta_2; else pt[2] += delta_2;
+        const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
+        double t, hit[3], pos[3], orn[3], quat[4];
+        bool on = ray_closest_wave(P, pt, end, lane, t, hit) >= 0;
+        if (on) on = hook_point_wave(P, hit, lane, pos, orn);
+        if (!on) {
+            orn[0] = cur_norm[0];
+            orn[1] = cur_norm[1];
+            orn[2] = cur_norm[2];
+        }
+        pose_orn_quat(orn, quat);
+        if (!on) {
+            transform_point(cur_pose, quat, d2, d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
+            if (S.last_on_part) {                                    // rob:292-300
+                S.last_on_part = 0;
+            } else {
+                S.terminate_counter += 1;
+                if (S.terminate_counter > NOT_ON_PART_TERMINATE) S.terminate = 1;
+            }
+        } else {
+            S.last_on_part = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cur_pose[k] = pos[k];
+            cur_norm[k] = orn[k];
+            S.pose[k] = pos[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];
+        // rob:277-278 shot centre, bpw:568-577 fast_paint + _paint
+        double center[3];
+        transform_point(pos, quat, 0.0, 0.0, 0.1, center);
+        ball_query_wave<KW>(P, center, lane, cur);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            succeeded_l += __popcll(cur[k] & ~painted[k]);
+            painted[k] |= cur[k];
+            uni[k] |= cur[k] & ~last[k];
+            last[k] = cur[k];
+            cur[k] = 0;
+        }
+    }
+    uint32_t pix_l = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
+    const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
+    const int succeeded = (int)(sums >> 32), pixel_counter = (int)(sums & 0xffffffffu);
+    const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
+    if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
+
+    // ---- reward, penalty, termination   rge:321-340, 289-304
+    const double rew = (double)succeeded / 100;
+    S.total_reward += rew;
+    double pen = 0.2;
+    if (C.overlap_penalty) pen += 0.1 * (1 - rate);
+    if (C.turning_penalty) pen += 0.1 * (angle_diff / PI);
+    const double actual = rew - pen;
+    S.step_counter += 1;
+    const double max_pts = C.max_possible_point[part_id & 7];
+    const int finished = max_pts > S.total_reward * 100 ? 0 : 1;
+    const double avg = S.total_reward / S.step_counter;
+    const double expected = max_pts / (C.expected_episode_len * 100);
+    int dn;
+    if (avg < expected && C.termination_mode != PRL_TERM_LATE &&
+        (C.termination_mode == PRL_TERM_EARLY || S.total_reward < C.switch_threshold * max_pts / 100))
+        dn = 1;
+    else
+        dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
+    if (!dn) S.total_return += actual;
+
+    const bool do_reset = dn && C.auto_reset;
+    double *obs_row = a.obs + (size_t)env * od;
+    double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
+    if (term_row) observation_wave<KW>(P, C, S.pose, painted, lane, term_row);
+    if (lane == 0) {
+        a.reward[env] = actual;
+        a.done[env] = (uint8_t)dn;
+        a.info[2 * (size_t)env] = rew;
+        a.info[2 * (size_t)env + 1] = pen;
+    }
+    if (dn) {                                   // episode statistics (the RCCL gather payload)
+        uint32_t cnt_l = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) cnt_l += __popcll(painted[k]);
+        S.last_ep_painted = (int)wave_sum_u64(cnt_l);
+        S.last_ep_return = S.total_return;
+        S.last_ep_reward = S.total_reward;
+        S.last_ep_len = S.step_counter;
+    }
+    if (do_reset) {
+        int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
+        start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
+        reset_state(P, S, start);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            painted[k] = 0;
+            last[k] = 0;
+        }
+        observation_wave<KW>(P, C, S.pose, painted, lane, obs_row);
+    }
+    store_masks<KW>(a, env, P.n_words, lane, painted, last);
+    if (lane == 0) *reinterpret_cast<EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES) = S;
+}
+
+// ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
+__global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int n, const double *from,
+                                                        const double *to, int *tri, double *frac, double *pos) {
+    const int lane = threadIdx.x & 63;
+    const int r = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= n) return;
+    const double o[3] = {from[3 * r], from[3 * r + 1], from[3 * r + 2]};
+    const double e[3] = {to[3 * r], to[3 * r + 1], to[3 * r + 2]};
+    double t, hit[3] = {0, 0, 0};
+    const int idx = ray_closest_wave(*part, o, e, lane, t, hit);
+    if (lane == 0) {
+        tri[r] = idx;
+        frac[r] = t;
+        pos[3 * r] = hit[0];
+        pos[3 * r + 1] = hit[1];
+        pos[3 * r + 2] = hit[2];
+    }
+}
+
+__global__ void gather_state_kernel(const double *state, int n, int field, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = state[(size_t)i * PRL_STATE_DOUBLES + field];
+}
+
+// ================================================================= host side
+thread_local char g_error[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PRL_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+}  // namespace
+
+struct PrlPart {
+    int device = 0;
+    PartDev dev{};                 // device pointers inside
+    std::vector<void *> allocs;
+    int max_adj = 0;
+    PartDev *dev_copy = nullptr;   // single-part device copy (prl_ray_batch)
+};
+
+struct PrlBatch {
+    int device = 0, n_envs = 0, n_parts = 0, mask_stride = 0, kw = 0;
+    PrlConfig cfg{};
+    PartDev *parts_dev = nullptr;
+    PrlConfig *cfg_dev = nullptr;
+    int *env_part_dev = nullptr;
+    uint64_t *painted = nullptr, *last = nullptr;
+    double *state = nullptr;
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(PrlPart *p, const T *host, size_t count, const T **out) {
+    *out = nullptr;
+    if (count == 0) return PRL_OK;
+    if (!host) return fail(PRL_E_INVALID, "null table pointer");
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, count * sizeof(T)));
+    p->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return PRL_OK;
+}
+
+#define UP(field, host, count)                                        \
+    do {                                                              \
+        int rc_ = upload(p, host, (size_t)(count), &p->dev.field);    \
+        if (rc_) return rc_;                                          \
+    } while (0)
+
+int part_fill(PrlPart *p, const PrlPartTables *t) {
+    PartDev &d = p->dev;
+    if (t->n_samples <= 0 || t->n_samples_pad % 64 || t->n_samples_pad < t->n_samples)
+        return fail(PRL_E_INVALID, "bad sample counts %d/%d", t->n_samples, t->n_samples_pad);
+    d.n_samples = t->n_samples;
+    d.n_samples_pad = t->n_samples_pad;
+    d.n_words = t->n_samples_pad / 64;
+    if (d.n_words > 64 * KW_MAX)
+        return fail(PRL_E_UNSUPPORTED, "part has %d samples; this build keeps at most %d per env in registers",
+                    t->n_samples, 64 * 64 * KW_MAX);
+    for (int k = 0; k < 3; ++k) UP(samp[k], t->sample_xyz[k], t->n_samples_pad);
+    UP(word_bbox, t->word_bbox, (size_t)d.n_words * 4);
+    UP(word_valid, t->word_valid, d.n_words);
+    d.sg_o1 = t->sgrid_origin[0];
+    d.sg_o2 = t->sgrid_origin[1];
+    d.sg_inv = t->sgrid_inv_cell;
+    d.sg_nx = t->sgrid_nx;
+    d.sg_ny = t->sgrid_ny;
+    if (d.sg_nx <= 0 || d.sg_ny <= 0) return fail(PRL_E_INVALID, "empty sample grid");
+    UP(sg_start, t->sgrid_start, (size_t)d.sg_nx * d.sg_ny + 1);
+    if (t->sgrid_start[(size_t)d.sg_nx * d.sg_ny] > t->n_samples_pad) return fail(PRL_E_INVALID, "sample grid overruns");
+    d.n_obs_cells = t->n_obs_cells;
+    if (d.n_obs_cells > 0) {
+        UP(cell_mask, t->obs_cell_mask, (size_t)d.n_obs_cells * d.n_words);
+        UP(cell_count, t->obs_cell_count, d.n_obs_cells);
+    }
+    d.n_vertices = t->n_vertices;
+    if (d.n_vertices <= 0) return fail(PRL_E_INVALID, "part has no same-side vertices");
+    for (int k = 0; k < 3; ++k) UP(vert[k], t->vertex_xyz[k], d.n_vertices);
+    UP(vert_rank, t->vertex_rank, d.n_vertices);
+    UP(vadj_off, t->vertex_adj_off, (size_t)d.n_vertices + 1);
+    const int n_adj = t->vertex_adj_off[d.n_vertices];
+    d.n_triangles = t->n_triangles;
+    for (int v = 0; v < d.n_vertices; ++v) {
+        const int c = t->vertex_adj_off[v + 1] - t->vertex_adj_off[v];
+        if (c < 0 || c > 64) return fail(PRL_E_UNSUPPORTED, "vertex %d has %d incident triangles (max 64)", v, c);
+        if (c > p->max_adj) p->max_adj = c;
+    }
+    for (int k = 0; k < n_adj; ++k)
+        if (t->vertex_adj_tri[k] < 0 || t->vertex_adj_tri[k] >= d.n_triangles)
+            return fail(PRL_E_INVALID, "adjacency entry %d out of range", k);
+    UP(vadj_tri, t->vertex_adj_tri, n_adj);
+    d.vg_o1 = t->vgrid_origin[0];
+    d.vg_o2 = t->vgrid_origin[1];
+    d.vg_inv = t->vgrid_inv_cell;
+    d.vg_accept_d2 = t->vgrid_accept_d2;
+    d.vg_nx = t->vgrid_nx;
+    d.vg_ny = t->vgrid_ny;
+    if (d.vg_nx <= 0 || d.vg_ny <= 0) return fail(PRL_E_INVALID, "empty vertex grid");
+    UP(vg_start, t->vgrid_start, (size_t)d.vg_nx * d.vg_ny + 1);
+    if (t->vgrid_start[(size_t)d.vg_nx * d.vg_ny] != d.n_vertices) return fail(PRL_E_INVALID, "vertex grid mismatch");
+    UP(tri_rec, t->tri_records, (size_t)d.n_triangles * 16);
+    d.n_col = t->n_collision;
+    d.n_col_pad = t->n_collision_pad;
+    if (d.n_col <= 0 || d.n_col_pad % 64 || d.n_col_pad < d.n_col) return fail(PRL_E_INVALID, "bad collision counts");
+    for (int k = 0; k < 9; ++k) UP(col[k], t->col_v0e1e2[k], d.n_col_pad);
+    UP(col_bbox, t->col_bbox, (size_t)d.n_col_pad * 4);
+    UP(grid_lo, t->grid_lo, GRID_GRANULARITY);
+    UP(grid_hi, t->grid_hi, GRID_GRANULARITY);
+    d.r1min = t->range1[0];
+    d.r1max = t->range1[1];
+    d.r2min = t->range2[0];
+    d.r2max = t->range2[1];
+    d.lwr = t->length_width_ratio;
+    d.a0 = t->axis0;
+    d.a1 = t->axis1;
+    d.a2 = t->axis2;
+    if (d.a0 < 0 || d.a0 > 2 || d.a1 < 0 || d.a1 > 2 || d.a2 < 0 || d.a2 > 2 || d.a0 == d.a1 || d.a1 == d.a2 ||
+        d.a0 == d.a2)
+        return fail(PRL_E_INVALID, "axes must be a permutation of 0,1,2");
+    d.n_start = t->n_start;
+    if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
+    UP(start_pos, t->start_pos, (size_t)d.n_start * 3);
+    UP(start_quat, t->start_quat, (size_t)d.n_start * 4);
+    d.n_beams = t->n_beams;
+    if (d.n_beams > 0) UP(beams, t->beams, (size_t)d.n_beams * 3);
+    return PRL_OK;
+}
+
+int check_config(const PrlConfig *c) {
+    if (c->obs_mode < 0 || c->obs_mode > 3) return fail(PRL_E_INVALID, "obs_mode %d", c->obs_mode);
+    if ((c->obs_mode == PRL_OBS_SECTION || c->obs_mode == PRL_OBS_DISCRETE) && c->obs_grad != 4)
+        return fail(PRL_E_UNSUPPORTED, "section/discrete observation: only OBS_GRAD=4 (the 4-sector rule) is on device");
+    if (c->obs_mode == PRL_OBS_GRID && (c->obs_grad < 1 || c->obs_grad > 16))
+        return fail(PRL_E_UNSUPPORTED, "grid observation: OBS_GRAD must be 1..16");
+    if (c->action_mode == PRL_ACT_DISCRETE) {
+        if (c->n_discrete < 1 || c->n_discrete > PRL_MAX_DISCRETE) return fail(PRL_E_INVALID, "n_discrete %d", c->n_discrete);
+    } else if (c->action_mode == PRL_ACT_CONTINUOUS) {
+        if (c->action_dim < 1 || c->action_dim > 2) return fail(PRL_E_INVALID, "action_dim %d", c->action_dim);
+    } else {
+        return fail(PRL_E_INVALID, "action_mode %d", c->action_mode);
+    }
+    if (c->termination_mode < 0 || c->termination_mode > 2) return fail(PRL_E_INVALID, "termination_mode");
+    if (c->paint_method != PRL_PAINT_FAST)
+        return fail(PRL_E_UNSUPPORTED, "PAINT_METHOD='normal' (cone beams) is not on device yet");
+    if (c->max_episode_len < 1 || c->expected_episode_len < 1) return fail(PRL_E_INVALID, "episode lengths");
+    return PRL_OK;
+}
+
+template <int KW>
+void launch_step(const StepArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(step_kernel<KW>, dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+}
+
+template <int KW>
+void launch_reset(const StepArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(reset_kernel<KW>, dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+}
+
+StepArgs base_args(PrlBatch *b) {
+    StepArgs a{};
+    a.parts = b->parts_dev;
+    a.cfg = b->cfg_dev;
+    a.env_part = b->env_part_dev;
+    a.n_envs = b->n_envs;
+    a.mask_stride = b->mask_stride;
+    a.painted = b->painted;
+    a.last = b->last;
+    a.state = b->state;
+    return a;
+}
+
+}  // namespace
+
+// ================================================================= C ABI
+extern "C" {
+
+int prl_abi_version(void) { return PRL_ABI_VERSION; }
+const char *prl_last_error(void) { return g_error; }
+
+int prl_obs_dim(const PrlConfig *cfg) {
+    if (!cfg) return fail(PRL_E_INVALID, "null config");
+    return obs_dim_of(*cfg);
+}
+
+int prl_struct_sizes(int *config_bytes, int *part_tables_bytes) {
+    if (config_bytes) *config_bytes = (int)sizeof(PrlConfig);
+    if (part_tables_bytes) *part_tables_bytes = (int)sizeof(PrlPartTables);
+    return PRL_OK;
+}
+
+int prl_part_create(const PrlPartTables *t, int device, PrlPart **out) {
+    if (!t || !out) return fail(PRL_E_INVALID, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    PrlPart *p = new (std::nothrow) PrlPart();
+    if (!p) return fail(PRL_E_NOMEM, "out of host memory");
+    p->device = device;
+    int rc = part_fill(p, t);
+    if (rc == PRL_OK) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p->dev_copy), sizeof(PartDev));
+        if (e == hipSuccess) e = hipMemcpy(p->dev_copy, &p->dev, sizeof(PartDev), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(PRL_E_HIP, "part descriptor upload: %s", hipGetErrorString(e));
+    }
+    if (rc != PRL_OK) {
+        prl_part_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return PRL_OK;
+}
+
+void prl_part_destroy(PrlPart *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (void *d : p->allocs) (void)hipFree(d);
+    if (p->dev_copy) (void)hipFree(p->dev_copy);
+    delete p;
+}
+
+int prl_part_mask_words(const PrlPart *p) { return p ? p->dev.n_words : fail(PRL_E_INVALID, "null part"); }
+
+int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part_id, int n_envs, const PrlConfig *cfg,
+                     PrlBatch **out) {
+    if (!parts || !cfg || !out || n_parts < 1 || n_parts > 8 || n_envs < 1)
+        return fail(PRL_E_INVALID, "bad arguments (n_parts 1..8, n_envs >= 1)");
+    *out = nullptr;
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    for (int i = 0; i < n_parts; ++i) {
+        if (!parts[i]) return fail(PRL_E_INVALID, "null part %d", i);
+        if (parts[i]->device != parts[0]->device) return fail(PRL_E_INVALID, "parts live on different devices");
+        if (cfg->obs_mode == PRL_OBS_GRID && parts[i]->dev.n_obs_cells != cfg->obs_grad * cfg->obs_grad)
+            return fail(PRL_E_INVALID, "part %d was packed for %d observation cells, config wants %d", i,
+                        parts[i]->dev.n_obs_cells, cfg->obs_grad * cfg->obs_grad);
+    }
+    if (env_part_id)
+        for (int i = 0; i < n_envs; ++i)
+            if (env_part_id[i] < 0 || env_part_id[i] >= n_parts) return fail(PRL_E_INVALID, "env_part_id[%d] out of range", i);
+    PrlBatch *b = new (std::nothrow) PrlBatch();
+    if (!b) return fail(PRL_E_NOMEM, "out of host memory");
+    b->device = parts[0]->device;
+    b->n_envs = n_envs;
+    b->n_parts = n_parts;
+    b->cfg = *cfg;
+    for (int i = 0; i < n_parts; ++i)
+        if (parts[i]->dev.n_words > b->mask_stride) b->mask_stride = parts[i]->dev.n_words;
+    b->kw = (b->mask_stride + 63) / 64;
+    hipError_t e = hipSetDevice(b->device);
+    std::vector<PartDev> pd(n_parts);
+    for (int i = 0; i < n_parts; ++i) pd[i] = parts[i]->dev;
+    const size_t mask_bytes = (size_t)n_envs * b->mask_stride * sizeof(uint64_t);
+    const size_t state_bytes = (size_t)n_envs * PRL_STATE_DOUBLES * sizeof(double);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->parts_dev), sizeof(PartDev) * n_parts);
+    if (e == hipSuccess) e = hipMemcpy(b->parts_dev, pd.data(), sizeof(PartDev) * n_parts, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cfg_dev), sizeof(PrlConfig));
+    if (e == hipSuccess) e = hipMemcpy(b->cfg_dev, cfg, sizeof(PrlConfig), hipMemcpyHostToDevice);
+    if (e == hipSuccess && env_part_id) {
+        e = hipMalloc(reinterpret_cast<void **>(&b->env_part_dev), sizeof(int) * n_envs);
+        if (e == hipSuccess) e = hipMemcpy(b->env_part_dev, env_part_id, sizeof(int) * n_envs, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->painted), mask_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last), mask_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->state), state_bytes);
+    if (e == hipSuccess) e = hipMemset(b->painted, 0, mask_bytes);
+    if (e == hipSuccess) e = hipMemset(b->last, 0, mask_bytes);
+    if (e == hipSuccess) e = hipMemset(b->state, 0, state_bytes);
+    if (e != hipSuccess) {
+        rc = fail(PRL_E_HIP, "batch allocation: %s", hipGetErrorString(e));
+        prl_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return PRL_OK;
+}
+
+void prl_batch_destroy(PrlBatch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (hipEvent_t ev : b->ev_start) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : b->ev_stop) (void)hipEventDestroy(ev);
+    (void)hipFree(b->parts_dev);
+    (void)hipFree(b->cfg_dev);
+    (void)hipFree(b->env_part_dev);
+    (void)hipFree(b->painted);
+    (void)hipFree(b->last);
+    (void)hipFree(b->state);
+    delete b;
+}
+
+int prl_batch_mask_stride(const PrlBatch *b) { return b ? b->mask_stride : fail(PRL_E_INVALID, "null batch"); }
+
+int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start_idx, double *obs, void *stream) {
+    if (!b) return fail(PRL_E_INVALID, "null batch");
+    StepArgs a = base_args(b);
+    a.reset_mask = reset_mask;
+    a.start_idx = start_idx;
+    a.obs = obs;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (b->kw) {
+    case 1: launch_reset<1>(a, s); break;
+    case 2: launch_reset<2>(a, s); break;
+    case 3: launch_reset<3>(a, s); break;
+    default: launch_reset<4>(a, s); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward, uint8_t *done, double *info,
+                   double *final_obs, const int32_t *start_idx, void *stream) {
+    if (!b || !actions || !obs || !reward || !done || !info) return fail(PRL_E_INVALID, "null argument");
+    StepArgs a = base_args(b);
+    a.actions = actions;
+    a.obs = obs;
+    a.reward = reward;
+    a.done = done;
+    a.info = info;
+    a.final_obs = final_obs;
+    a.start_idx = start_idx;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (b->timing) {
+        if (b->ev_used == b->ev_start.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            b->ev_start.push_back(e0);
+            b->ev_stop.push_back(e1);
+        }
+        HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
+    }
+    switch (b->kw) {
+    case 1: launch_step<1>(a, s); break;
+    case 2: launch_step<2>(a, s); break;
+    case 3: launch_step<3>(a, s); break;
+    default: launch_step<4>(a, s); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (b->timing) {
+        HIP_TRY(hipEventRecord(b->ev_stop[b->ev_used], s));
+        b->ev_used += 1;
+    }
+    return PRL_OK;
+}
+
+int prl_batch_get_mask(PrlBatch *b, uint64_t *painted, void *stream) {
+    if (!b || !painted) return fail(PRL_E_INVALID, "null argument");
+    HIP_TRY(hipMemcpyAsync(painted, b->painted, (size_t)b->n_envs * b->mask_stride * sizeof(uint64_t),
+                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return PRL_OK;
+}
+
+int prl_batch_get_state(PrlBatch *b, double *state, void *stream) {
+    if (!b || !state) return fail(PRL_E_INVALID, "null argument");
+    HIP_TRY(hipMemcpyAsync(state, b->state, (size_t)b->n_envs * PRL_STATE_DOUBLES * sizeof(double),
+                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return PRL_OK;
+}
+
+int prl_batch_get_returns(PrlBatch *b, double *episode_return, void *stream) {
+    if (!b || !episode_return) return fail(PRL_E_INVALID, "null argument");
+    hipLaunchKernelGGL(gather_state_kernel, dim3((b->n_envs + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), b->state, b->n_envs, 13, episode_return);
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_ray_batch(PrlPart *p, int n, const double *from, const double *to, int32_t *tri, double *frac, double *pos,
+                  void *stream) {
+    if (!p || n < 0 || !from || !to || !tri || !frac || !pos) return fail(PRL_E_INVALID, "bad argument");
+    if (n == 0) return PRL_OK;
+    hipLaunchKernelGGL(ray_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       p->dev_copy, n, from, to, tri, frac, pos);
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_batch_timing_enable(PrlBatch *b, int enable) {
+    if (!b) return fail(PRL_E_INVALID, "null batch");
+    b->timing = enable != 0;
+    b->ev_used = 0;
+    return PRL_OK;
+}
+
+int prl_batch_timing_read(PrlBatch *b, double *total_ms, int64_t *launches) {
+    if (!b || !total_ms || !launches) return fail(PRL_E_INVALID, "null argument");
+    double sum = 0;
+    for (size_t i = 0; i < b->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(b->ev_stop[i]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev_start[i], b->ev_stop[i]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)b->ev_used;
+    b->ev_used = 0;
+    return PRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""PartTables (host, reference order) -> the device layout of include/paintrl.h PrlPartTables.
+
+Layout decisions (DESIGN.md "Data layout in HBM"):
+  * samples and same-side vertices are sorted by the cell of a uniform grid over
+    the principal plane (cell edge 0.052 > paint radius 0.051), x-fastest, so the
+    3x3 neighbourhood of a shot is three contiguous index ranges;
+  * a sample's coverage bit is its position in that order; per 64-sample word the
+    table keeps a principal-plane bounding box and a valid-bit mask;
+  * collision triangles are SoA (v0, e1, e2 components) with a float32 box each.
+"""
+import numpy as np
+
+from . import _lib
+from . import part_tables as pt
+
+CELL = 0.052             # > PAINT_RADIUS, so a ball overlaps at most 3x3 cells
+FAR = 1.0e15             # coordinate of padding samples
+
+
+class DeviceTables(object):
+    """Numpy arrays in device layout + the ctypes struct that points at them."""
+
+    def __init__(self, tables, obs_grad=4, start_points=None):
+        t = tables
+        a1, a2 = t.a1, t.a2
+        self.tables = t
+        P = t.sample_pos.shape[0]
+        # ---- samples sorted by grid cell
+        o1, o2 = float(t.sample_pos[:, a1].min()), float(t.sample_pos[:, a2].min())
+        inv = 1.0 / CELL
+        cx = np.floor((t.sample_pos[:, a1] - o1) * inv).astype(np.int64)
+        cy = np.floor((t.sample_pos[:, a2] - o2) * inv).astype(np.int64)
+        nx, ny = int(cx.max()) + 1, int(cy.max()) + 1
+        cell = cy * nx + cx
+        self.perm = np.argsort(cell, kind='stable')          # device position -> canonical sample index
+        self.inv_perm = np.empty(P, dtype=np.int64)
+        self.inv_perm[self.perm] = np.arange(P)
+        n_pad = ((P + 63) // 64) * 64
+        n_words = n_pad // 64
+        xyz = np.full((3, n_pad), FAR, dtype=np.float64)
+        xyz[:, :P] = t.sample_pos[self.perm].T
+        self.sample_xyz = [np.ascontiguousarray(xyz[k]) for k in range(3)]
+        self.sgrid_start = np.searchsorted(cell[self.perm], np.arange(nx * ny + 1)).astype(np.int32)
+        valid = np.zeros(n_pad, dtype=bool)
+        valid[:P] = True
+        self.word_valid = np.packbits(valid, bitorder='little').view(np.uint64).copy()
+        bbox = np.empty((n_words, 4), dtype=np.float64)
+        c1 = np.where(valid, xyz[a1], np.nan).reshape(n_words, 64)
+        c2 = np.where(valid, xyz[a2], np.nan).reshape(n_words, 64)
+        with np.errstate(all='ignore'):
+            bbox[:, 0], bbox[:, 1] = np.nanmin(c1, axis=1), np.nanmax(c1, axis=1)
+            bbox[:, 2], bbox[:, 3] = np.nanmin(c2, axis=1), np.nanmax(c2, axis=1)
+        self.word_bbox = bbox
+        self.n_samples, self.n_samples_pad, self.n_words = P, n_pad, n_words
+        self.sgrid = (o1, o2, inv, nx, ny)
+        # ---- grid-observation cell masks (bpw GridObservation)
+        self.obs_grad = int(obs_grad)
+        cells = t.sample_cell if obs_grad == t.obs_grad else pt.grid_observation_cells(t, obs_grad)
+        n_cells = self.obs_grad ** 2
+        onehot = np.zeros((n_cells, n_pad), dtype=bool)
+        onehot[cells[self.perm], np.arange(P)] = True
+        self.obs_cell_mask = np.packbits(onehot, axis=1, bitorder='little').view(np.uint64).reshape(n_cells, n_words).copy()
+        self.obs_cell_count = np.bincount(cells, minlength=n_cells).astype(np.int32)
+        # ---- same-side vertices sorted by grid cell, CSR adjacency to compact triangle ids
+        side_ids = np.nonzero(t.vertex_is_side)[0]
+        vpos = t._side_data[side_ids]
+        vo1, vo2 = float(vpos[:, a1].min()), float(vpos[:, a2].min())
+        vcx = np.floor((vpos[:, a1] - vo1) * inv).astype(np.int64)
+        vcy = np.floor((vpos[:, a2] - vo2) * inv).astype(np.int64)
+        vnx, vny = int(vcx.max()) + 1, int(vcy.max()) + 1
+        vcell = vcy * vnx + vcx
+        vorder = np.argsort(vcell, kind='stable')
+        self.vertex_xyz = [np.ascontiguousarray(vpos[vorder, k]) for k in range(3)]
+        self.vertex_rank = vorder.astype(np.int32)            # rank in the reference's vertex order
+        self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
+        self.vgrid = (vo1, vo2, inv, vnx, vny)
+        self.vgrid_accept_d2 = (0.99 * CELL) ** 2
+        front_ids = np.nonzero(t.tri_side == pt.SIDE_FRONT)[0]
+        compact = -np.ones(t.tri_side.shape[0], dtype=np.int64)
+        compact[front_ids] = np.arange(front_ids.size)
+        off, adj = [0], []
+        for v in side_ids[vorder]:
+            adj.extend(int(compact[ti]) for ti in t.vertex_adj[v])
+            off.append(len(adj))
+        self.vertex_adj_off = np.asarray(off, dtype=np.int32)
+        self.vertex_adj_tri = np.asarray(adj, dtype=np.int32)
+        # ---- triangle records: a v0 v1 d00 d01 d11 inv normal
+        rec = np.empty((front_ids.size, 16), dtype=np.float64)
+        rec[:, 0:3], rec[:, 3:6], rec[:, 6:9] = t.tri_a[front_ids], t.tri_v0[front_ids], t.tri_v1[front_ids]
+        rec[:, 9], rec[:, 10], rec[:, 11] = t.tri_d00[front_ids], t.tri_d01[front_ids], t.tri_d11[front_ids]
+        rec[:, 12] = t.tri_inv[front_ids]
+        rec[:, 13:16] = t.tri_normal[front_ids]
+        self.tri_records = rec
+        # ---- collision triangles, SoA + float32 boxes (outward by 1e-6 and one float ulp)
+        C0 = t.col_v0.shape[0]
+        c_pad = ((C0 + 63) // 64) * 64
+        col = np.zeros((9, c_pad), dtype=np.float64)
+        col[0:3, :C0], col[3:6, :C0], col[6:9, :C0] = t.col_v0.T, t.col_e1.T, t.col_e2.T
+        self.col = [np.ascontiguousarray(col[k]) for k in range(9)]
+        corners = np.stack([t.col_v0, t.col_v0 + t.col_e1, t.col_v0 + t.col_e2], axis=1)
+        box = np.empty((c_pad, 4), dtype=np.float32)
+        box[:, 0], box[:, 1], box[:, 2], box[:, 3] = np.inf, -np.inf, np.inf, -np.inf
+        lo1, hi1 = corners[:, :, a1].min(1) - 1e-6, corners[:, :, a1].max(1) + 1e-6
+        lo2, hi2 = corners[:, :, a2].min(1) - 1e-6, corners[:, :, a2].max(1) + 1e-6
+        box[:C0, 0] = np.nextafter(lo1.astype(np.float32), np.float32(-np.inf))
+        box[:C0, 1] = np.nextafter(hi1.astype(np.float32), np.float32(np.inf))
+        box[:C0, 2] = np.nextafter(lo2.astype(np.float32), np.float32(-np.inf))
+        box[:C0, 3] = np.nextafter(hi2.astype(np.float32), np.float32(np.inf))
+        self.col_bbox = box
+        self.n_collision, self.n_collision_pad = C0, c_pad
+        # ---- rows, start points, beams
+        self.grid_lo = np.ascontiguousarray(t.grid_lo, dtype=np.float64)
+        self.grid_hi = np.ascontiguousarray(t.grid_hi, dtype=np.float64)
+        if start_points is None:
+            start_points = t.anchor_points
+        self.start_pos = np.asarray([p[0] for p in start_points], dtype=np.float64).reshape(-1, 3)
+        self.start_quat = np.asarray([pt.pose_orn_quaternion(p[1]) for p in start_points],
+                                     dtype=np.float64).reshape(-1, 4)
+        self.beams = np.ascontiguousarray(t.beams, dtype=np.float64)
+
+    # ------------------------------------------------------------------
+    def c_struct(self):
+        """PrlPartTables pointing at this object's arrays (keep ``self`` alive while it is used)."""
+        t = self.tables
+        s = _lib.PrlPartTables()
+
+        def dp(a):
+            return a.ctypes.data_as(_lib._dp)
+
+        def ip(a):
+            return a.ctypes.data_as(_lib._ip)
+
+        s.n_samples, s.n_samples_pad = self.n_samples, self.n_samples_pad
+        for k in range(3):
+            s.sample_xyz[k] = dp(self.sample_xyz[k])
+            s.vertex_xyz[k] = dp(self.vertex_xyz[k])
+        s.word_bbox = dp(self.word_bbox)
+        s.word_valid = self.word_valid.ctypes.data_as(_lib._up)
+        s.sgrid_origin[0], s.sgrid_origin[1], s.sgrid_inv_cell, s.sgrid_nx, s.sgrid_ny = self.sgrid
+        s.sgrid_start = ip(self.sgrid_start)
+        s.n_obs_cells = self.obs_grad ** 2
+        s.obs_cell_mask = self.obs_cell_mask.ctypes.data_as(_lib._up)
+        s.obs_cell_count = ip(self.obs_cell_count)
+        s.n_vertices = self.vertex_rank.shape[0]
+        s.vertex_rank = ip(self.vertex_rank)
+        s.vertex_adj_off, s.vertex_adj_tri = ip(self.vertex_adj_off), ip(self.vertex_adj_tri)
+        s.vgrid_origin[0], s.vgrid_origin[1], s.vgrid_inv_cell, s.vgrid_nx, s.vgrid_ny = self.vgrid
+        s.vgrid_accept_d2 = self.vgrid_accept_d2
+        s.vgrid_start = ip(self.vgrid_start)
+        s.n_triangles = self.tri_records.shape[0]
+        s.tri_records = dp(self.tri_records)
+        s.n_collision, s.n_collision_pad = self.n_collision, self.n_collision_pad
+        for k in range(9):
+            s.col_v0e1e2[k] = dp(self.col[k])
+        s.col_bbox = self.col_bbox.ctypes.data_as(_lib._fp)
+        s.grid_lo, s.grid_hi = dp(self.grid_lo), dp(self.grid_hi)
+        s.range1[0], s.range1[1] = t.ranges[0]
+        s.range2[0], s.range2[1] = t.ranges[1]
+        s.length_width_ratio = t.lwr
+        s.axis0, s.axis1, s.axis2 = t.a0, t.a1, t.a2
+        s.n_start = self.start_pos.shape[0]
+        s.start_pos, s.start_quat = dp(self.start_pos), dp(self.start_quat)
+        s.n_beams = self.beams.shape[0]
+        s.beams = dp(self.beams)
+        return s
+
+    def mask_to_canonical(self, words):
+        """u64[..., n_words] device-order coverage words -> bool[..., P] in canonical sample order
+        (ascending j*W+i, the order of PartTables.sample_pix)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        bits = np.unpackbits(words[..., :self.n_words].view(np.uint8), axis=-1, bitorder='little')
+        bits = bits[..., :self.n_samples].astype(bool)
+        out = np.empty_like(bits)
+        out[..., self.perm] = bits
+        return out

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import env_kwargs_from_cfg, load_episodes, start_points_for, synthetic_tables
+from test_oracle_golden import CASES, PART, replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_env(tables, n, start_points, **kw):
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    obs_grad = kw.get('obs_grad', 4)
+    return BatchedPaintEnv(DeviceTables(tables, obs_grad=obs_grad, start_points=start_points), n, **kw)
+
+
+DEVICE_CASES = [c for c in CASES if 'normal' not in c[1]]      # cone-beam paint is not on device yet
+
+
+@pytest.mark.parametrize('tag,name', DEVICE_CASES)
+def test_gpu_replays_reference_episode(tag, name):
+    ep = load_episodes(tag)[name]
+    cfg = ep['cfg']
+    tables = synthetic_tables(PART[tag])
+    env = _gpu_env(tables, 1, start_points_for(tables, cfg['start_mode']), **env_kwargs_from_cfg(cfg))
+    continuous = cfg['action_mode'] == 'continuous'
+
+    def reset(idx):
+        return env.reset(start_idx=[idx]).cpu().numpy()[0]
+
+    def step(a, want_bits):
+        obs, rew, done, info = env.step([a])
+        bits = env.painted_bits(0) if want_bits else None
+        return obs.cpu().numpy()[0], float(rew[0]), bool(done[0]), info.cpu().numpy()[0], bits
+
+    replay(step, reset, ep, exact=not continuous, atol=1e-9)
+    st = env.state()
+    if not continuous:
+        assert np.array_equal(st['pose'][0], ep['final_pose']) and np.array_equal(st['quat'][0], ep['final_quat'])
+        assert st['total_return'][0] == float(ep['total_return'])
+    env.close()
+
+
+@pytest.mark.parametrize('part,kw', [
+    ('door_test', dict(obs_mode='section')),
+    ('door_test', dict(obs_mode='grid', overlap_penalty=True, turning_penalty=True)),
+    ('door_test', dict(obs_mode='discrete', termination_mode='hybrid')),
+    ('square', dict(obs_mode='section', max_possible_point=14350)),
+    ('square', dict(obs_mode='simple', n_discrete=8, max_possible_point=14350)),
+])
+def test_gpu_matches_oracle_on_random_batch(part, kw):
+    tables = synthetic_tables(part)
+    sp = start_points_for(tables, 'all')
+    n, steps = 192, 40
+    env = _gpu_env(tables, n, sp, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, **kw)
+    rng = np.random.RandomState(11)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    nd = kw.get('n_discrete', 4)
+    for k in range(steps):
+        a = rng.randint(0, nd, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(i.cpu().numpy(), ii), 'reward, step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        # finished envs restart from a fresh start point on both sides
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            o2 = env.reset(mask=dd, start_idx=new).cpu().numpy()
+            o3 = orc.reset(new, mask=dd)
+            assert np.array_equal(o2[dd], o3[dd])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = env.parts[0].mask_to_canonical(words)
+    for e in range(n):
+        assert np.array_equal(bits[e], orc.painted_bits(e)), 'painted set, env %d' % e
+    st = env.state()
+    for e in range(n):
+        so = orc.state(e)
+        assert np.array_equal(st['pose'][e], so['pose']) and np.array_equal(st['quat'][e], so['quat'])
+        assert st['total_return'][e] == so['total_return'] and st['step_counter'][e] == so['step_counter']
+    env.close()
+
+
+def test_gpu_auto_reset_matches_manual_reset():
+    """auto_reset inside the step kernel == done -> reset with the same start index."""
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n, steps = 128, 60
+    env_a = _gpu_env(tables, n, sp, auto_reset=True)
+    env_m = _gpu_env(tables, n, sp)
+    rng = np.random.RandomState(5)
+    start = rng.randint(0, len(sp), size=n)
+    env_a.reset(start_idx=start)
+    env_m.reset(start_idx=start)
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        nxt = rng.randint(0, len(sp), size=n)
+        oa, ra, da, ia = env_a.step(a, start_idx=nxt)
+        fa = env_a.final_obs.cpu().numpy()
+        oa, ra, da = oa.cpu().numpy().copy(), ra.cpu().numpy().copy(), da.cpu().numpy().copy()
+        om, rm, dm, im = env_m.step(a)
+        om, dm = om.cpu().numpy().copy(), dm.cpu().numpy().copy()
+        assert np.array_equal(da, dm) and np.array_equal(ra, rm.cpu().numpy())
+        assert np.array_equal(oa[~dm], om[~dm]) and np.array_equal(fa[dm], om[dm])
+        if dm.any():
+            o2 = env_m.reset(mask=dm, start_idx=nxt).cpu().numpy()
+            assert np.array_equal(oa[dm], o2[dm])
+    assert np.array_equal(env_a.painted_words().cpu().numpy(), env_m.painted_words().cpu().numpy())
+    assert (env_a.state()['episode'] >= 1).all()
+    env_a.close()
+    env_m.close()
+
+
+def test_gpu_ray_batch_matches_numpy_and_oracle():
+    from paintrl_amd import geometry as geo
+    tables = synthetic_tables('door_test')
+    env = _gpu_env(tables, 1, None)
+    rng = np.random.RandomState(2)
+    n = 3000
+    o = np.stack([rng.uniform(-0.2, 0.3, n), rng.uniform(-0.8, 0.6, n), rng.uniform(0.1, 1.3, n)], axis=1)
+    d = o + np.stack([-rng.uniform(0.2, 1.0, n), rng.normal(0, 0.2, n), rng.normal(0, 0.2, n)], axis=1)
+    idx, t, pos = geo.ray_closest_hit(tables.col_v0, tables.col_e1, tables.col_e2, o, d)
+    gi, gt, gp = env.ray_test_batch(o, d)
+    gi, gt, gp = gi.cpu().numpy(), gt.cpu().numpy(), gp.cpu().numpy()
+    assert (idx >= 0).sum() > 500 and (idx < 0).sum() > 100
+    assert np.array_equal(gi, idx)
+    hit = idx >= 0
+    assert np.array_equal(gt[hit], t[hit]) and np.array_equal(gp[hit], pos[hit])
+    oi, ot, op = oracle.Oracle(tables, 1).ray_batch(o, d)
+    assert np.array_equal(oi, idx) and np.array_equal(ot[hit], t[hit]) and np.array_equal(op[hit], pos[hit])
+    env.close()
+
+
+def test_gpu_mixed_part_batch():
+    """Config 5: door and sheet envs interleaved in one batch, each equal to its oracle."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    door, sheet = synthetic_tables('door_test'), synthetic_tables('square')
+    sp_d, sp_s = start_points_for(door, 'anchor'), start_points_for(sheet, 'anchor')
+    n = 64
+    ids = (np.arange(n) % 2).astype(np.int32)
+    env = BatchedPaintEnv([DeviceTables(door, start_points=sp_d), DeviceTables(sheet, start_points=sp_s)], n,
+                          env_part_id=ids, max_possible_point=[9148, 14350])
+    od = oracle.Oracle(door, n // 2, start_points=sp_d, max_possible_point=9148)
+    os_ = oracle.Oracle(sheet, n // 2, start_points=sp_s, max_possible_point=14350)
+    start = np.arange(n) % 4
+    obs = env.reset(start_idx=start).cpu().numpy()
+    assert np.array_equal(obs[0::2], od.reset(start[0::2])) and np.array_equal(obs[1::2], os_.reset(start[1::2]))
+    rng = np.random.RandomState(9)
+    for k in range(25):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        o1, r1, d1, _ = od.step(a[0::2])
+        o2, r2, d2, _ = os_.step(a[1::2])
+        assert np.array_equal(o[0::2], o1) and np.array_equal(o[1::2], o2)
+        assert np.array_equal(r[0::2], r1) and np.array_equal(r[1::2], r2)
+        assert np.array_equal(d[0::2], d1) and np.array_equal(d[1::2], d2)
+    env.close()
