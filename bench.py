@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched paint-coverage step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic door panel
+(seed-0 generator, 9664 front samples, 742 hull facets), OBS_MODE='section',
+OBS_GRAD=4, START_POINT_MODE='anchor', TERMINATION_MODE='late',
+EPISODE_MAX_LENGTH=245, fast paint, 4096 envs per GPU, random discrete-4 actions
+from a device generator seeded 1234, auto-reset inside the step kernel with the
+library's counter-based start-point RNG (seed 5678).  One "step" = one batched
+PaintGymEnv.step() of all 4096 envs of a GPU = one launch of step_kernel.
+
+For N > 1 the driver starts one process per GPU with torch.distributed.run; envs
+are sharded (weak scaling, 4096 per GPU, no data-path collective) and every 100
+steps the ranks all_gather their episode returns over RCCL.
+
+Prints ONE JSON line on rank 0 (see README / the task contract), including
+"roofline" for step_kernel and "cpu_baseline" (the C oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ENVS_PER_GPU = 4096
+FRAGMENT = 100                  # rollout fragment length (paint_ppo.py:190 sample_batch_size)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(dt, n_envs, obs_dim):
+    """Minimal HBM bytes of one step launch (DESIGN.md "Roofline accounting")."""
+    words = dt.n_words
+    per_env = (2 * 2 * words * 8          # painted + last-shot masks, read and write
+               + 2 * 16 * 8               # 128-byte scalar state record, read and write
+               + 4                        # action (int32)
+               + obs_dim * 8 + 8 + 1 + 16)  # obs, reward, done, info (float64 like the reference)
+    static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sgrid_start.nbytes
+              + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj_off.nbytes
+              + dt.vertex_adj_tri.nbytes + dt.vgrid_start.nbytes + dt.tri_records.nbytes
+              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
+              + dt.start_pos.nbytes + dt.start_quat.nbytes)
+    return per_env, static, per_env * n_envs + static
+
+
+def cpu_baseline(tables, steps_sample=25, n_envs=ENVS_PER_GPU):
+    """The C oracle (a scalar float64 port of the reference step()) on all host cores."""
+    import numpy as np
+    import oracle
+    cores = os.cpu_count() or 1
+    orc = oracle.Oracle(tables, n_envs, threads=cores)
+    rng = np.random.RandomState(1234)
+    start = rng.randint(0, 4, size=n_envs)
+    orc.reset(start)
+    acts = rng.randint(0, 4, size=(steps_sample, n_envs))
+    t0 = time.perf_counter()
+    for k in range(steps_sample):
+        _, _, done, _ = orc.step(acts[k])
+        if done.any():
+            orc.reset(rng.randint(0, 4, size=n_envs), mask=done)
+    dt = time.perf_counter() - t0
+    return {'value': steps_sample / dt, 'unit': 'batched steps/s (4096 envs each)', 'cores': cores,
+            'kind': 'port', 'env_steps_per_s': steps_sample * n_envs / dt,
+            'sample': '%d batched steps of %d envs (same door, same action distribution, reset on done), '
+                      'oracle/paint_oracle.c with OpenMP over envs, %.1f s wall' % (steps_sample, n_envs, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--envs', type=int, default=ENVS_PER_GPU, help='envs per GPU (default: the BASELINE config)')
+    ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from paintrl_amd import distributed as pdist
+    from paintrl_amd import part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+
+    rank, local_rank, world = pdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240),
+                                           name='door_test')
+    dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, 'anchor'))
+    overlap = args.obs_mode == 'grid'
+    env = BatchedPaintEnv(dt, args.envs, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
+                          overlap_penalty=overlap, seed=pdist.rank_seed(5678, rank), max_possible_point=9148)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    total = args.steps + args.warmup
+    actions = torch.randint(0, 4, (total, args.envs), generator=gen, device=device, dtype=torch.int32)
+    env.reset()
+    stream_sync = torch.cuda.synchronize
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            env.step_raw(actions[k])
+            if world > 1 and (k + 1) % FRAGMENT == 0:
+                pdist.gather_returns(env.episode_returns())
+
+    run(0, args.warmup)
+    stream_sync()
+    pdist.barrier()
+    stream_sync()
+    env.timing(True)
+    t0 = time.perf_counter()
+    run(args.warmup, total)
+    stream_sync()
+    pdist.barrier()
+    stream_sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = env.timing_read()
+    env.timing(False)
+    elapsed = pdist.max_over_ranks(elapsed, device)
+
+    st = env.state()
+    episodes = int(st['episode'].sum()) - args.envs
+    if rank == 0:
+        per_env, static, per_launch = algorithmic_bytes(dt, args.envs, env.obs_dim)
+        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        achieved = per_launch / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+        if os.path.isfile(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get('bytes_per_launch_%s' % args.obs_mode)
+        value = world * args.steps / elapsed
+        out = {
+            'metric': 'batched env steps/sec (door panel, N=4096)', 'value': value,
+            'unit': 'batched steps/s (4096 envs each)', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
+                                   'random discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs),
+                       'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
+                       'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
+                       'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_env_step': per_env, 'static_table_bytes': static,
+                         'bytes_per_launch': per_launch, 'avg_kernel_us': avg_kernel_s * 1e6,
+                         'launches_timed': int(launches)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of independent environments.
+
+Envs are independent, so the path shards with no data-path collective: global
+env id e lives on rank e // envs_per_rank, every rank holds a replica of the
+part tables, actions are produced rank-locally.  The only exchange is the
+gather of per-env episode returns once per rollout fragment (the analogue of
+RLlib's worker -> learner metrics flow, paint_ppo.py:36-61): one all_gather of
+envs_per_rank float64 values over RCCL (backend "nccl" on ROCm) or gloo on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), \
+        int(os.environ.get('WORLD_SIZE', '1'))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block of global env ids owned by ``rank`` (n_total must divide evenly)."""
+    if n_total % world:
+        raise ValueError('n_total=%d is not divisible by world size %d' % (n_total, world))
+    per = n_total // world
+    return rank * per, (rank + 1) * per
+
+
+def rank_seed(base_seed, rank):
+    """Decorrelate the per-rank start-point RNG streams (the kernel hashes seed ^ env ^ episode)."""
+    return (int(base_seed) + 0x9E3779B97F4A7C15 * (rank + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def gather_returns(local_returns):
+    """all_gather the per-env episode returns of every rank -> tensor (world * n_local,).
+
+    ``local_returns`` is a 1-D tensor on the rank's device (cuda with RCCL, cpu with gloo)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_returns.clone()
+    world = dist.get_world_size()
+    out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(out, local_returns.contiguous())
+    return out
+
+
+def max_over_ranks(value, device):
+    """MAX-reduce a python float over ranks (used for the timed region of bench.py)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
