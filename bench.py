@@ -40,9 +40,9 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
                + 4                        # action (int32)
                + obs_dim * 8 + 8 + 1 + 16)  # obs, reward, done, info (float64 like the reference)
     static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sgrid_start.nbytes
-              + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj_off.nbytes
-              + dt.vertex_adj_tri.nbytes + dt.vgrid_start.nbytes + dt.tri_records.nbytes
-              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
+              + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
+              + dt.vgrid_start.nbytes + dt.tri_records.nbytes
+              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
               + dt.start_pos.nbytes + dt.start_quat.nbytes)
     return per_env, static, per_env * n_envs + static
 

@@ -65,9 +65,10 @@ typedef struct {
     int32_t n_vertices;
     const double *vertex_xyz[3];
     const int32_t *vertex_rank;      /* original order, the nearest-vertex tie break */
-    const int32_t *vertex_adj_off;   /* [n_vertices+1] CSR into vertex_adj_tri (bpw uv_map) */
-    const int32_t *vertex_adj_tri;
-    double vgrid_origin[2], vgrid_inv_cell, vgrid_accept_d2;
+    int32_t adj_width;               /* incident same-side triangles per vertex, padded (<= 64) */
+    const int32_t *vertex_adj;       /* [n_vertices][adj_width] triangle ids in file order (bpw uv_map), -1 = pad */
+    double vgrid_origin[2], vgrid_inv_cell;
+    double vgrid_accept;             /* 0.99 * cell edge: a ring-k search is exact within k * this distance */
     int32_t vgrid_nx, vgrid_ny;
     const int32_t *vgrid_start;      /* [nx*ny+1] */
     /* same-side triangle records (bpw BarycentricInterpolator), 16 doubles each:
@@ -79,6 +80,8 @@ typedef struct {
     int32_t n_collision_pad;
     const double *col_v0e1e2[9];     /* v0.xyz e1.xyz e2.xyz, [n_collision_pad] each */
     const float *col_bbox;           /* [n_collision_pad][4] outward-rounded principal-plane box */
+    int32_t n_col_chunks;            /* n_collision_pad / 64 */
+    const float *col_chunk_bbox;     /* [n_col_chunks padded to 64][4] union box of each 64-triangle chunk */
     /* grid rows (bpw grid_dict), extents, axes */
     const double *grid_lo, *grid_hi; /* [100] */
     double range1[2], range2[2], length_width_ratio;

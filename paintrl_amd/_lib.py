@@ -24,11 +24,12 @@ class PrlPartTables(C.Structure):
         ('sgrid_nx', C.c_int32), ('sgrid_ny', C.c_int32), ('sgrid_start', _ip),
         ('n_obs_cells', C.c_int32), ('obs_cell_mask', _up), ('obs_cell_count', _ip),
         ('n_vertices', C.c_int32), ('vertex_xyz', _dp * 3), ('vertex_rank', _ip),
-        ('vertex_adj_off', _ip), ('vertex_adj_tri', _ip),
-        ('vgrid_origin', C.c_double * 2), ('vgrid_inv_cell', C.c_double), ('vgrid_accept_d2', C.c_double),
+        ('adj_width', C.c_int32), ('vertex_adj', _ip),
+        ('vgrid_origin', C.c_double * 2), ('vgrid_inv_cell', C.c_double), ('vgrid_accept', C.c_double),
         ('vgrid_nx', C.c_int32), ('vgrid_ny', C.c_int32), ('vgrid_start', _ip),
         ('n_triangles', C.c_int32), ('tri_records', _dp),
         ('n_collision', C.c_int32), ('n_collision_pad', C.c_int32), ('col_v0e1e2', _dp * 9), ('col_bbox', _fp),
+        ('n_col_chunks', C.c_int32), ('col_chunk_bbox', _fp),
         ('grid_lo', _dp), ('grid_hi', _dp),
         ('range1', C.c_double * 2), ('range2', C.c_double * 2), ('length_width_ratio', C.c_double),
         ('axis0', C.c_int32), ('axis1', C.c_int32), ('axis2', C.c_int32),

@@ -47,37 +47,51 @@ constexpr double RAY_EPS_DET = 1e-12;
 constexpr double RAY_EPS_BARY = 1e-9;
 constexpr double PI = 3.141592653589793;
 
+// Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
+// space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
+// (address space 1) gives global_load with counted vmcnt waits.
+#define GAS __attribute__((address_space(1)))
+typedef const double GAS *gdouble_p;
+typedef const float GAS *gfloat_p;
+typedef const int GAS *gint_p;
+typedef const uint64_t GAS *gu64_p;
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 struct PartDev {
     int n_samples, n_samples_pad, n_words;
-    const double *samp[3];
-    const double *word_bbox;
-    const uint64_t *word_valid;
+    gdouble_p samp[3];
+    gdouble_p word_bbox;
+    gu64_p word_valid;
     double sg_o1, sg_o2, sg_inv;
     int sg_nx, sg_ny;
-    const int *sg_start;
+    gint_p sg_start;
     int n_obs_cells;
-    const uint64_t *cell_mask;
-    const int *cell_count;
+    gu64_p cell_mask;
+    gint_p cell_count;
     int n_vertices;
-    const double *vert[3];
-    const int *vert_rank;
-    const int *vadj_off;
-    const int *vadj_tri;
-    double vg_o1, vg_o2, vg_inv, vg_accept_d2;
+    gdouble_p vert[3];
+    gint_p vert_rank;
+    int adj_width;
+    gint_p vadj;
+    double vg_o1, vg_o2, vg_inv, vg_accept;
     int vg_nx, vg_ny;
-    const int *vg_start;
+    gint_p vg_start;
     int n_triangles;
-    const double *tri_rec;
+    gdouble_p tri_rec;
     int n_col, n_col_pad;
-    const double *col[9];
-    const float *col_bbox;
-    const double *grid_lo, *grid_hi;
+    gdouble_p col[9];
+    gfloat_p col_bbox;
+    int n_col_chunks;
+    gfloat_p col_chunk_bbox;
+    gdouble_p grid_lo, grid_hi;
     double r1min, r1max, r2min, r2max, lwr;
     int a0, a1, a2;
     int n_start;
-    const double *start_pos, *start_quat;
+    gdouble_p start_pos, start_quat;
     int n_beams;
-    const double *beams;
+    gdouble_p beams;
 };
 
 struct StepArgs {
@@ -93,6 +107,36 @@ struct StepArgs {
     const int *start_idx;
     const uint8_t *reset_mask;
 };
+
+// ---------------------------------------------------------------- diagnostic build only (-DPRL_PHASE_TIMING)
+// Per-phase s_memtime deltas summed over all waves into a buffer nothing else reads
+// (cdna_hip_programming.md "In-kernel stamps").  The product build contains no stamp.
+#ifdef PRL_PHASE_TIMING
+enum { PH_LOAD = 0, PH_RAY, PH_VERTEX, PH_BARY, PH_MATH, PH_BALL, PH_APPLY, PH_OBS, PH_STORE, PH_COUNT };
+__device__ unsigned long long g_phase_cycles[16];
+struct Prof {
+    unsigned long long acc[PH_COUNT];
+    unsigned long long prev;
+};
+#define PROF_ARG , Prof &prof
+#define PROF_PASS , prof
+#define STAMP(ph)                                                         \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        __builtin_amdgcn_s_waitcnt(0);                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+        prof.acc[ph] += now_ - prof.prev;                                 \
+        prof.prev = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define STAMP(ph) \
+    do {          \
+    } while (0)
+#endif
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -113,31 +157,48 @@ __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
     return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// Wave-wide min/max by DPP row shifts + row broadcasts (VALU speed) instead of ds_bpermute chains.
+// After the six steps lane 63 holds the reduction of all 64 lanes; it is broadcast with readlane.
+// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.  Lanes with no source
+// (bound_ctrl off) keep `old`, which is the lane's own value -- harmless for idempotent min/max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+#define WAVE_REDUCE_DPP(T, v, OP, DPPF)               \
+    do {                                              \
+        T x_;                                         \
+        x_ = DPPF<0x111, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x112, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x114, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x118, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x142, 0xa>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x143, 0xc>(v); v = OP(x_, v);      \
+    } while (0)
+
+#define OP_MIN(x, y) ((x) < (y) ? (x) : (y))
+#define OP_MAX(x, y) ((x) > (y) ? (x) : (y))
+
 __device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        double x = __shfl_xor(v, o);
-        v = x < v ? x : v;
-    }
-    return v;
+    WAVE_REDUCE_DPP(double, v, OP_MIN, dpp_d);
+    return bcast_d(v, 63);
 }
 
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        double x = __shfl_xor(v, o);
-        v = x > v ? x : v;
-    }
-    return v;
+    WAVE_REDUCE_DPP(double, v, OP_MAX, dpp_d);
+    return bcast_d(v, 63);
 }
 
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-        int x = __shfl_xor(v, o);
-        v = x < v ? x : v;
-    }
-    return v;
+    WAVE_REDUCE_DPP(int, v, OP_MIN, dpp_i);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
@@ -214,6 +275,8 @@ __device__ __forceinline__ int cell_coord(double x, double origin, double inv, i
 }
 
 // ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
+// Two-level cull: lane c tests the union box of 64-triangle chunk c, then only the chunks whose box
+// overlaps the segment are visited (one triangle per lane, box + 9 doubles loaded in one round trip).
 __device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
                                 double hit[3]) {
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
@@ -225,42 +288,46 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
     const float s2lo = nextafterf((float)fmin(o2, e2p), -INFINITY), s2hi = nextafterf((float)fmax(o2, e2p), INFINITY);
     double best_t = INFINITY;
     int best_i = 0x7fffffff;
-    const float4 *boxes = reinterpret_cast<const float4 *>(P.col_bbox);
-    for (int base = 0; base < P.n_col_pad; base += 64) {
-        const int i = base + lane;
-        const float4 b = boxes[i];                                   // pads carry an empty box
-        const bool cand = (s1lo <= b.y) && (s1hi >= b.x) && (s2lo <= b.w) && (s2hi >= b.z);
-        if (__ballot(cand) == 0) continue;
-        if (cand) {
+    const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
+    const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
+    for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
+        const f32x4 cb = chunk_boxes[cbase + lane];                 // table is padded to 64 with empty boxes
+        uint64_t cm = __ballot((s1lo <= cb.y) && (s1hi >= cb.x) && (s2lo <= cb.w) && (s2hi >= cb.z));
+        while (cm) {
+            const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+            cm &= cm - 1;
+            const f32x4 b = boxes[i];
             const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
             const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
             const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
-            const double p0 = d1 * e22 - d2 * e21;
-            const double p1 = d2 * e20 - d0 * e22;
-            const double p2 = d0 * e21 - d1 * e20;
-            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-            if (fabs(det) >= RAY_EPS_DET) {
-                const double inv = 1.0 / det;
-                const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-                const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-                const double q0 = s1 * e12 - s2 * e11;
-                const double q1 = s2 * e10 - s0 * e12;
-                const double q2 = s0 * e11 - s1 * e10;
-                const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-                const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-                if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
-                    t <= 1.0 && t < best_t) {
-                    best_t = t;
-                    best_i = i;
+            if ((s1lo <= b.y) && (s1hi >= b.x) && (s2lo <= b.w) && (s2hi >= b.z)) {
+                const double p0 = d1 * e22 - d2 * e21;
+                const double p1 = d2 * e20 - d0 * e22;
+                const double p2 = d0 * e21 - d1 * e20;
+                const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+                if (fabs(det) >= RAY_EPS_DET) {
+                    const double inv = 1.0 / det;
+                    const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+                    const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+                    const double q0 = s1 * e12 - s2 * e11;
+                    const double q1 = s2 * e10 - s0 * e12;
+                    const double q2 = s0 * e11 - s1 * e10;
+                    const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+                    const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+                    if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
+                        t <= 1.0 && t < best_t) {
+                        best_t = t;
+                        best_i = i;
+                    }
                 }
             }
         }
     }
-    const double tmin = wave_min_d(best_t);
-    if (!(tmin < INFINITY)) {
+    if (__ballot(best_t < INFINITY) == 0) {
         t_out = INFINITY;
         return -1;
     }
+    const double tmin = wave_min_d(best_t);
     const int imin = wave_min_i(best_t == tmin ? best_i : 0x7fffffff);   // equal t: lowest triangle index
     t_out = tmin;
     hit[0] = o[0] + tmin * d0;
@@ -270,61 +337,149 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
 }
 
 // ---------------------------------------------------------------- bpw:526 nearest same-side vertex
+// Grid rows cy-1..cy+1 of a uniform grid: each row's three cells are one contiguous index range.
+// Lanes 0..5 fetch the six range bounds in one load; `rows` returns them wave-uniform.
+struct Rows3 {
+    int begin[3], count[3];
+};
+
+__device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int icx, int icy, int lane) {
+    const int r = lane >> 1, cy = icy - 1 + r;
+    const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > nx - 1 ? nx - 1 : icx + 1;
+    const bool ok = lane < 6 && cy >= 0 && cy < ny && cx0 <= cx1;
+    const int v = ok ? start[cy * nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+    Rows3 out;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int b = __builtin_amdgcn_readlane(v, 2 * k), e = __builtin_amdgcn_readlane(v, 2 * k + 1);
+        out.begin[k] = b;
+        out.count[k] = e - b;
+    }
+    return out;
+}
+
 __device__ __forceinline__ void nv_scan(const PartDev &P, int begin, int end, const double pt[3], int lane,
                                         double &best_d, int &best_rank, int &best_idx) {
-    for (int b = begin; b < end; b += 64) {
-        const int v = b + lane;
-        if (v < end) {
-            const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
+    for (int b = begin; b < end; b += 128) {                   // two batches per trip: eight loads in flight
+        const int v0 = b + lane, v1 = v0 + 64;
+        const bool k0 = v0 < end, k1 = v1 < end;
+        double x0 = 0, y0 = 0, z0 = 0, x1 = 0, y1 = 0, z1 = 0;
+        int r0 = 0, r1 = 0;
+        if (k0) {
+            x0 = P.vert[0][v0];
+            y0 = P.vert[1][v0];
+            z0 = P.vert[2][v0];
+            r0 = P.vert_rank[v0];
+        }
+        if (k1) {
+            x1 = P.vert[0][v1];
+            y1 = P.vert[1][v1];
+            z1 = P.vert[2][v1];
+            r1 = P.vert_rank[v1];
+        }
+        if (k0) {
+            const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            const int rk = P.vert_rank[v];
-            if (dd < best_d || (dd == best_d && rk < best_rank)) {
+            if (dd < best_d || (dd == best_d && r0 < best_rank)) {
                 best_d = dd;
-                best_rank = rk;
-                best_idx = v;
+                best_rank = r0;
+                best_idx = v0;
+            }
+        }
+        if (k1) {
+            const double dx = x1 - pt[0], dy = y1 - pt[1], dz = z1 - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd < best_d || (dd == best_d && r1 < best_rank)) {
+                best_d = dd;
+                best_rank = r1;
+                best_idx = v1;
             }
         }
     }
 }
 
+// Exact nearest neighbour by expanding rings: the (2k+1)^2 cell block around the query's cell is
+// scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
+// outside the block is at least k cells away in the principal plane, so the result is exact once the
+// best distance is within k * 0.99 * cell.  After ring 3 the whole table is scanned.
 __device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lane) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
-    double best_d = INFINITY;
+    double best_d = INFINITY, dmin = INFINITY;
     int best_rank = 0x7fffffff, best_idx = -1;
-    for (int cy = icy - 1; cy <= icy + 1; ++cy) {
-        if (cy < 0 || cy >= P.vg_ny) continue;
-        const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > P.vg_nx - 1 ? P.vg_nx - 1 : icx + 1;
-        if (cx0 > cx1) continue;
-        nv_scan(P, P.vg_start[cy * P.vg_nx + cx0], P.vg_start[cy * P.vg_nx + cx1 + 1], pt, lane, best_d, best_rank,
-                best_idx);
+    bool exact = false;
+    for (int ring = 1; ring <= 3 && !exact; ++ring) {
+        const int nrows = 2 * ring + 1;
+        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
+        const int rcy = icy - ring + (lane >> 1);
+        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
+        const int bound = okr ? P.vg_start[rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        // per-row begin and exclusive prefix of counts, wave-uniform (<= 7 rows)
+        int rbeg[7], rpre[8];
+        rpre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+            rbeg[r] = b0;
+            rpre[r + 1] = rpre[r] + ((r < nrows) ? e0 - b0 : 0);
+        }
+        const int total = rpre[7];
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < total) {
+                int v = rbeg[0] + c;
+#pragma unroll
+                for (int r = 1; r < 7; ++r)
+                    if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
+                const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                const int rk = P.vert_rank[v];
+                if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                    best_d = dd;
+                    best_rank = rk;
+                    best_idx = v;
+                }
+            }
+        }
+        dmin = wave_min_d(best_d);
+        const double lim = ring * P.vg_accept;          // ring * 0.99 * cell
+        exact = dmin <= lim * lim;
     }
-    double dmin = wave_min_d(best_d);
-    if (!(dmin <= P.vg_accept_d2)) {   // a vertex outside the 3x3 block could be nearer: exact scan of all vertices
+    if (!exact) {
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
         nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
         dmin = wave_min_d(best_d);
     }
+    const uint64_t tie = __ballot(best_d == dmin);
+    if (tie == 0) return -1;                                        // NaN query point
+    if ((tie & (tie - 1)) == 0) return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(tie)));
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
     const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
-    if (win == 0) return -1;                                        // NaN query point
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
 
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
-__device__ bool hook_point_wave(const PartDev &P, const double pt[3], int lane, double pose[3], double orn[3]) {
+__device__ bool hook_point_wave(const PartDev &P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
+#ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
+    const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
+#else
     const int vidx = nearest_vertex_wave(P, pt, lane);
+#endif
+    STAMP(PH_VERTEX);
     if (vidx < 0) return false;
-    const int k0 = P.vadj_off[vidx], cnt = P.vadj_off[vidx + 1] - k0;     // <= 64, checked at upload
-    if (cnt <= 0) return false;
+    const int ti = lane < P.adj_width ? P.vadj[vidx * P.adj_width + lane] : -1;   // file order, -1 = pad
+    if (__ballot(ti >= 0) == 0) return false;
     bool inside = false, ok = false;
     double m = -INFINITY, n0 = 0, n1 = 0, n2 = 0;
-    if (lane < cnt) {
-        const double *r = P.tri_rec + (size_t)P.vadj_tri[k0 + lane] * 16;
-        const double2 *r2 = reinterpret_cast<const double2 *>(r);
-        const double2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
+    if (ti >= 0) {
+        gdouble_p r = P.tri_rec + (size_t)ti * 16;
+        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(r);
+        const f64x2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
         // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
         const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
         const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
@@ -368,34 +523,150 @@ __device__ bool hook_point_wave(const PartDev &P, const double pt[3], int lane, 
     orn[0] = -n0;
     orn[1] = -n1;
     orn[2] = -n2;
+    STAMP(PH_BARY);
     return true;
 }
 
 // ---------------------------------------------------------------- bpw:568-570 fast_paint (ball query)
 template <int KW>
+__device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b, int lane) {
+    const int owner = w & 63, slot = w >> 6;
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+        if (k == slot && lane == owner) cur[k] |= b;
+}
+
+template <int KW>
 __device__ void ball_query_wave(const PartDev &P, const double c[3], int lane, uint64_t cur[KW_MAX]) {
     const double r2 = PAINT_RADIUS * PAINT_RADIUS;
     const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
     const int icx = cell_coord(c1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(c2, P.sg_o2, P.sg_inv, P.sg_ny);
-    for (int cy = icy - 1; cy <= icy + 1; ++cy) {
-        if (cy < 0 || cy >= P.sg_ny) continue;
-        const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : icx + 1;
-        if (cx0 > cx1) continue;
-        const int begin = P.sg_start[cy * P.sg_nx + cx0], end = P.sg_start[cy * P.sg_nx + cx1 + 1];
-        if (begin >= end) continue;
-        for (int w = begin >> 6; w <= (end - 1) >> 6; ++w) {
-            const int s = (w << 6) + lane;
-            const double dx = P.samp[0][s] - c[0], dy = P.samp[1][s] - c[1], dz = P.samp[2][s] - c[2];
-            const double dd = (dx * dx + dy * dy) + dz * dz;
-            const uint64_t b = __ballot(s >= begin && s < end && dd <= r2);
-            if (b) {
-                const int owner = w & 63, slot = w >> 6;
+    const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
 #pragma unroll
-                for (int k = 0; k < KW; ++k)
-                    if (k == slot && lane == owner) cur[k] |= b;
+    for (int r = 0; r < 3; ++r) {
+        const int begin = R.begin[r], end = begin + R.count[r];
+        if (R.count[r] <= 0) continue;
+        const int wlast = (end - 1) >> 6;
+        for (int w = begin >> 6; w <= wlast; w += 2) {            // two words per trip: six loads in flight
+            const int s0 = (w << 6) + lane, s1 = s0 + 64;
+            const bool two = w + 1 <= wlast;
+            const double x0 = P.samp[0][s0], y0 = P.samp[1][s0], z0 = P.samp[2][s0];
+            double x1 = 0, y1 = 0, z1 = 0;
+            if (two) {
+                x1 = P.samp[0][s1];
+                y1 = P.samp[1][s1];
+                z1 = P.samp[2][s1];
+            }
+            {
+                const double dx = x0 - c[0], dy = y0 - c[1], dz = z0 - c[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                const uint64_t b = __ballot(s0 >= begin && s0 < end && dd <= r2);
+                if (b) set_word<KW>(cur, w, b, lane);
+            }
+            if (two) {
+                const double dx = x1 - c[0], dy = y1 - c[1], dz = z1 - c[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                const uint64_t b = __ballot(s1 >= begin && s1 < end && dd <= r2);
+                if (b) set_word<KW>(cur, w + 1, b, lane);
             }
         }
     }
+}
+
+// ---------------------------------------------------------------- the five shots of one step, painted together
+// The five shot centres of a step are 0.0102 apart, so their 3x3 neighbourhoods overlap almost
+// entirely.  Each candidate sample is loaded once and tested against all five centres; the per-word
+// hit ballots b_0..b_4 are wave-uniform, so the reference's shot-by-shot bookkeeping (bpw:572-577:
+// count newly painted, paint, valid = affected minus last shot, last = affected) runs on the scalar
+// unit for that word and is written back to the lane that owns the word.  Words outside the
+// neighbourhood have no hits in any shot: painted is unchanged and their last-shot bits become 0.
+// The centres are written to LDS by the shot loop (a register array indexed by the runtime shot
+// number would live in scratch) and read back wave-uniformly here.
+struct ShotCentres {
+    double c[PAINT_PER_ACTION][3];
+};
+
+template <int KW>
+__device__ bool paint_shots_union(const PartDev &P, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
+                                  const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
+                                  int &pixel_counter) {
+    const double r2 = PAINT_RADIUS * PAINT_RADIUS;
+    ShotCentres sc;
+#pragma unroll
+    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+        sc.c[k][0] = cen_lds[3 * k];
+        sc.c[k][1] = cen_lds[3 * k + 1];
+        sc.c[k][2] = cen_lds[3 * k + 2];
+    }
+    int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+        const int icx = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a1), P.sg_o1, P.sg_inv, P.sg_nx);
+        const int icy = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a2), P.sg_o2, P.sg_inv, P.sg_ny);
+        cx_lo = icx < cx_lo ? icx : cx_lo;
+        cx_hi = icx > cx_hi ? icx : cx_hi;
+        cy_lo = icy < cy_lo ? icy : cy_lo;
+        cy_hi = icy > cy_hi ? icy : cy_hi;
+    }
+    if (cy_hi - cy_lo > 1) return false;            // centres spread over > 2 cell rows: caller paints shot by shot
+    // rows cy_lo-1 .. cy_hi+1 (<= 4), columns cx_lo-1 .. cx_hi+1: lanes 0..7 fetch the range bounds
+    const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
+    const int rcy = cy_lo - 1 + (lane >> 1);
+    const bool ok = lane < 8 && rcy <= cy_hi + 1 && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
+    const int bound = ok ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+    int rb[4], re[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rb[r] = __builtin_amdgcn_readlane(bound, 2 * r);
+        re[r] = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+    }
+    int done_w = -1;                                 // a word shared by two rows' ranges is handled once
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (re[r] <= rb[r]) continue;
+        const int wlast = (re[r] - 1) >> 6;
+        for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
+            const int s = (w << 6) + lane;
+            const double x = P.samp[0][s], y = P.samp[1][s], z = P.samp[2][s];
+            const bool in = (s >= rb[0] && s < re[0]) || (s >= rb[1] && s < re[1]) || (s >= rb[2] && s < re[2]) ||
+                            (s >= rb[3] && s < re[3]);
+            uint64_t b[PAINT_PER_ACTION];
+            uint64_t any = 0;
+#pragma unroll
+            for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+                const double dx = x - sc.c[k][0], dy = y - sc.c[k][1], dz = z - sc.c[k][2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                b[k] = __ballot(in && dd <= r2);
+                any |= b[k];
+            }
+            done_w = w;
+            const int owner = w & 63, slot = w >> 6;
+            uint64_t pw = 0, lw = 0;
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+                if (k == slot) {
+                    pw = bcast_u64(painted[k], owner);
+                    lw = bcast_u64(last[k], owner);
+                }
+            if (any == 0 && lw == 0) continue;       // nothing to record for this word
+            uint64_t uw = 0;
+#pragma unroll
+            for (int k = 0; k < PAINT_PER_ACTION; ++k) {             // scalar-unit bookkeeping, shot by shot
+                succeeded += __popcll(b[k] & ~pw);
+                pw |= b[k];
+                uw |= b[k] & ~lw;
+                lw = b[k];
+            }
+            pixel_counter += __popcll(uw);
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+                if (k == slot && lane == owner) {
+                    painted[k] = pw;
+                    new_last[k] = lw;
+                }
+        }
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------- observation (rge:306-319)
@@ -464,7 +735,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
         return;
     }
     // section / discrete, 4-sector rule bpw:1034-1043 (only obs_grad == 4 reaches the device)
-    const double *sx = P.samp[P.a1], *sy = P.samp[P.a2];
+    gdouble_p sx = P.samp[P.a1], sy = P.samp[P.a2];
     uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane
     uint32_t tot_u[4] = {0, 0, 0, 0}, und_u[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -472,7 +743,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
         const int w = lane + 64 * k;
         bool straddle = false;
         if (w < P.n_words) {
-            const double4 bb = reinterpret_cast<const double4 *>(P.word_bbox)[w];
+            const f64x4 bb = reinterpret_cast<const f64x4 GAS *>(P.word_bbox)[w];
             const uint64_t valid = P.word_valid[w];
             const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
             if ((xg || xl) && (yg || yl)) {
@@ -484,27 +755,45 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
             }
         }
         uint64_t sm = __ballot(straddle);
-        while (sm) {                                // wave-uniform loop over the words that straddle the tool
-            const int L = __builtin_ctzll(sm);
-            sm &= sm - 1;
-            const int w2 = L + 64 * k;
-            const uint64_t pw = bcast_u64(painted[k], L);
-            const uint64_t vw = P.word_valid[w2];
-            const int s = (w2 << 6) + lane;
-            const double x = sx[s], y = sy[s];
-            const uint64_t m0 = __ballot(x > x1 && y > x2) & vw;
-            const uint64_t m1 = __ballot(x < x1 && y > x2) & vw;
-            const uint64_t m2 = __ballot(x < x1 && y < x2) & vw;
-            const uint64_t skip = __ballot(x == x1 && y == x2);
-            const uint64_t m3 = vw & ~(m0 | m1 | m2 | skip);
-            tot_u[0] += __popcll(m0);
-            tot_u[1] += __popcll(m1);
-            tot_u[2] += __popcll(m2);
-            tot_u[3] += __popcll(m3);
-            und_u[0] += __popcll(m0 & ~pw);
-            und_u[1] += __popcll(m1 & ~pw);
-            und_u[2] += __popcll(m2 & ~pw);
-            und_u[3] += __popcll(m3 & ~pw);
+#ifdef PRL_ABLATE_STRADDLE
+        sm = 0;
+#endif
+        while (sm) {                                // wave-uniform loop over the words that straddle the tool,
+            int L[4];                               // four per trip so eight loads are in flight
+            bool use[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                use[j] = sm != 0;
+                L[j] = use[j] ? __builtin_ctzll(sm) : L[0];
+                sm &= sm - (use[j] ? 1 : 0);
+            }
+            double xs[4], ys[4];
+            uint64_t vs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w2 = L[j] + 64 * k;
+                xs[j] = sx[(w2 << 6) + lane];
+                ys[j] = sy[(w2 << 6) + lane];
+                vs[j] = P.word_valid[w2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!use[j]) continue;
+                const uint64_t pw = bcast_u64(painted[k], L[j]);
+                const uint64_t m0 = __ballot(xs[j] > x1 && ys[j] > x2) & vs[j];
+                const uint64_t m1 = __ballot(xs[j] < x1 && ys[j] > x2) & vs[j];
+                const uint64_t m2 = __ballot(xs[j] < x1 && ys[j] < x2) & vs[j];
+                const uint64_t skip = __ballot(xs[j] == x1 && ys[j] == x2);
+                const uint64_t m3 = vs[j] & ~(m0 | m1 | m2 | skip);
+                tot_u[0] += __popcll(m0);
+                tot_u[1] += __popcll(m1);
+                tot_u[2] += __popcll(m2);
+                tot_u[3] += __popcll(m3);
+                und_u[0] += __popcll(m0 & ~pw);
+                und_u[1] += __popcll(m1 & ~pw);
+                und_u[2] += __popcll(m2 & ~pw);
+                und_u[3] += __popcll(m3 & ~pw);
+            }
         }
     }
     tot_l = wave_sum_u64(tot_l);
@@ -621,7 +910,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 template <int KW>
-__global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
+__global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
@@ -631,8 +920,13 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
     const int od = obs_dim_of(C);
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    uint64_t cur[KW_MAX] = {0, 0, 0, 0}, uni[KW_MAX] = {0, 0, 0, 0};
+#ifdef PRL_PHASE_TIMING
+    Prof prof;
+    for (int k = 0; k < PH_COUNT; ++k) prof.acc[k] = 0;
+    prof.prev = __builtin_amdgcn_s_memtime();
+#endif
     load_masks<KW>(a, env, P.n_words, lane, painted, last);
+    STAMP(PH_LOAD);
 
     // ---- action -> (delta1, delta2, turning angle)   rge:342-347, rob:390-398, 352-358
     double delta1, delta2, new_angle;
@@ -676,7 +970,8 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
     double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
     tcp_orn_norm(S.pose, S.quat, cur_norm);
     const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
-    uint32_t succeeded_l = 0;
+    __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
+    double *cen = s_centres[threadIdx.x >> 6];
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
         // bpw:865-880 get_guided_point
         double pt[3] = {cur_pose[0], cur_pose[1], cur_pose[2]};
@@ -685,8 +980,18 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
         if (P.a2 == 0) pt[0] += delta_2; else if (P.a2 == 1) pt[1] += delta_2; else pt[2] += delta_2;
         const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
         double t, hit[3], pos[3], orn[3], quat[4];
+        STAMP(PH_MATH);
+#ifdef PRL_ABLATE_RAY                       // diagnostic stand-in: hit 0.1 along the normal, no table reads
+        bool on = true;
+        t = 0.1;
+        hit[0] = pt[0] + 0.1 * cur_norm[0];
+        hit[1] = pt[1] + 0.1 * cur_norm[1];
+        hit[2] = pt[2] + 0.1 * cur_norm[2];
+#else
         bool on = ray_closest_wave(P, pt, end, lane, t, hit) >= 0;
-        if (on) on = hook_point_wave(P, hit, lane, pos, orn);
+#endif
+        STAMP(PH_RAY);
+        if (on) on = hook_point_wave(P, hit, lane, pos, orn PROF_PASS);
         if (!on) {
             orn[0] = cur_norm[0];
             orn[1] = cur_norm[1];
@@ -712,24 +1017,48 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];
-        // rob:277-278 shot centre, bpw:568-577 fast_paint + _paint
+        // rob:277-278 shot centre; painting is deferred until all five centres are known
         double center[3];
         transform_point(pos, quat, 0.0, 0.0, 0.1, center);
-        ball_query_wave<KW>(P, center, lane, cur);
 #pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            succeeded_l += __popcll(cur[k] & ~painted[k]);
-            painted[k] |= cur[k];
-            uni[k] |= cur[k] & ~last[k];
-            last[k] = cur[k];
-            cur[k] = 0;
+        for (int k = 0; k < 3; ++k)
+            if (lane == 0) cen[3 * shot + k] = center[k];
+        STAMP(PH_MATH);
+    }
+    // bpw:568-577 fast_paint + _paint for the five shots
+    int succeeded = 0, pixel_counter = 0;
+    {
+        uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+#ifdef PRL_ABLATE_BALL
+        if (true) {
+#else
+        if (paint_shots_union<KW>(P, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
+#endif
+#pragma unroll
+            for (int k = 0; k < KW; ++k) last[k] = new_last[k];
+        } else {                                   // general path: one ball query per shot
+            uint64_t uni[KW_MAX] = {0, 0, 0, 0};
+            uint32_t succeeded_l = 0, pix_l = 0;
+            for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+                uint64_t cur[KW_MAX] = {0, 0, 0, 0};
+                const double c3[3] = {cen[3 * shot], cen[3 * shot + 1], cen[3 * shot + 2]};
+                ball_query_wave<KW>(P, c3, lane, cur);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    succeeded_l += __popcll(cur[k] & ~painted[k]);
+                    painted[k] |= cur[k];
+                    uni[k] |= cur[k] & ~last[k];
+                    last[k] = cur[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
+            const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
+            succeeded = (int)(sums >> 32);
+            pixel_counter = (int)(sums & 0xffffffffu);
         }
     }
-    uint32_t pix_l = 0;
-#pragma unroll
-    for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
-    const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
-    const int succeeded = (int)(sums >> 32), pixel_counter = (int)(sums & 0xffffffffu);
+    STAMP(PH_BALL);
     const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
 
@@ -752,11 +1081,14 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
     else
         dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
     if (!dn) S.total_return += actual;
+    STAMP(PH_APPLY);
 
     const bool do_reset = dn && C.auto_reset;
     double *obs_row = a.obs + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
+#ifndef PRL_ABLATE_OBS
     if (term_row) observation_wave<KW>(P, C, S.pose, painted, lane, term_row);
+#endif
     if (lane == 0) {
         a.reward[env] = actual;
         a.done[env] = (uint8_t)dn;
@@ -783,8 +1115,14 @@ __global__ __launch_bounds__(256) void step_kernel(StepArgs a) {
         }
         observation_wave<KW>(P, C, S.pose, painted, lane, obs_row);
     }
+    STAMP(PH_OBS);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     if (lane == 0) *reinterpret_cast<EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES) = S;
+    STAMP(PH_STORE);
+#ifdef PRL_PHASE_TIMING
+    if (lane == 0)
+        for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], prof.acc[k]);
+#endif
 }
 
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
@@ -854,7 +1192,7 @@ struct PrlBatch {
 namespace {
 
 template <typename T>
-int upload(PrlPart *p, const T *host, size_t count, const T **out) {
+int upload(PrlPart *p, const T *host, size_t count, const T GAS **out) {
     *out = nullptr;
     if (count == 0) return PRL_OK;
     if (!host) return fail(PRL_E_INVALID, "null table pointer");
@@ -862,7 +1200,7 @@ int upload(PrlPart *p, const T *host, size_t count, const T **out) {
     HIP_TRY(hipMalloc(&d, count * sizeof(T)));
     p->allocs.push_back(d);
     HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
-    *out = static_cast<const T *>(d);
+    *out = (const T GAS *)(d);
     return PRL_OK;
 }
 
@@ -902,22 +1240,19 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (d.n_vertices <= 0) return fail(PRL_E_INVALID, "part has no same-side vertices");
     for (int k = 0; k < 3; ++k) UP(vert[k], t->vertex_xyz[k], d.n_vertices);
     UP(vert_rank, t->vertex_rank, d.n_vertices);
-    UP(vadj_off, t->vertex_adj_off, (size_t)d.n_vertices + 1);
-    const int n_adj = t->vertex_adj_off[d.n_vertices];
     d.n_triangles = t->n_triangles;
-    for (int v = 0; v < d.n_vertices; ++v) {
-        const int c = t->vertex_adj_off[v + 1] - t->vertex_adj_off[v];
-        if (c < 0 || c > 64) return fail(PRL_E_UNSUPPORTED, "vertex %d has %d incident triangles (max 64)", v, c);
-        if (c > p->max_adj) p->max_adj = c;
-    }
-    for (int k = 0; k < n_adj; ++k)
-        if (t->vertex_adj_tri[k] < 0 || t->vertex_adj_tri[k] >= d.n_triangles)
-            return fail(PRL_E_INVALID, "adjacency entry %d out of range", k);
-    UP(vadj_tri, t->vertex_adj_tri, n_adj);
+    d.adj_width = t->adj_width;
+    if (d.adj_width < 1 || d.adj_width > 64)
+        return fail(PRL_E_UNSUPPORTED, "adjacency width %d (a vertex may have at most 64 incident triangles)", d.adj_width);
+    if (!t->vertex_adj) return fail(PRL_E_INVALID, "null adjacency table");
+    for (size_t k = 0; k < (size_t)d.n_vertices * d.adj_width; ++k)
+        if (t->vertex_adj[k] < -1 || t->vertex_adj[k] >= d.n_triangles)
+            return fail(PRL_E_INVALID, "adjacency entry %zu out of range", k);
+    UP(vadj, t->vertex_adj, (size_t)d.n_vertices * d.adj_width);
     d.vg_o1 = t->vgrid_origin[0];
     d.vg_o2 = t->vgrid_origin[1];
     d.vg_inv = t->vgrid_inv_cell;
-    d.vg_accept_d2 = t->vgrid_accept_d2;
+    d.vg_accept = t->vgrid_accept;
     d.vg_nx = t->vgrid_nx;
     d.vg_ny = t->vgrid_ny;
     if (d.vg_nx <= 0 || d.vg_ny <= 0) return fail(PRL_E_INVALID, "empty vertex grid");
@@ -929,6 +1264,9 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (d.n_col <= 0 || d.n_col_pad % 64 || d.n_col_pad < d.n_col) return fail(PRL_E_INVALID, "bad collision counts");
     for (int k = 0; k < 9; ++k) UP(col[k], t->col_v0e1e2[k], d.n_col_pad);
     UP(col_bbox, t->col_bbox, (size_t)d.n_col_pad * 4);
+    d.n_col_chunks = t->n_col_chunks;
+    if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
+    UP(col_chunk_bbox, t->col_chunk_bbox, (size_t)((d.n_col_chunks + 63) / 64) * 64 * 4);
     UP(grid_lo, t->grid_lo, GRID_GRANULARITY);
     UP(grid_hi, t->grid_hi, GRID_GRANULARITY);
     d.r1min = t->range1[0];
@@ -1198,6 +1536,18 @@ int prl_ray_batch(PrlPart *p, int n, const double *from, const double *to, int32
     HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
+
+#ifdef PRL_PHASE_TIMING
+// diagnostic build only: read and clear the per-phase cycle sums
+int prl_debug_phase_cycles(unsigned long long *out, int n) {
+    unsigned long long host[16] = {0};
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof host) != hipSuccess) return PRL_E_HIP;
+    for (int k = 0; k < n && k < 16; ++k) out[k] = host[k];
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
+    return PRL_OK;
+}
+#endif
 
 int prl_batch_timing_enable(PrlBatch *b, int enable) {
     if (!b) return fail(PRL_E_INVALID, "null batch");

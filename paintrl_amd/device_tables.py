@@ -74,16 +74,18 @@ class DeviceTables(object):
         self.vertex_rank = vorder.astype(np.int32)            # rank in the reference's vertex order
         self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
         self.vgrid = (vo1, vo2, inv, vnx, vny)
-        self.vgrid_accept_d2 = (0.99 * CELL) ** 2
+        self.vgrid_accept = 0.99 * CELL
         front_ids = np.nonzero(t.tri_side == pt.SIDE_FRONT)[0]
         compact = -np.ones(t.tri_side.shape[0], dtype=np.int64)
         compact[front_ids] = np.arange(front_ids.size)
-        off, adj = [0], []
-        for v in side_ids[vorder]:
-            adj.extend(int(compact[ti]) for ti in t.vertex_adj[v])
-            off.append(len(adj))
-        self.vertex_adj_off = np.asarray(off, dtype=np.int32)
-        self.vertex_adj_tri = np.asarray(adj, dtype=np.int32)
+        lists = [[int(compact[ti]) for ti in t.vertex_adj[v]] for v in side_ids[vorder]]
+        self.adj_width = max(1, max(len(l) for l in lists))
+        if self.adj_width > 64:
+            raise NotImplementedError('a vertex has %d incident same-side triangles (max 64)' % self.adj_width)
+        adj = -np.ones((len(lists), self.adj_width), dtype=np.int32)
+        for i, l in enumerate(lists):
+            adj[i, :len(l)] = l
+        self.vertex_adj = adj
         # ---- triangle records: a v0 v1 d00 d01 d11 inv normal
         rec = np.empty((front_ids.size, 16), dtype=np.float64)
         rec[:, 0:3], rec[:, 3:6], rec[:, 6:9] = t.tri_a[front_ids], t.tri_v0[front_ids], t.tri_v1[front_ids]
@@ -107,6 +109,13 @@ class DeviceTables(object):
         box[:C0, 2] = np.nextafter(lo2.astype(np.float32), np.float32(-np.inf))
         box[:C0, 3] = np.nextafter(hi2.astype(np.float32), np.float32(np.inf))
         self.col_bbox = box
+        n_chunks = c_pad // 64
+        cb = box.reshape(n_chunks, 64, 4)
+        chunk = np.empty((((n_chunks + 63) // 64) * 64, 4), dtype=np.float32)
+        chunk[:, 0], chunk[:, 1], chunk[:, 2], chunk[:, 3] = np.inf, -np.inf, np.inf, -np.inf
+        chunk[:n_chunks, 0], chunk[:n_chunks, 1] = cb[:, :, 0].min(1), cb[:, :, 1].max(1)
+        chunk[:n_chunks, 2], chunk[:n_chunks, 3] = cb[:, :, 2].min(1), cb[:, :, 3].max(1)
+        self.col_chunk_bbox, self.n_col_chunks = chunk, n_chunks
         self.n_collision, self.n_collision_pad = C0, c_pad
         # ---- rows, start points, beams
         self.grid_lo = np.ascontiguousarray(t.grid_lo, dtype=np.float64)
@@ -143,9 +152,9 @@ class DeviceTables(object):
         s.obs_cell_count = ip(self.obs_cell_count)
         s.n_vertices = self.vertex_rank.shape[0]
         s.vertex_rank = ip(self.vertex_rank)
-        s.vertex_adj_off, s.vertex_adj_tri = ip(self.vertex_adj_off), ip(self.vertex_adj_tri)
+        s.adj_width, s.vertex_adj = self.adj_width, ip(self.vertex_adj)
         s.vgrid_origin[0], s.vgrid_origin[1], s.vgrid_inv_cell, s.vgrid_nx, s.vgrid_ny = self.vgrid
-        s.vgrid_accept_d2 = self.vgrid_accept_d2
+        s.vgrid_accept = self.vgrid_accept
         s.vgrid_start = ip(self.vgrid_start)
         s.n_triangles = self.tri_records.shape[0]
         s.tri_records = dp(self.tri_records)
@@ -153,6 +162,8 @@ class DeviceTables(object):
         for k in range(9):
             s.col_v0e1e2[k] = dp(self.col[k])
         s.col_bbox = self.col_bbox.ctypes.data_as(_lib._fp)
+        s.n_col_chunks = self.n_col_chunks
+        s.col_chunk_bbox = self.col_chunk_bbox.ctypes.data_as(_lib._fp)
         s.grid_lo, s.grid_hi = dp(self.grid_lo), dp(self.grid_hi)
         s.range1[0], s.range1[1] = t.ranges[0]
         s.range2[0], s.range2[1] = t.ranges[1]
