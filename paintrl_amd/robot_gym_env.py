@@ -1,0 +1,194 @@
+"""PaintGymEnv: the Gym-facing drop-in for ``PaintRLEnv/robot_gym_env.py`` (rge:120-422).
+
+Same constructor, class attributes, spaces, classmethods, ``step`` 4-tuple and
+``reset`` as the reference, so ``env_creator = lambda cfg: PaintGymEnv(**cfg)``
+(paint_ppo.py:135-137) keeps working.  Internally it is a one-env view of
+``BatchedPaintEnv``: every ``step`` is one launch of the HIP step kernel.  For
+throughput use ``BatchedPaintEnv`` directly (thousands of envs per launch).
+
+Differences from the reference, by design:
+  * ``with_robot=True`` (KUKA inverse kinematics through Bullet) is out of scope;
+    the flag is accepted and ignored (training uses with_robot=False, paint_ppo.py:87);
+  * ``renders`` only controls printing of the replay buffer; there is no GUI;
+  * rays hit an explicit collision triangle set (``collision_mode``), see DESIGN.md.
+"""
+import os
+import random
+
+import numpy as np
+
+from . import config as _config
+from . import part_tables as _pt
+from . import spaces
+from .config import EXTRA_CONFIG as _DEFAULT_EXTRA, Part_Dict
+
+_urdf_cache = {}          # (path, mtime, collision_mode) -> PartTables, like bpw._urdf_cache
+
+
+def load_part_tables(path, collision_mode='hull', obs_grad=4):
+    key = (os.path.abspath(path), os.path.getmtime(path), collision_mode)
+    if key not in _urdf_cache:
+        _urdf_cache[key] = _pt.build_part_tables(path, obs_grad=obs_grad, collision_mode=collision_mode)
+    return _urdf_cache[key]
+
+
+class _RobotView(object):
+    """The few ``env.robot`` members scripts touch (rge:436, spiral.py:38)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def get_angle_diff(self):
+        raise NotImplementedError('angle_diff is consumed inside the step kernel (TURNING_PENALTY)')
+
+    def termination_request(self):
+        return bool(self._env._batch.state()['terminate'][0])
+
+    def get_observation(self):
+        st = self._env._batch.state()
+        return st['pose'][0], st['quat'][0]
+
+
+class PaintGymEnv(spaces.Env):
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 30}
+    reward_range = (-1e3, 1e3)
+
+    # Adjust env by hand when using Ray (rge:126-132)
+    ACTION_SHAPE = 1
+    ACTION_MODE = 'discrete'
+    DISCRETE_GRANULARITY = 4
+    OBS_MODE = 'section'
+    OBS_GRAD = 4
+    EXTRA_CONFIG = dict(_DEFAULT_EXTRA)
+
+    action_space = spaces.Discrete(DISCRETE_GRANULARITY)
+    observation_space = spaces.Box(low=0.0, high=1.0, shape=(OBS_GRAD + 2,), dtype=np.float64)
+
+    @classmethod
+    def change_obs_mode(cls, mode='section', grad=5):
+        """rge:176-193 (the observation_space shape follows the actual observation here)."""
+        cls.OBS_MODE = mode
+        cls.OBS_GRAD = grad
+        cls.observation_space = spaces.Box(low=0.0, high=1.0, shape=(_config.obs_dim(mode, grad),), dtype=np.float64)
+
+    @classmethod
+    def change_action_mode(cls, shape=2, mode='continuous', discrete_granularity=20):
+        """rge:195-205."""
+        cls.ACTION_SHAPE = shape
+        cls.ACTION_MODE = mode
+        if mode == 'continuous':
+            cls.action_space = spaces.Box(low=-1.0, high=1.0, shape=(shape,), dtype=np.float64)
+        else:
+            cls.DISCRETE_GRANULARITY = discrete_granularity
+            cls.action_space = spaces.Discrete(discrete_granularity)
+
+    def __init__(self, urdf_root, with_robot=True, renders=False, render_video=False, rollout=False,
+                 extra_config=None, collision_mode='hull', device=None):
+        from .batched_env import BatchedPaintEnv
+        from .device_tables import DeviceTables
+        if extra_config is None:
+            extra_config = self.EXTRA_CONFIG
+        cfg = dict(_DEFAULT_EXTRA)
+        cfg.update(extra_config)
+        self._setup_extra_config(cfg)
+        self._with_robot = False
+        self._renders = renders
+        self._rollout = rollout
+        self._urdf_root = urdf_root
+        self._step_counter = 0
+        self.replay_buffer = []
+        path = os.path.join(urdf_root, 'urdf', 'painting', self._part_name)
+        self._tables = load_part_tables(path, collision_mode, self.OBS_GRAD)
+        self._start_points = _pt.start_points(self._tables, self.START_POINT_MODE)
+        n_disc = self.action_space.n if self.ACTION_MODE != 'continuous' else 4
+        self._batch = BatchedPaintEnv(
+            DeviceTables(self._tables, obs_grad=self.OBS_GRAD, start_points=self._start_points), 1, device=device,
+            obs_mode=self.OBS_MODE, obs_grad=self.OBS_GRAD, action_mode=self.ACTION_MODE,
+            action_dim=self.ACTION_SHAPE if self.ACTION_MODE == 'continuous' else 1, n_discrete=n_disc,
+            termination_mode=self.TERMINATION_MODE, turning_penalty=self.TURNING_PENALTY,
+            overlap_penalty=self.OVERLAP_PENALTY, paint_method='fast', max_episode_len=self.EPISODE_MAX_LENGTH,
+            expected_episode_len=self.Expected_Episode_Length, switch_threshold=self.SWITCH_THRESHOLD,
+            max_possible_point=self._max_possible_point)
+        self.robot = _RobotView(self)
+        self.reset()
+
+    def _setup_extra_config(self, config):                                    # rge:240-252
+        self._part_name = Part_Dict[config['Part_NO']][0]
+        self._max_possible_point = Part_Dict[config['Part_NO']][1]
+        self.RENDER_WIDTH, self.RENDER_HEIGHT = config['RENDER_WIDTH'], config['RENDER_HEIGHT']
+        self.Expected_Episode_Length = config['Expected_Episode_Length']
+        self.EPISODE_MAX_LENGTH = config['EPISODE_MAX_LENGTH']
+        self.TERMINATION_MODE = config['TERMINATION_MODE']
+        self.SWITCH_THRESHOLD = config['SWITCH_THRESHOLD']
+        self.START_POINT_MODE = config['START_POINT_MODE']
+        self.TURNING_PENALTY = config['TURNING_PENALTY']
+        self.OVERLAP_PENALTY = config['OVERLAP_PENALTY']
+        self.COLOR_MODE = config['COLOR_MODE']
+        if self.COLOR_MODE != 'RGB':
+            raise NotImplementedError("COLOR_MODE='HSI' (thickness mode) is out of scope, see DESIGN.md")
+
+    def _obs_out(self, row):
+        return np.array(row.cpu().numpy(), dtype=np.float64)
+
+    def step(self, action):                                                    # rge:349-368
+        if self.ACTION_MODE == 'continuous':
+            act = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        else:
+            act = [int(action)]
+        obs, reward, done, info = self._batch.step(act)
+        self._step_counter += 1
+        done = bool(done[0])
+        info_row = info[0].cpu().numpy()
+        if self._renders and self._rollout:
+            self.replay_buffer.append(action)
+            if done:
+                print(self.replay_buffer)
+        return self._obs_out(obs[0]), float(reward[0]), done, {'reward': float(info_row[0]),
+                                                               'penalty': float(info_row[1])}
+
+    def reset(self):                                                           # rge:370-387
+        if self._rollout:
+            index = 0
+            self.replay_buffer = []
+        else:
+            random.randint(0, 7)              # the reference draws an (unused) pre-paint mode first, rge:378
+            index = random.randint(0, len(self._start_points) - 1)
+        self._step_counter = 0
+        return self._obs_out(self._batch.reset(start_idx=[index])[0])
+
+    def get_texture_image(self):
+        """(H, W, 3) uint8 texture: painted texels red, unpainted front texels grey (bpw:585-592, 737-738)."""
+        t = self._tables
+        img = np.zeros((t.tex_h, t.tex_w, 3), dtype=np.uint8)
+        bits = self._batch.painted_bits(0)
+        pix = t.sample_pix
+        img[pix[:, 1], pix[:, 0]] = (191, 191, 191)
+        img[pix[bits, 1], pix[bits, 0]] = (255, 0, 0)
+        return img
+
+    def get_job_status(self):
+        """Number of painted samples (bpw:727-732)."""
+        return int(self._batch.painted_bits(0).sum())
+
+    def get_job_limit(self):
+        return int(self._tables.sample_pos.shape[0])
+
+    def render(self, mode='human'):                                            # rge:389-415
+        if mode == 'human':
+            raise Exception('please set render parameter to true to see the result')
+        return self.get_texture_image()
+
+    def close(self):
+        if getattr(self, '_batch', None) is not None:
+            self._batch.close()
+            self._batch = None
+
+    def seed(self, seed=None):
+        return spaces.np_random(seed)[1]
+
+    def __enter__(self):
+        self.reset()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()

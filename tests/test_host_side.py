@@ -1,0 +1,154 @@
+"""CPU tests of the host side: table builder vs the reference's tables (G0), ParamTestEnv (G1),
+device layout invariants, the C ABI surface, numpy ray vs oracle ray."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, REPO, synthetic_tables
+from paintrl_amd import _lib, config, geometry, part_tables
+from paintrl_amd.device_tables import CELL, DeviceTables
+from paintrl_amd.param_test_env import ParamTestEnv, spiral, zigzag
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('tag,name', [('door', 'door_test'), ('sheet', 'square')])
+def test_tables_match_reference_digests(tag, name):
+    """G0: every static table equals what the reference built for the same synthetic mesh."""
+    g = np.load(os.path.join(GOLDEN, 'g0_tables_%s.npz' % tag))
+    t = synthetic_tables(name)
+    front = t.tri_side == 1
+    assert int(g['P']) == t.sample_pos.shape[0] and int(g['T']) == t.tri_side.shape[0]
+    assert int(g['V']) == t.vertices.shape[0]
+    assert list(g['side_counts']) == [int((t.tri_side == k).sum()) for k in (1, 2, 3)]
+    assert list(g['axes']) == [t.a1, t.a2, t.a0]
+    assert np.array_equal(g['ranges'], np.array(t.ranges)) and float(g['lwr']) == t.lwr
+    assert np.array_equal(g['grid_lo'], t.grid_lo) and np.array_equal(g['grid_hi'], t.grid_hi)
+    assert float(g['density']) == t.density and np.array_equal(g['beams'], t.beams)
+    assert str(g['sha_pix']) == sha(t.sample_pix.astype(np.int32))
+    assert str(g['sha_pos']) == sha(t.sample_pos)
+    assert str(g['sha_sides']) == sha(t.tri_side.astype(np.int8))
+    assert str(g['sha_front_normals']) == sha(t.tri_normal[front])
+    assert str(g['sha_side_vertices']) == sha(t._side_data)
+    assert str(g['sha_cells4']) == sha(part_tables.grid_observation_cells(t, 4).astype(np.int32))
+    sp = np.array(part_tables.start_points(t, 'all'), dtype=np.float64)
+    assert int(g['n_start_all']) == sp.shape[0] and str(g['sha_start_points']) == sha(sp)
+    assert np.array_equal(g['pos_head'], t.sample_pos[:32]) and np.array_equal(g['normals_tail'], t.tri_normal[front][-32:])
+    assert len(t.vertices_mutated) == 0        # synthetic parts never trigger the sparse-row mutation
+
+
+@pytest.mark.parametrize('size,driver,steps,total', [(22, zigzag, 399, 320.2), (20, spiral, 323, 259.4),
+                                                      (14, zigzag, 143, 115.4)])
+def test_param_test_env_golden(size, driver, steps, total):
+    """G1: ParamTestEnv replays the reference's trajectories and the survey's totals."""
+    z = np.load(os.path.join(GOLDEN, 'g1_param_test.npz'))
+    key = '%s%d' % (driver.__name__, size)
+    env = ParamTestEnv(size)
+    assert np.array_equal(env.reset(), z[key + '_obs'][0])
+    for k, a in enumerate(z[key + '_actions']):
+        o, r, d, info = env.step(int(a))
+        assert np.array_equal(o, z[key + '_obs'][k + 1]) and r == z[key + '_reward'][k] and d == z[key + '_done'][k]
+    n, ret, acts = driver(size)
+    assert n == steps and abs(ret - total) < 1e-9 and acts == z[key + '_actions'].tolist()
+    with pytest.raises(IndexError):
+        env.step(7)
+
+
+def test_capi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/paintrl.h declares."""
+    header = open(os.path.join(REPO, 'include', 'paintrl.h')).read()
+    declared = set(re.findall(r'\b(prl_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.prl_abi_version() == 1
+    cfg = config.make_config(obs_mode='grid', obs_grad=4)
+    assert lib.prl_obs_dim(cfg) == 16
+    assert lib.prl_obs_dim(config.make_config(obs_mode='discrete')) == 5
+    # error paths that need no device
+    import ctypes as C
+    out = C.c_void_p()
+    assert lib.prl_batch_create(None, 0, None, 0, cfg, C.byref(out)) < 0
+    assert b'bad arguments' in lib.prl_last_error()
+
+
+def test_discrete_action_table_keeps_reference_rounding():
+    d1, d2, ang = config.discrete_action_table(4)
+    assert d1[0] == 0.051 and d2[2] != 0.0 and abs(d1[1]) < 1e-17 and d1[1] != 0.0     # cos(pi/2)*0.051 = 3.1e-18
+    assert ang[0] == 0.0 and abs(ang[1] - np.pi / 2) < 1e-15
+    o1, o2, oa = oracle.paint_oracle.discrete_action_table(4)
+    assert np.array_equal(o1, d1) and np.array_equal(o2, d2) and np.array_equal(oa, ang)
+
+
+@pytest.mark.parametrize('name', ['door_test', 'square'])
+def test_device_layout_invariants(name):
+    t = synthetic_tables(name)
+    d = DeviceTables(t)
+    P = t.sample_pos.shape[0]
+    assert sorted(d.perm.tolist()) == list(range(P)) and d.n_samples_pad % 64 == 0
+    assert int(np.unpackbits(d.word_valid.view(np.uint8)).sum()) == P
+    # every sample within the paint radius of a random centre lies in the 3x3 cell block the kernel scans
+    rng = np.random.RandomState(0)
+    xyz = np.stack([a[:P] for a in d.sample_xyz], axis=1)
+    o1, o2, inv, nx, ny = d.sgrid
+    for _ in range(200):
+        c = xyz[rng.randint(P)] + rng.normal(0, 0.02, 3)
+        near = np.nonzero(((xyz - c) ** 2).sum(1) <= 0.051 ** 2)[0]
+        icx, icy = int(np.floor((c[t.a1] - o1) * inv)), int(np.floor((c[t.a2] - o2) * inv))
+        got = []
+        for cy in range(icy - 1, icy + 2):
+            if 0 <= cy < ny:
+                cx0, cx1 = max(icx - 1, 0), min(icx + 1, nx - 1)
+                if cx0 <= cx1:
+                    got.extend(range(d.sgrid_start[cy * nx + cx0], d.sgrid_start[cy * nx + cx1 + 1]))
+        assert set(near.tolist()) <= set(got)
+    # grid-observation masks partition the samples
+    assert int(d.obs_cell_count.sum()) == P
+    total = np.zeros(d.n_words, dtype=np.uint64)
+    for m in d.obs_cell_mask:
+        assert not (total & m).any()
+        total |= m
+    assert np.array_equal(total, d.word_valid)
+    # adjacency is the reference's uv_map restricted to the side, file order
+    assert d.vertex_adj.max() < d.tri_records.shape[0] and (d.vertex_adj >= -1).all()
+    assert CELL > 0.051
+    words = rng.randint(0, 2 ** 63, size=(2, d.n_words)).astype(np.uint64) & d.word_valid
+    back = d.mask_to_canonical(words)
+    assert back.shape == (2, P) and back.sum() == np.unpackbits(words.view(np.uint8)).sum()
+
+
+def test_numpy_ray_equals_oracle_ray(door_tables):
+    t = door_tables
+    rng = np.random.RandomState(4)
+    n = 2000
+    o = np.stack([rng.uniform(-0.2, 0.3, n), rng.uniform(-0.8, 0.6, n), rng.uniform(0.1, 1.3, n)], axis=1)
+    e = o + np.stack([-rng.uniform(0.2, 1.0, n), rng.normal(0, 0.2, n), rng.normal(0, 0.2, n)], axis=1)
+    idx, tt, pos = geometry.ray_closest_hit(t.col_v0, t.col_e1, t.col_e2, o, e)
+    oi, ot, op = oracle.Oracle(t, 1).ray_batch(o, e)
+    hit = idx >= 0
+    assert hit.sum() > 300 and (~hit).sum() > 100
+    assert np.array_equal(idx, oi) and np.array_equal(tt[hit], ot[hit]) and np.array_equal(pos[hit], op[hit])
+
+
+def test_oracle_envs_are_independent(door_tables):
+    """Sharding premise: an env's trajectory does not depend on its batch neighbours."""
+    sp = part_tables.start_points(door_tables, 'all')
+    rng = np.random.RandomState(1)
+    n, steps = 16, 15
+    start = rng.randint(0, len(sp), size=n)
+    acts = rng.randint(0, 4, size=(steps, n))
+    full = oracle.Oracle(door_tables, n, start_points=sp)
+    half = oracle.Oracle(door_tables, n // 2, start_points=sp)
+    full.reset(start)
+    half.reset(start[n // 2:])
+    for k in range(steps):
+        of, rf, df, _ = full.step(acts[k])
+        oh, rh, dh, _ = half.step(acts[k][n // 2:])
+        assert np.array_equal(of[n // 2:], oh) and np.array_equal(rf[n // 2:], rh) and np.array_equal(df[n // 2:], dh)
