@@ -47,11 +47,23 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
     return per_env, static, per_env * n_envs + static
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask and cgroup cpu quota both count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(tables, steps_sample=25, n_envs=ENVS_PER_GPU):
     """The C oracle (a scalar float64 port of the reference step()) on all host cores."""
     import numpy as np
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     orc = oracle.Oracle(tables, n_envs, threads=cores)
     rng = np.random.RandomState(1234)
     start = rng.randint(0, 4, size=n_envs)

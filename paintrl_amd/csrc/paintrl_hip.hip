@@ -837,6 +837,15 @@ struct EnvState {                 // PRL_STATE_DOUBLES record
 };
 static_assert(sizeof(EnvState) == PRL_STATE_DOUBLES * 8, "state record layout");
 
+// Store the 128-byte record as one coalesced write: lane l < 16 writes double l.
+__device__ __forceinline__ void store_state(double *dst, const EnvState &S, int lane) {
+    const double *src = reinterpret_cast<const double *>(&S);
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < PRL_STATE_DOUBLES; ++k) v = lane == k ? src[k] : v;
+    if (lane < PRL_STATE_DOUBLES) dst[lane] = v;
+}
+
 __device__ __forceinline__ void reset_state(const PartDev &P, EnvState &S, int start) {   // rge:370-387, rob:366-372
     S.pose[0] = P.start_pos[3 * start];
     S.pose[1] = P.start_pos[3 * start + 1];
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     reset_state(P, S, start);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
-    if (lane == 0) *reinterpret_cast<EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES) = S;
+    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     if (a.obs) observation_wave<KW>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C));
 }
 
@@ -1117,7 +1126,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     }
     STAMP(PH_OBS);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
-    if (lane == 0) *reinterpret_cast<EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES) = S;
+    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     STAMP(PH_STORE);
 #ifdef PRL_PHASE_TIMING
     if (lane == 0)
@@ -1142,6 +1151,13 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int
         pos[3 * r + 1] = hit[1];
         pos[3 * r + 2] = hit[2];
     }
+}
+
+// Copies the coverage words out (prl_batch_get_mask).  Same access shape as the step kernel's mask
+// traffic (8 bytes per lane, coalesced), so tools/hbm_calibration.py uses it to calibrate FETCH_SIZE.
+__global__ void copy_mask_kernel(const uint64_t *src, uint64_t *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 __global__ void gather_state_kernel(const double *state, int n, int field, double *out) {
@@ -1507,8 +1523,10 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
 
 int prl_batch_get_mask(PrlBatch *b, uint64_t *painted, void *stream) {
     if (!b || !painted) return fail(PRL_E_INVALID, "null argument");
-    HIP_TRY(hipMemcpyAsync(painted, b->painted, (size_t)b->n_envs * b->mask_stride * sizeof(uint64_t),
-                           hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    const size_t n = (size_t)b->n_envs * b->mask_stride;
+    hipLaunchKernelGGL(copy_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), b->painted, painted, n);
+    HIP_TRY(hipGetLastError());
     return PRL_OK;
 }
 
