@@ -42,7 +42,7 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
     static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sgrid_start.nbytes
               + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
               + dt.vgrid_start.nbytes + dt.tri_records.nbytes
-              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
+              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
               + dt.start_pos.nbytes + dt.start_quat.nbytes)
     return per_env, static, per_env * n_envs + static
 
@@ -152,7 +152,7 @@ def main():
         value = world * args.steps / elapsed
         out = {
             'metric': 'batched env steps/sec (door panel, N=4096)', 'value': value,
-            'unit': 'batched steps/s (4096 envs each)', 'n_gpus': world, 'steps': args.steps,
+            'unit': 'batched steps/s (%d envs each)' % args.envs, 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
@@ -168,7 +168,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs)
-        print(json.dumps(out))
+        print(json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)))
     env.close()
     if world > 1:
         import torch.distributed as dist

@@ -56,7 +56,8 @@ typedef struct {
     /* uniform grid over the principal plane that orders the samples */
     double sgrid_origin[2], sgrid_inv_cell;
     int32_t sgrid_nx, sgrid_ny;
-    const int32_t *sgrid_start;   /* [nx*ny+1] */
+    const int32_t *sgrid_start;   /* [nx*ny+1] first sample of each cell; every cell row starts on a 64-sample
+                                     word, the pads in between are far away and never valid */
     /* grid observation (bpw GridObservation): one sample bitmask per observation cell */
     int32_t n_obs_cells;
     const uint64_t *obs_cell_mask;   /* [n_obs_cells][n_samples_pad/64] */
@@ -79,9 +80,10 @@ typedef struct {
     int32_t n_collision;
     int32_t n_collision_pad;
     const double *col_v0e1e2[9];     /* v0.xyz e1.xyz e2.xyz, [n_collision_pad] each */
-    const float *col_bbox;           /* [n_collision_pad][4] outward-rounded principal-plane box */
+    const float *col_bbox;           /* [n_collision_pad][8] outward-rounded box: lo,hi on axis1, axis2, axis0, 2 pad */
+    const int32_t *col_rank;         /* [n_collision_pad] index in the reference (tie-break) order */
     int32_t n_col_chunks;            /* n_collision_pad / 64 */
-    const float *col_chunk_bbox;     /* [n_col_chunks padded to 64][4] union box of each 64-triangle chunk */
+    const float *col_chunk_bbox;     /* [n_col_chunks padded to 64][8] union box of each 64-triangle chunk */
     /* grid rows (bpw grid_dict), extents, axes */
     const double *grid_lo, *grid_hi; /* [100] */
     double range1[2], range2[2], length_width_ratio;

@@ -83,6 +83,7 @@ struct PartDev {
     int n_col, n_col_pad;
     gdouble_p col[9];
     gfloat_p col_bbox;
+    gint_p col_rank;
     int n_col_chunks;
     gfloat_p col_chunk_bbox;
     gdouble_p grid_lo, grid_hi;
@@ -275,65 +276,105 @@ __device__ __forceinline__ int cell_coord(double x, double origin, double inv, i
 }
 
 // ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
-// Two-level cull: lane c tests the union box of 64-triangle chunk c, then only the chunks whose box
-// overlaps the segment are visited (one triangle per lane, box + 9 doubles loaded in one round trip).
+// Cull before the float64 Moller-Trumbore test:
+//   * 3-D float boxes (rounded outward) per triangle and per 64-triangle chunk; lane c tests chunk c,
+//     only surviving chunks are visited (one triangle per lane, boxes + 9 doubles in one round trip);
+//   * two stages: first only the near part of the segment, t <= 0.125 (the tool hovers 0.1 above
+//     the part, so this is where the hit almost always is, and the short box excludes back and side
+//     facets); the whole segment only if nothing was hit.  The closest hit of the whole segment is
+//     the closest hit of the near part whenever the latter exists, so the result is unchanged.
+// Equal t resolves to the lowest reference-order index (col_rank), as in paintrl_amd/geometry.py.
+struct SegBox {
+    float lo[3], hi[3];      // axis1, axis2, axis0
+};
+
+__device__ __forceinline__ SegBox seg_box(const double o3[3], const double d3[3], double tmax) {
+    SegBox b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double e = o3[k] + tmax * d3[k];
+        b.lo[k] = nextafterf((float)fmin(o3[k], e), -INFINITY);
+        b.hi[k] = nextafterf((float)fmax(o3[k], e), INFINITY);
+    }
+    return b;
+}
+
+__device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, const f32x4 b) {
+    return (s.lo[0] <= a.y) && (s.hi[0] >= a.x) && (s.lo[1] <= a.w) && (s.hi[1] >= a.z) && (s.lo[2] <= b.y) &&
+           (s.hi[2] >= b.x);
+}
+
 __device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
                                 double hit[3]) {
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
-    const int a1 = P.a1, a2 = P.a2;
-    const double o1 = sel3(o[0], o[1], o[2], a1), o2 = sel3(o[0], o[1], o[2], a2);
-    const double e1p = sel3(e[0], e[1], e[2], a1), e2p = sel3(e[0], e[1], e[2], a2);
-    // segment box in the principal plane, one float ulp wider than the doubles
-    const float s1lo = nextafterf((float)fmin(o1, e1p), -INFINITY), s1hi = nextafterf((float)fmax(o1, e1p), INFINITY);
-    const float s2lo = nextafterf((float)fmin(o2, e2p), -INFINITY), s2hi = nextafterf((float)fmax(o2, e2p), INFINITY);
+    const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
+    const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
     double best_t = INFINITY;
-    int best_i = 0x7fffffff;
+    int best_r = 0x7fffffff;
     const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
     const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
-    for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
-        const f32x4 cb = chunk_boxes[cbase + lane];                 // table is padded to 64 with empty boxes
-        uint64_t cm = __ballot((s1lo <= cb.y) && (s1hi >= cb.x) && (s2lo <= cb.w) && (s2hi >= cb.z));
-        while (cm) {
-            const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
-            cm &= cm - 1;
-            const f32x4 b = boxes[i];
-            const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
-            const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
-            const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
-            if ((s1lo <= b.y) && (s1hi >= b.x) && (s2lo <= b.w) && (s2hi >= b.z)) {
-                const double p0 = d1 * e22 - d2 * e21;
-                const double p1 = d2 * e20 - d0 * e22;
-                const double p2 = d0 * e21 - d1 * e20;
-                const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-                if (fabs(det) >= RAY_EPS_DET) {
-                    const double inv = 1.0 / det;
-                    const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-                    const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-                    const double q0 = s1 * e12 - s2 * e11;
-                    const double q1 = s2 * e10 - s0 * e12;
-                    const double q2 = s0 * e11 - s1 * e10;
-                    const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-                    const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-                    if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
-                        t <= 1.0 && t < best_t) {
-                        best_t = t;
-                        best_i = i;
+    for (int stage = 0; stage < 2; ++stage) {
+#ifdef PRL_PHASE_COUNTERS
+        if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
+#endif
+        const double tmax = stage == 0 ? 0.125 : 1.0;
+        const SegBox sb = seg_box(o3, d3, tmax);
+        for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
+            const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
+            uint64_t cm = __ballot(box_overlap(sb, ca, cb));       // table is padded to 64 with empty boxes
+            while (cm) {
+                const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+                cm &= cm - 1;
+                const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
+#ifdef PRL_PHASE_COUNTERS
+                {
+                    const uint64_t mt_ = __ballot(box_overlap(sb, ba, bb));
+                    if (lane == 0) {
+                        atomicAdd(&g_phase_cycles[12], 1ull);
+                        atomicAdd(&g_phase_cycles[13], (unsigned long long)__popcll(mt_));
+                    }
+                }
+#endif
+                const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
+                const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
+                const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
+                const int rk = P.col_rank[i];
+                if (box_overlap(sb, ba, bb)) {
+                    const double p0 = d1 * e22 - d2 * e21;
+                    const double p1 = d2 * e20 - d0 * e22;
+                    const double p2 = d0 * e21 - d1 * e20;
+                    const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+                    if (fabs(det) >= RAY_EPS_DET) {
+                        const double inv = 1.0 / det;
+                        const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+                        const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+                        const double q0 = s1 * e12 - s2 * e11;
+                        const double q1 = s2 * e10 - s0 * e12;
+                        const double q2 = s0 * e11 - s1 * e10;
+                        const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+                        const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+                        if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
+                            t <= tmax && (t < best_t || (t == best_t && rk < best_r))) {
+                            best_t = t;
+                            best_r = rk;
+                        }
                     }
                 }
             }
         }
+        if (__ballot(best_t < INFINITY)) break;
     }
     if (__ballot(best_t < INFINITY) == 0) {
         t_out = INFINITY;
         return -1;
     }
     const double tmin = wave_min_d(best_t);
-    const int imin = wave_min_i(best_t == tmin ? best_i : 0x7fffffff);   // equal t: lowest triangle index
+    const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);   // equal t: lowest reference index
     t_out = tmin;
     hit[0] = o[0] + tmin * d0;
     hit[1] = o[1] + tmin * d1;
     hit[2] = o[2] + tmin * d2;
-    return imin;
+    return rmin;
 }
 
 // ---------------------------------------------------------------- bpw:526 nearest same-side vertex
@@ -1279,10 +1320,11 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     d.n_col_pad = t->n_collision_pad;
     if (d.n_col <= 0 || d.n_col_pad % 64 || d.n_col_pad < d.n_col) return fail(PRL_E_INVALID, "bad collision counts");
     for (int k = 0; k < 9; ++k) UP(col[k], t->col_v0e1e2[k], d.n_col_pad);
-    UP(col_bbox, t->col_bbox, (size_t)d.n_col_pad * 4);
+    UP(col_bbox, t->col_bbox, (size_t)d.n_col_pad * 8);
+    UP(col_rank, t->col_rank, d.n_col_pad);
     d.n_col_chunks = t->n_col_chunks;
     if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
-    UP(col_chunk_bbox, t->col_chunk_bbox, (size_t)((d.n_col_chunks + 63) / 64) * 64 * 4);
+    UP(col_chunk_bbox, t->col_chunk_bbox, (size_t)((d.n_col_chunks + 63) / 64) * 64 * 8);
     UP(grid_lo, t->grid_lo, GRID_GRANULARITY);
     UP(grid_hi, t->grid_hi, GRID_GRANULARITY);
     d.r1min = t->range1[0];

@@ -25,31 +25,53 @@ class DeviceTables(object):
         a1, a2 = t.a1, t.a2
         self.tables = t
         P = t.sample_pos.shape[0]
-        # ---- samples sorted by grid cell
+        # ---- samples sorted by grid cell; every cell ROW starts on a 64-sample word boundary, so no
+        # word mixes the end of one row with the start of the next (such words would straddle the
+        # tool in every observation)
         o1, o2 = float(t.sample_pos[:, a1].min()), float(t.sample_pos[:, a2].min())
         inv = 1.0 / CELL
         cx = np.floor((t.sample_pos[:, a1] - o1) * inv).astype(np.int64)
         cy = np.floor((t.sample_pos[:, a2] - o2) * inv).astype(np.int64)
         nx, ny = int(cx.max()) + 1, int(cy.max()) + 1
         cell = cy * nx + cx
-        self.perm = np.argsort(cell, kind='stable')          # device position -> canonical sample index
-        self.inv_perm = np.empty(P, dtype=np.int64)
-        self.inv_perm[self.perm] = np.arange(P)
-        n_pad = ((P + 63) // 64) * 64
+        order = np.argsort(cell, kind='stable')
+        per_cell = np.bincount(cell, minlength=nx * ny)
+        starts = np.zeros(nx * ny + 1, dtype=np.int64)
+        pos = 0
+        for row in range(ny):
+            pos = ((pos + 63) // 64) * 64
+            for col in range(nx):
+                starts[row * nx + col] = pos
+                pos += per_cell[row * nx + col]
+        starts[nx * ny] = pos
+        n_pad = ((pos + 63) // 64) * 64
         n_words = n_pad // 64
+        # device position of each sorted sample; cells of one row are contiguous, rows are word aligned
+        rank_in_cell = np.arange(P) - np.searchsorted(cell[order], cell[order], side='left')
+        dev_pos = starts[cell[order]] + rank_in_cell
+        self.perm = -np.ones(n_pad, dtype=np.int64)       # device position -> canonical sample index (-1 = pad)
+        self.perm[dev_pos] = order
+        self.inv_perm = np.empty(P, dtype=np.int64)        # canonical sample index -> device position
+        self.inv_perm[order] = dev_pos
+        valid = self.perm >= 0
         xyz = np.full((3, n_pad), FAR, dtype=np.float64)
-        xyz[:, :P] = t.sample_pos[self.perm].T
+        xyz[:, valid] = t.sample_pos[self.perm[valid]].T
         self.sample_xyz = [np.ascontiguousarray(xyz[k]) for k in range(3)]
-        self.sgrid_start = np.searchsorted(cell[self.perm], np.arange(nx * ny + 1)).astype(np.int32)
-        valid = np.zeros(n_pad, dtype=bool)
-        valid[:P] = True
+        # a row's range for cells [cx0, cx1] is [start[row, cx0], start[row, cx1 + 1]); at the end of a row
+        # that takes in the alignment pads, which are far away and never valid
+        self.sgrid_start = starts.astype(np.int32)
         self.word_valid = np.packbits(valid, bitorder='little').view(np.uint64).copy()
         bbox = np.empty((n_words, 4), dtype=np.float64)
         c1 = np.where(valid, xyz[a1], np.nan).reshape(n_words, 64)
         c2 = np.where(valid, xyz[a2], np.nan).reshape(n_words, 64)
         with np.errstate(all='ignore'):
-            bbox[:, 0], bbox[:, 1] = np.nanmin(c1, axis=1), np.nanmax(c1, axis=1)
-            bbox[:, 2], bbox[:, 3] = np.nanmin(c2, axis=1), np.nanmax(c2, axis=1)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                bbox[:, 0], bbox[:, 1] = np.nanmin(c1, axis=1), np.nanmax(c1, axis=1)
+                bbox[:, 2], bbox[:, 3] = np.nanmin(c2, axis=1), np.nanmax(c2, axis=1)
+        empty = ~valid.reshape(n_words, 64).any(axis=1)
+        bbox[empty] = (np.inf, -np.inf, np.inf, -np.inf)
         self.word_bbox = bbox
         self.n_samples, self.n_samples_pad, self.n_words = P, n_pad, n_words
         self.sgrid = (o1, o2, inv, nx, ny)
@@ -58,7 +80,7 @@ class DeviceTables(object):
         cells = t.sample_cell if obs_grad == t.obs_grad else pt.grid_observation_cells(t, obs_grad)
         n_cells = self.obs_grad ** 2
         onehot = np.zeros((n_cells, n_pad), dtype=bool)
-        onehot[cells[self.perm], np.arange(P)] = True
+        onehot[cells, self.inv_perm] = True
         self.obs_cell_mask = np.packbits(onehot, axis=1, bitorder='little').view(np.uint64).reshape(n_cells, n_words).copy()
         self.obs_cell_count = np.bincount(cells, minlength=n_cells).astype(np.int32)
         # ---- same-side vertices sorted by grid cell, CSR adjacency to compact triangle ids
@@ -93,28 +115,58 @@ class DeviceTables(object):
         rec[:, 12] = t.tri_inv[front_ids]
         rec[:, 13:16] = t.tri_normal[front_ids]
         self.tri_records = rec
-        # ---- collision triangles, SoA + float32 boxes (outward by 1e-6 and one float ulp)
+        # ---- collision triangles: SoA + float32 3-D boxes (outward by 1e-6 and one float ulp).
+        # ``col_rank`` keeps the reference order for the equal-t tie break.
         C0 = t.col_v0.shape[0]
-        c_pad = ((C0 + 63) // 64) * 64
-        col = np.zeros((9, c_pad), dtype=np.float64)
-        col[0:3, :C0], col[3:6, :C0], col[6:9, :C0] = t.col_v0.T, t.col_e1.T, t.col_e2.T
-        self.col = [np.ascontiguousarray(col[k]) for k in range(9)]
         corners = np.stack([t.col_v0, t.col_v0 + t.col_e1, t.col_v0 + t.col_e2], axis=1)
-        box = np.empty((c_pad, 4), dtype=np.float32)
-        box[:, 0], box[:, 1], box[:, 2], box[:, 3] = np.inf, -np.inf, np.inf, -np.inf
-        lo1, hi1 = corners[:, :, a1].min(1) - 1e-6, corners[:, :, a1].max(1) + 1e-6
-        lo2, hi2 = corners[:, :, a2].min(1) - 1e-6, corners[:, :, a2].max(1) + 1e-6
-        box[:C0, 0] = np.nextafter(lo1.astype(np.float32), np.float32(-np.inf))
-        box[:C0, 1] = np.nextafter(hi1.astype(np.float32), np.float32(np.inf))
-        box[:C0, 2] = np.nextafter(lo2.astype(np.float32), np.float32(-np.inf))
-        box[:C0, 3] = np.nextafter(hi2.astype(np.float32), np.float32(np.inf))
+        lo, hi = corners.min(axis=1), corners.max(axis=1)
+        nrm = np.cross(t.col_e1, t.col_e2)
+        with np.errstate(all='ignore'):
+            facing = nrm[:, t.a0] / np.linalg.norm(nrm, axis=1)
+        large = ((hi[:, a1] - lo[:, a1]) > 4 * CELL) | ((hi[:, a2] - lo[:, a2]) > 4 * CELL)
+        facing = np.nan_to_num(facing)
+        # chunks of 64: small facets bucketed by a coarse K x K grid over the principal plane (compact
+        # chunk boxes), then large front-facing, large back-facing and large other facets, each group
+        # padded to a multiple of 64 so that no chunk mixes groups
+        small_ids = np.nonzero(~large)[0]
+        K = max(1, int(round(np.sqrt(max(small_ids.size, 1) / 48.0))))
+        cen = corners.mean(axis=1)
+        span1 = max(float(hi[:, a1].max() - lo[:, a1].min()), 1e-12)
+        span2 = max(float(hi[:, a2].max() - lo[:, a2].min()), 1e-12)
+        k1 = np.clip(((cen[:, a1] - lo[:, a1].min()) / span1 * K).astype(np.int64), 0, K - 1)
+        k2 = np.clip(((cen[:, a2] - lo[:, a2].min()) / span2 * K).astype(np.int64), 0, K - 1)
+        buckets = [small_ids[(k2[small_ids] * K + k1[small_ids]) == c] for c in range(K * K)]
+        buckets += [np.nonzero(large & (facing > 0.5))[0], np.nonzero(large & (facing < -0.5))[0],
+                    np.nonzero(large & (np.abs(facing) <= 0.5))[0]]
+        slots = []
+        for ids in buckets:
+            if ids.size:
+                slots.extend(ids.tolist())
+                slots.extend([-1] * ((-ids.size) % 64))
+        slots = np.asarray(slots, dtype=np.int64)
+        c_pad = slots.size
+        real = slots >= 0
+        corder = slots[real]
+        col = np.zeros((9, c_pad), dtype=np.float64)
+        col[0:3, real], col[3:6, real], col[6:9, real] = t.col_v0[corder].T, t.col_e1[corder].T, t.col_e2[corder].T
+        self.col = [np.ascontiguousarray(col[k]) for k in range(9)]
+        self.col_rank = np.full(c_pad, 0x7fffffff, dtype=np.int32)
+        self.col_rank[real] = corder
+        box = np.empty((c_pad, 8), dtype=np.float32)
+        box[:, 0::2], box[:, 1::2] = np.inf, -np.inf
+        for k, ax in enumerate((a1, a2, t.a0)):
+            box[real, 2 * k] = np.nextafter((lo[corder, ax] - 1e-6).astype(np.float32), np.float32(-np.inf))
+            box[real, 2 * k + 1] = np.nextafter((hi[corder, ax] + 1e-6).astype(np.float32), np.float32(np.inf))
+        box[:, 6], box[:, 7] = 0.0, 0.0
         self.col_bbox = box
         n_chunks = c_pad // 64
-        cb = box.reshape(n_chunks, 64, 4)
-        chunk = np.empty((((n_chunks + 63) // 64) * 64, 4), dtype=np.float32)
-        chunk[:, 0], chunk[:, 1], chunk[:, 2], chunk[:, 3] = np.inf, -np.inf, np.inf, -np.inf
-        chunk[:n_chunks, 0], chunk[:n_chunks, 1] = cb[:, :, 0].min(1), cb[:, :, 1].max(1)
-        chunk[:n_chunks, 2], chunk[:n_chunks, 3] = cb[:, :, 2].min(1), cb[:, :, 3].max(1)
+        cb = box.reshape(n_chunks, 64, 8)
+        chunk = np.empty((((n_chunks + 63) // 64) * 64, 8), dtype=np.float32)
+        chunk[:, 0::2], chunk[:, 1::2] = np.inf, -np.inf
+        for k in range(3):
+            chunk[:n_chunks, 2 * k] = cb[:, :, 2 * k].min(1)
+            chunk[:n_chunks, 2 * k + 1] = cb[:, :, 2 * k + 1].max(1)
+        chunk[:, 6], chunk[:, 7] = 0.0, 0.0
         self.col_chunk_bbox, self.n_col_chunks = chunk, n_chunks
         self.n_collision, self.n_collision_pad = C0, c_pad
         # ---- rows, start points, beams
@@ -162,6 +214,7 @@ class DeviceTables(object):
         for k in range(9):
             s.col_v0e1e2[k] = dp(self.col[k])
         s.col_bbox = self.col_bbox.ctypes.data_as(_lib._fp)
+        s.col_rank = ip(self.col_rank)
         s.n_col_chunks = self.n_col_chunks
         s.col_chunk_bbox = self.col_chunk_bbox.ctypes.data_as(_lib._fp)
         s.grid_lo, s.grid_hi = dp(self.grid_lo), dp(self.grid_hi)
@@ -180,7 +233,4 @@ class DeviceTables(object):
         (ascending j*W+i, the order of PartTables.sample_pix)."""
         words = np.ascontiguousarray(words, dtype=np.uint64)
         bits = np.unpackbits(words[..., :self.n_words].view(np.uint8), axis=-1, bitorder='little')
-        bits = bits[..., :self.n_samples].astype(bool)
-        out = np.empty_like(bits)
-        out[..., self.perm] = bits
-        return out
+        return bits[..., self.inv_perm].astype(bool)

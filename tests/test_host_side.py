@@ -92,14 +92,17 @@ def test_device_layout_invariants(name):
     t = synthetic_tables(name)
     d = DeviceTables(t)
     P = t.sample_pos.shape[0]
-    assert sorted(d.perm.tolist()) == list(range(P)) and d.n_samples_pad % 64 == 0
+    valid = d.perm >= 0
+    assert sorted(d.perm[valid].tolist()) == list(range(P)) and d.n_samples_pad % 64 == 0
+    assert np.array_equal(d.perm[d.inv_perm], np.arange(P))
     assert int(np.unpackbits(d.word_valid.view(np.uint8)).sum()) == P
+    o1, o2, inv, nx, ny = d.sgrid
+    assert (d.sgrid_start[::nx][:ny] % 64 == 0).all()          # every cell row starts on a word
     # every sample within the paint radius of a random centre lies in the 3x3 cell block the kernel scans
     rng = np.random.RandomState(0)
-    xyz = np.stack([a[:P] for a in d.sample_xyz], axis=1)
-    o1, o2, inv, nx, ny = d.sgrid
+    xyz = np.stack(d.sample_xyz, axis=1)
     for _ in range(200):
-        c = xyz[rng.randint(P)] + rng.normal(0, 0.02, 3)
+        c = xyz[d.inv_perm[rng.randint(P)]] + rng.normal(0, 0.02, 3)
         near = np.nonzero(((xyz - c) ** 2).sum(1) <= 0.051 ** 2)[0]
         icx, icy = int(np.floor((c[t.a1] - o1) * inv)), int(np.floor((c[t.a2] - o2) * inv))
         got = []
@@ -118,6 +121,8 @@ def test_device_layout_invariants(name):
     assert np.array_equal(total, d.word_valid)
     # adjacency is the reference's uv_map restricted to the side, file order
     assert d.vertex_adj.max() < d.tri_records.shape[0] and (d.vertex_adj >= -1).all()
+    assert sorted(d.col_rank[d.col_rank != 0x7fffffff].tolist()) == list(range(d.n_collision))
+    assert d.n_collision_pad % 64 == 0 and d.n_col_chunks <= 64
     assert CELL > 0.051
     words = rng.randint(0, 2 ** 63, size=(2, d.n_words)).astype(np.uint64) & d.word_valid
     back = d.mask_to_canonical(words)

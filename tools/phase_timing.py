@@ -33,7 +33,7 @@ def main():
     else:
         lib.prl_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
-    n = 4096
+    n = int(os.environ.get('PRL_ENVS', '4096'))
     env = BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=5678)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
@@ -58,6 +58,7 @@ def main():
     print('wall per step: %.1f us' % ((time.perf_counter() - t0) / 300 * 1e6))
     per_wave = tot / (300 * n)
     print('cycles per env-step (wave lifetime, stamped build): %.0f' % per_wave)
+    print('rays %d, second-stage rays %d (%.1f %%), chunks visited per ray %.2f, MT evaluations per ray %.2f' % (buf[10], buf[11], 100.0 * buf[11] / max(buf[10], 1), buf[12] / max(buf[10], 1), buf[13] / max(buf[10], 1)))
     for name, v in zip(NAMES, buf):
         print('  %-7s %6.1f %%  %8.0f cyc/env-step' % (name, 100.0 * v / tot, v / (300 * n)))
 
