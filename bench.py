@@ -39,7 +39,7 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
                + 2 * 16 * 8               # 128-byte scalar state record, read and write
                + 4                        # action (int32)
                + obs_dim * 8 + 8 + 1 + 16)  # obs, reward, done, info (float64 like the reference)
-    static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sgrid_start.nbytes
+    static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sample_rank.nbytes + dt.sgrid_start.nbytes
               + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
               + dt.vgrid_start.nbytes + dt.tri_records.nbytes
               + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes

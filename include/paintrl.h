@@ -53,6 +53,7 @@ typedef struct {
     const double *sample_xyz[3];  /* world x, y, z, [n_samples_pad]; pads are far away */
     const double *word_bbox;      /* [n_samples_pad/64][4]: min/max on axis a1, min/max on axis a2 */
     const uint64_t *word_valid;   /* [n_samples_pad/64] bit set = real sample */
+    const int32_t *sample_rank;   /* [n_samples_pad] index in the reference order (nearest-sample tie break), pads INT32_MAX */
     /* uniform grid over the principal plane that orders the samples */
     double sgrid_origin[2], sgrid_inv_cell;
     int32_t sgrid_nx, sgrid_ny;

@@ -19,7 +19,7 @@ _fp = C.POINTER(C.c_float)
 class PrlPartTables(C.Structure):
     _fields_ = [
         ('n_samples', C.c_int32), ('n_samples_pad', C.c_int32),
-        ('sample_xyz', _dp * 3), ('word_bbox', _dp), ('word_valid', _up),
+        ('sample_xyz', _dp * 3), ('word_bbox', _dp), ('word_valid', _up), ('sample_rank', _ip),
         ('sgrid_origin', C.c_double * 2), ('sgrid_inv_cell', C.c_double),
         ('sgrid_nx', C.c_int32), ('sgrid_ny', C.c_int32), ('sgrid_start', _ip),
         ('n_obs_cells', C.c_int32), ('obs_cell_mask', _up), ('obs_cell_count', _ip),

@@ -64,6 +64,7 @@ struct PartDev {
     gdouble_p samp[3];
     gdouble_p word_bbox;
     gu64_p word_valid;
+    gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
     double sg_o1, sg_o2, sg_inv;
     int sg_nx, sg_ny;
     gint_p sg_start;
@@ -501,6 +502,69 @@ __device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lan
     if ((tie & (tie - 1)) == 0) return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(tie)));
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
     const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
+    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
+}
+
+// ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1): nearest sample
+// Same exact expanding-ring search as for vertices, over the sample grid; equal distances resolve
+// to the lowest reference-order index.  Returns the device position of the sample, or -1.
+__device__ int nearest_sample_wave(const PartDev &P, const double pt[3], int lane) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(h2, P.sg_o2, P.sg_inv, P.sg_ny);
+    double best_d = INFINITY, dmin = INFINITY;
+    int best_rank = 0x7fffffff, best_idx = -1;
+    bool exact = false;
+    for (int ring = 1; ring <= 3 && !exact; ++ring) {
+        const int nrows = 2 * ring + 1;
+        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.sg_nx - 1 ? P.sg_nx - 1 : icx + ring;
+        const int rcy = icy - ring + (lane >> 1);
+        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
+        const int bound = okr ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+            if (r >= nrows) continue;
+            for (int s0 = b0; s0 < e0; s0 += 64) {
+                const int sidx = s0 + lane;
+                if (sidx < e0) {
+                    const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const int rk = P.samp_rank[sidx];
+                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        best_d = dd;
+                        best_rank = rk;
+                        best_idx = sidx;
+                    }
+                }
+            }
+        }
+        dmin = wave_min_d(best_d);
+        const double lim = ring * P.vg_accept;
+        exact = dmin <= lim * lim;
+    }
+    if (!exact) {                                   // far from every sample: scan the whole table
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        for (int s0 = 0; s0 < P.n_samples_pad; s0 += 64) {
+            const int sidx = s0 + lane;
+            const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            const int rk = P.samp_rank[sidx];
+            if (rk != 0x7fffffff && (dd < best_d || (dd == best_d && rk < best_rank))) {
+                best_d = dd;
+                best_rank = rk;
+                best_idx = sidx;
+            }
+        }
+        dmin = wave_min_d(best_d);
+    }
+    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
+    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin && best_idx >= 0);
+    if (win == 0) return -1;
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
 
@@ -959,7 +1023,8 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
 }
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
-template <int KW>
+// NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
+template <int KW, bool NORMAL>
 __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1020,6 +1085,8 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
     tcp_orn_norm(S.pose, S.quat, cur_norm);
     const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
+    uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
+    uint32_t n_succeeded_l = 0;
     __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
     double *cen = s_centres[threadIdx.x >> 6];
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
@@ -1074,10 +1141,41 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         for (int k = 0; k < 3; ++k)
             if (lane == 0) cen[3 * shot + k] = center[k];
         STAMP(PH_MATH);
+        if constexpr (NORMAL) {
+            // rob:251-258, 280-285: one ray per cone beam from the tool to the beam's end point on the
+            // plane 0.2 ahead; bpw:562-566: every hit paints the sample nearest to it.  No hit at all:
+            // the reference returns early and leaves the last-shot set untouched.
+            uint64_t cur[KW_MAX] = {0, 0, 0, 0};
+            int beam_hits = 0;
+            for (int bm = 0; bm < P.n_beams; ++bm) {
+                double dst[3], bt, bh[3];
+                transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
+                if (ray_closest_wave(P, pos, dst, lane, bt, bh) < 0) continue;
+                ++beam_hits;
+                const int sidx = nearest_sample_wave(P, bh, lane);
+                if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
+            }
+            if (beam_hits > 0) {
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    n_succeeded_l += __popcll(cur[k] & ~painted[k]);
+                    painted[k] |= cur[k];
+                    n_uni[k] |= cur[k] & ~last[k];
+                    last[k] = cur[k];
+                }
+            }
+        }
     }
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
-    {
+    if constexpr (NORMAL) {
+        uint32_t pix_l = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) pix_l += __popcll(n_uni[k]);
+        const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
+        succeeded = (int)(sums >> 32);
+        pixel_counter = (int)(sums & 0xffffffffu);
+    } else {
         uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
 #ifdef PRL_ABLATE_BALL
         if (true) {
@@ -1280,6 +1378,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     for (int k = 0; k < 3; ++k) UP(samp[k], t->sample_xyz[k], t->n_samples_pad);
     UP(word_bbox, t->word_bbox, (size_t)d.n_words * 4);
     UP(word_valid, t->word_valid, d.n_words);
+    UP(samp_rank, t->sample_rank, t->n_samples_pad);
     d.sg_o1 = t->sgrid_origin[0];
     d.sg_o2 = t->sgrid_origin[1];
     d.sg_inv = t->sgrid_inv_cell;
@@ -1361,15 +1460,15 @@ int check_config(const PrlConfig *c) {
         return fail(PRL_E_INVALID, "action_mode %d", c->action_mode);
     }
     if (c->termination_mode < 0 || c->termination_mode > 2) return fail(PRL_E_INVALID, "termination_mode");
-    if (c->paint_method != PRL_PAINT_FAST)
-        return fail(PRL_E_UNSUPPORTED, "PAINT_METHOD='normal' (cone beams) is not on device yet");
+    if (c->paint_method != PRL_PAINT_FAST && c->paint_method != PRL_PAINT_NORMAL) return fail(PRL_E_INVALID, "paint_method");
     if (c->max_episode_len < 1 || c->expected_episode_len < 1) return fail(PRL_E_INVALID, "episode lengths");
     return PRL_OK;
 }
 
 template <int KW>
-void launch_step(const StepArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(step_kernel<KW>, dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+void launch_step(const StepArgs &a, bool normal, hipStream_t s) {
+    if (normal) hipLaunchKernelGGL((step_kernel<KW, true>), dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<KW, false>), dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
 }
 
 template <int KW>
@@ -1450,6 +1549,8 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     for (int i = 0; i < n_parts; ++i) {
         if (!parts[i]) return fail(PRL_E_INVALID, "null part %d", i);
         if (parts[i]->device != parts[0]->device) return fail(PRL_E_INVALID, "parts live on different devices");
+        if (cfg->paint_method == PRL_PAINT_NORMAL && parts[i]->dev.n_beams <= 0)
+            return fail(PRL_E_INVALID, "part %d has no cone beams but PAINT_METHOD='normal' was requested", i);
         if (cfg->obs_mode == PRL_OBS_GRID && parts[i]->dev.n_obs_cells != cfg->obs_grad * cfg->obs_grad)
             return fail(PRL_E_INVALID, "part %d was packed for %d observation cells, config wants %d", i,
                         parts[i]->dev.n_obs_cells, cfg->obs_grad * cfg->obs_grad);
@@ -1539,6 +1640,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     a.final_obs = final_obs;
     a.start_idx = start_idx;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL;
     if (b->timing) {
         if (b->ev_used == b->ev_start.size()) {
             hipEvent_t e0, e1;
@@ -1550,10 +1652,10 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
     switch (b->kw) {
-    case 1: launch_step<1>(a, s); break;
-    case 2: launch_step<2>(a, s); break;
-    case 3: launch_step<3>(a, s); break;
-    default: launch_step<4>(a, s); break;
+    case 1: launch_step<1>(a, normal, s); break;
+    case 2: launch_step<2>(a, normal, s); break;
+    case 3: launch_step<3>(a, normal, s); break;
+    default: launch_step<4>(a, normal, s); break;
     }
     HIP_TRY(hipGetLastError());
     if (b->timing) {

@@ -61,6 +61,7 @@ class DeviceTables(object):
         # that takes in the alignment pads, which are far away and never valid
         self.sgrid_start = starts.astype(np.int32)
         self.word_valid = np.packbits(valid, bitorder='little').view(np.uint64).copy()
+        self.sample_rank = np.where(valid, self.perm, 0x7fffffff).astype(np.int32)
         bbox = np.empty((n_words, 4), dtype=np.float64)
         c1 = np.where(valid, xyz[a1], np.nan).reshape(n_words, 64)
         c2 = np.where(valid, xyz[a2], np.nan).reshape(n_words, 64)
@@ -197,6 +198,7 @@ class DeviceTables(object):
             s.vertex_xyz[k] = dp(self.vertex_xyz[k])
         s.word_bbox = dp(self.word_bbox)
         s.word_valid = self.word_valid.ctypes.data_as(_lib._up)
+        s.sample_rank = ip(self.sample_rank)
         s.sgrid_origin[0], s.sgrid_origin[1], s.sgrid_inv_cell, s.sgrid_nx, s.sgrid_ny = self.sgrid
         s.sgrid_start = ip(self.sgrid_start)
         s.n_obs_cells = self.obs_grad ** 2

@@ -16,7 +16,7 @@ def _gpu_env(tables, n, start_points, **kw):
     return BatchedPaintEnv(DeviceTables(tables, obs_grad=obs_grad, start_points=start_points), n, **kw)
 
 
-DEVICE_CASES = [c for c in CASES if 'normal' not in c[1]]      # cone-beam paint is not on device yet
+DEVICE_CASES = CASES
 
 
 @pytest.mark.parametrize('tag,name', DEVICE_CASES)
@@ -49,11 +49,15 @@ def test_gpu_replays_reference_episode(tag, name):
     ('door_test', dict(obs_mode='discrete', termination_mode='hybrid')),
     ('square', dict(obs_mode='section', max_possible_point=14350)),
     ('square', dict(obs_mode='simple', n_discrete=8, max_possible_point=14350)),
+    ('door_test', dict(obs_mode='section', paint_method='normal', _n=48, _steps=8)),
+    ('square', dict(obs_mode='grid', paint_method='normal', overlap_penalty=True, max_possible_point=14350, _n=32,
+                    _steps=6)),
 ])
 def test_gpu_matches_oracle_on_random_batch(part, kw):
     tables = synthetic_tables(part)
     sp = start_points_for(tables, 'all')
-    n, steps = 192, 40
+    kw = dict(kw)
+    n, steps = kw.pop('_n', 192), kw.pop('_steps', 40)
     env = _gpu_env(tables, n, sp, **kw)
     orc = oracle.Oracle(tables, n, start_points=sp, threads=8, **kw)
     rng = np.random.RandomState(11)
