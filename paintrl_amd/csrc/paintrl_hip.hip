@@ -209,6 +209,12 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// A wave-uniform double computed by the vector ALU sits in a VGPR pair; moving it to scalar
+// registers frees vector registers for the per-lane work (masks, Moller-Trumbore temporaries).
+__device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(rfl(__double2hiint(v)), rfl(__double2loint(v)));
+}
+
 __device__ __forceinline__ double sel3(double x, double y, double z, int axis) {
     return axis == 0 ? x : (axis == 1 ? y : z);
 }
@@ -1084,7 +1090,9 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     // ---- five chained sub-shots   rob:302-329 + 403-424
     double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
     tcp_orn_norm(S.pose, S.quat, cur_norm);
-    const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cur_norm[k] = uni_d(cur_norm[k]);
+    const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
     uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
     uint32_t n_succeeded_l = 0;
     __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
@@ -1128,12 +1136,17 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            pos[k] = uni_d(pos[k]);
+            orn[k] = uni_d(orn[k]);
             cur_pose[k] = pos[k];
             cur_norm[k] = orn[k];
             S.pose[k] = pos[k];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];
+        for (int k = 0; k < 4; ++k) {
+            quat[k] = uni_d(quat[k]);
+            S.quat[k] = quat[k];
+        }
         // rob:277-278 shot centre; painting is deferred until all five centres are known
         double center[3];
         transform_point(pos, quat, 0.0, 0.0, 0.1, center);
