@@ -344,6 +344,21 @@ static int handle_pos(double v) {
     return (int)(v * 20) + 1;
 }
 
+/* CPython float_floor_div (Objects/floatobject.c): the `//` of bpw:1030 */
+static double py_floor_div(double vx, double wx) {
+    double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod) {
+        if ((wx < 0) != (mod < 0)) div -= 1.0;
+    }
+    if (div) {
+        double fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+        return fl;
+    }
+    return copysign(0.0, vx / wx);
+}
+
 /* rge:306-319 _augmented_observation (+ bpw:1045-1061, 1126-1139) */
 static void observation(const OrPart *p, const OrConfig *c, const OrEnv *e, const uint64_t *painted, double *obs) {
     double npose[2];
@@ -383,8 +398,8 @@ static void observation(const OrPart *p, const OrConfig *c, const OrEnv *e, cons
         } else {                                   /* bpw:1026-1031 */
             double ang = atan2(ry, rx);
             if (ang < 0) ang = 2 * M_PI + ang;
-            idx = (int)floor(ang / basis);
-            if (idx > g - 1) idx = g - 1;
+            idx = (int)py_floor_div(ang, basis);
+            if (idx > g - 1) idx = g - 1;       /* the reference raises IndexError here (angle rounds to 2*pi) */
         }
         total[idx] += 1;
         undone[idx] += 1 - (int)((painted[s >> 6] >> (s & 63)) & 1);

@@ -798,7 +798,54 @@ __device__ __forceinline__ int handle_pos(double v) {        // rge:92-98
     return (int)(v * 20) + 1;
 }
 
+// CPython float_floor_div, the `//` of bpw:1030 (exact floor of the true quotient)
+__device__ __forceinline__ double py_floor_div(double vx, double wx) {
+    const double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+    if (div != 0.0) {
+        double fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+        return fl;
+    }
+    return copysign(0.0, vx / wx);
+}
+
+// bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
+// is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
 template <int KW>
+__device__ void section_general_wave(const PartDev &P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
+                                     int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
+    gdouble_p sx = P.samp[P.a1], sy = P.samp[P.a2];
+    cnt[lane] = 0;
+    cnt[64 + lane] = 0;
+    const double two_pi = 2 * PI, basis = two_pi / g;
+    for (int w = 0; w < P.n_words; ++w) {
+        const uint64_t vw = P.word_valid[w];
+        uint64_t pw = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
+        if (!((vw >> lane) & 1)) continue;
+        const int s = (w << 6) + lane;
+        const double rx = sx[s] - x1, ry = sy[s] - x2;
+        if (rx == 0 && ry == 0) continue;
+        double ang = atan2(ry, rx);
+        if (ang < 0) ang = two_pi + ang;
+        int idx = (int)py_floor_div(ang, basis);
+        idx = idx > g - 1 ? g - 1 : (idx < 0 ? 0 : idx);
+        atomicAdd(&cnt[idx], 1);
+        if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
+    }
+    if (lane < g) {
+        const int t = cnt[lane], u = cnt[64 + lane];
+        out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
+    }
+}
+
+// GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
+// its registers or code.
+template <int KW, bool GENSEC>
 __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const double pose[3],
                                  const uint64_t painted[KW_MAX], int lane, double *out) {
     // bpw:965-978 get_normalized_pose
@@ -845,7 +892,21 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
         }
         return;
     }
-    // section / discrete, 4-sector rule bpw:1034-1043 (only obs_grad == 4 reaches the device)
+    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
+        __shared__ int s_cnt[4][128];
+        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, s_cnt[threadIdx.x >> 6], out);
+        if (lane == 0) {
+            if (mode == PRL_OBS_SECTION) {
+                out[C.obs_grad] = np0;
+                out[C.obs_grad + 1] = np1;
+            } else {
+                const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);
+                out[C.obs_grad] = 1.0 / (double)position;
+            }
+        }
+        return;
+    } else {
+    // section / discrete, 4-sector rule bpw:1034-1043
     gdouble_p sx = P.samp[P.a1], sy = P.samp[P.a2];
     uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane
     uint32_t tot_u[4] = {0, 0, 0, 0}, und_u[4] = {0, 0, 0, 0};
@@ -922,6 +983,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
             const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
             out[4] = 1.0 / (double)position;
         }
+    }
     }
 }
 
@@ -1010,7 +1072,7 @@ __host__ __device__ inline int obs_dim_of(const PrlConfig &c) {          // rge:
 }
 
 // ---------------------------------------------------------------- reset kernel (rge:370-387)
-template <int KW>
+template <int KW, bool GENSEC>
 __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1025,12 +1087,12 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) observation_wave<KW>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C));
+    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C));
 }
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
-template <int KW, bool NORMAL>
+template <int KW, bool NORMAL, bool GENSEC>
 __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1248,7 +1310,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     double *obs_row = a.obs + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
 #ifndef PRL_ABLATE_OBS
-    if (term_row) observation_wave<KW>(P, C, S.pose, painted, lane, term_row);
+    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
 #endif
     if (lane == 0) {
         a.reward[env] = actual;
@@ -1274,7 +1336,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             painted[k] = 0;
             last[k] = 0;
         }
-        observation_wave<KW>(P, C, S.pose, painted, lane, obs_row);
+        observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row);
     }
     STAMP(PH_OBS);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
@@ -1461,8 +1523,8 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
 
 int check_config(const PrlConfig *c) {
     if (c->obs_mode < 0 || c->obs_mode > 3) return fail(PRL_E_INVALID, "obs_mode %d", c->obs_mode);
-    if ((c->obs_mode == PRL_OBS_SECTION || c->obs_mode == PRL_OBS_DISCRETE) && c->obs_grad != 4)
-        return fail(PRL_E_UNSUPPORTED, "section/discrete observation: only OBS_GRAD=4 (the 4-sector rule) is on device");
+    if ((c->obs_mode == PRL_OBS_SECTION || c->obs_mode == PRL_OBS_DISCRETE) && (c->obs_grad < 1 || c->obs_grad > 62))
+        return fail(PRL_E_UNSUPPORTED, "section/discrete observation: OBS_GRAD must be 1..62");
     if (c->obs_mode == PRL_OBS_GRID && (c->obs_grad < 1 || c->obs_grad > 16))
         return fail(PRL_E_UNSUPPORTED, "grid observation: OBS_GRAD must be 1..16");
     if (c->action_mode == PRL_ACT_DISCRETE) {
@@ -1479,14 +1541,23 @@ int check_config(const PrlConfig *c) {
 }
 
 template <int KW>
-void launch_step(const StepArgs &a, bool normal, hipStream_t s) {
-    if (normal) hipLaunchKernelGGL((step_kernel<KW, true>), dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<KW, false>), dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+void launch_step(const StepArgs &a, bool normal, bool gensec, hipStream_t s) {
+    const dim3 grid((a.n_envs + 3) / 4), block(256);
+    if (normal && gensec) hipLaunchKernelGGL((step_kernel<KW, true, true>), grid, block, 0, s, a);
+    else if (normal) hipLaunchKernelGGL((step_kernel<KW, true, false>), grid, block, 0, s, a);
+    else if (gensec) hipLaunchKernelGGL((step_kernel<KW, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<KW, false, false>), grid, block, 0, s, a);
 }
 
 template <int KW>
-void launch_reset(const StepArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(reset_kernel<KW>, dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+void launch_reset(const StepArgs &a, bool gensec, hipStream_t s) {
+    const dim3 grid((a.n_envs + 3) / 4), block(256);
+    if (gensec) hipLaunchKernelGGL((reset_kernel<KW, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((reset_kernel<KW, false>), grid, block, 0, s, a);
+}
+
+bool general_section(const PrlConfig &c) {
+    return (c.obs_mode == PRL_OBS_SECTION || c.obs_mode == PRL_OBS_DISCRETE) && c.obs_grad != 4;
 }
 
 StepArgs base_args(PrlBatch *b) {
@@ -1632,10 +1703,10 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
     a.obs = obs;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (b->kw) {
-    case 1: launch_reset<1>(a, s); break;
-    case 2: launch_reset<2>(a, s); break;
-    case 3: launch_reset<3>(a, s); break;
-    default: launch_reset<4>(a, s); break;
+    case 1: launch_reset<1>(a, general_section(b->cfg), s); break;
+    case 2: launch_reset<2>(a, general_section(b->cfg), s); break;
+    case 3: launch_reset<3>(a, general_section(b->cfg), s); break;
+    default: launch_reset<4>(a, general_section(b->cfg), s); break;
     }
     HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -1665,10 +1736,10 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
     switch (b->kw) {
-    case 1: launch_step<1>(a, normal, s); break;
-    case 2: launch_step<2>(a, normal, s); break;
-    case 3: launch_step<3>(a, normal, s); break;
-    default: launch_step<4>(a, normal, s); break;
+    case 1: launch_step<1>(a, normal, general_section(b->cfg), s); break;
+    case 2: launch_step<2>(a, normal, general_section(b->cfg), s); break;
+    case 3: launch_step<3>(a, normal, general_section(b->cfg), s); break;
+    default: launch_step<4>(a, normal, general_section(b->cfg), s); break;
     }
     HIP_TRY(hipGetLastError());
     if (b->timing) {

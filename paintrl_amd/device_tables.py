@@ -78,12 +78,21 @@ class DeviceTables(object):
         self.sgrid = (o1, o2, inv, nx, ny)
         # ---- grid-observation cell masks (bpw GridObservation)
         self.obs_grad = int(obs_grad)
-        cells = t.sample_cell if obs_grad == t.obs_grad else pt.grid_observation_cells(t, obs_grad)
-        n_cells = self.obs_grad ** 2
-        onehot = np.zeros((n_cells, n_pad), dtype=bool)
-        onehot[cells, self.inv_perm] = True
-        self.obs_cell_mask = np.packbits(onehot, axis=1, bitorder='little').view(np.uint64).reshape(n_cells, n_words).copy()
-        self.obs_cell_count = np.bincount(cells, minlength=n_cells).astype(np.int32)
+        # (a granularity whose 100/h rows do not tile the part has no grid observation in the reference
+        # either -- it raises KeyError; section / discrete / simple modes do not need the cells)
+        try:
+            cells = t.sample_cell if obs_grad == t.obs_grad else pt.grid_observation_cells(t, obs_grad)
+            n_cells = self.obs_grad ** 2
+        except KeyError:
+            cells, n_cells = np.zeros(P, dtype=np.int32), 0
+        self.n_obs_cells = n_cells
+        onehot = np.zeros((max(n_cells, 1), n_pad), dtype=bool)
+        if n_cells:
+            onehot[cells, self.inv_perm] = True
+        self.obs_cell_mask = np.packbits(onehot, axis=1, bitorder='little').view(np.uint64).reshape(
+            max(n_cells, 1), n_words).copy()
+        self.obs_cell_count = np.bincount(cells, minlength=max(n_cells, 1)).astype(np.int32) if n_cells else \
+            np.zeros(1, dtype=np.int32)
         # ---- same-side vertices sorted by grid cell, CSR adjacency to compact triangle ids
         side_ids = np.nonzero(t.vertex_is_side)[0]
         vpos = t._side_data[side_ids]
@@ -201,7 +210,7 @@ class DeviceTables(object):
         s.sample_rank = ip(self.sample_rank)
         s.sgrid_origin[0], s.sgrid_origin[1], s.sgrid_inv_cell, s.sgrid_nx, s.sgrid_ny = self.sgrid
         s.sgrid_start = ip(self.sgrid_start)
-        s.n_obs_cells = self.obs_grad ** 2
+        s.n_obs_cells = self.n_obs_cells
         s.obs_cell_mask = self.obs_cell_mask.ctypes.data_as(_lib._up)
         s.obs_cell_count = ip(self.obs_cell_count)
         s.n_vertices = self.vertex_rank.shape[0]

@@ -289,6 +289,10 @@ def main():
     eps['g8_early'] = door.episode(302, zigzag_policy_discrete(), max_steps=80, want_idx=0)
     door.configure('section', 4, 'anchor', termination='hybrid', action=('discrete', 1, 8))
     eps['g8_hybrid_gran8'] = door.episode(303, random_policy(60, 8), max_steps=80, want_idx=0)
+    door.configure('section', 6, 'anchor')
+    eps['g9_section6'] = door.episode(305, zigzag_policy_grid(), max_steps=40, want_idx=0)
+    door.configure('discrete', 9, 'anchor', overlap=True)
+    eps['g9_discrete9'] = door.episode(306, random_policy(61), max_steps=40, want_idx=3)
     door.configure('section', 4, 'anchor', paint_method='normal')
     eps['g6_normal_door'] = door.episode(304, zigzag_policy(-1, 2), max_steps=12, want_idx=0)
     save_episodes('door', eps)
