@@ -1097,6 +1097,9 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
+#ifdef PRL_WAVE_TIMES
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int part_id = a.env_part ? a.env_part[env] : 0;
     const PartDev &P = a.parts[part_id];
     const PrlConfig &C = *a.cfg;
@@ -1342,6 +1345,13 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     STAMP(PH_STORE);
+#ifdef PRL_WAVE_TIMES      // diagnostic build: wave lifetime and on-part shot count into final_obs[env][0..1]
+    if (lane == 0 && a.final_obs) {
+        a.final_obs[(size_t)env * od] = (double)(__builtin_amdgcn_s_memtime() - wave_t0);
+        a.final_obs[(size_t)env * od + 1] = (double)(S.terminate_counter - counter_before);
+        a.final_obs[(size_t)env * od + 2] = (double)dn;
+    }
+#endif
 #ifdef PRL_PHASE_TIMING
     if (lane == 0)
         for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], prof.acc[k]);

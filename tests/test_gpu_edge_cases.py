@@ -1,0 +1,169 @@
+"""GPU edge cases of the C ABI: odd batch sizes, masked reset, error codes, RNG reset, read-back."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import start_points_for, synthetic_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(tables, n, sp=None, **kw):
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    return BatchedPaintEnv(DeviceTables(tables, obs_grad=kw.get('obs_grad', 4), start_points=sp), n, **kw)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 7, 65])
+def test_batch_sizes_not_multiple_of_workgroup(n):
+    """4 envs share a workgroup; the last workgroup may be partly empty."""
+    tables = synthetic_tables('door_test')
+    env = _env(tables, n)
+    orc = oracle.Oracle(tables, n)
+    start = np.arange(n) % 4
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    rng = np.random.RandomState(n)
+    for _ in range(6):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr)
+        assert np.array_equal(d.cpu().numpy(), dd) and np.array_equal(i.cpu().numpy(), ii)
+    env.close()
+
+
+def test_masked_reset_leaves_other_envs_untouched():
+    tables = synthetic_tables('door_test')
+    n = 16
+    env = _env(tables, n)
+    env.reset(start_idx=np.zeros(n, dtype=np.int32))
+    for _ in range(3):
+        env.step(np.ones(n, dtype=np.int32))
+    before = env.painted_words().cpu().numpy().copy()
+    st0 = env.state()
+    mask = np.zeros(n, dtype=bool)
+    mask[[1, 5, 6]] = True
+    obs_before = env.obs.cpu().numpy().copy()
+    obs = env.reset(mask=mask, start_idx=np.full(n, 2, dtype=np.int32)).cpu().numpy()
+    after = env.painted_words().cpu().numpy()
+    st1 = env.state()
+    assert (after[mask] == 0).all() and np.array_equal(after[~mask], before[~mask])
+    assert np.array_equal(obs[~mask], obs_before[~mask])              # rows of envs not reset are untouched
+    assert (st1['step_counter'][mask] == 0).all() and np.array_equal(st1['step_counter'][~mask], st0['step_counter'][~mask])
+    assert np.array_equal(st1['pose'][mask], np.tile(np.array(tables.anchor_points[2][0]), (3, 1)))
+    assert (st1['episode'][mask] == st0['episode'][mask] + 1).all()
+    env.close()
+
+
+def test_library_rng_start_points_are_valid_and_seeded():
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    pos = np.array([p[0] for p in sp])
+    a = _env(tables, 512, sp, seed=7)
+    b = _env(tables, 512, sp, seed=7)
+    c = _env(tables, 512, sp, seed=8)
+    a.reset(), b.reset(), c.reset()
+    pa, pb, pc = a.state()['pose'], b.state()['pose'], c.state()['pose']
+    assert np.array_equal(pa, pb) and not np.array_equal(pa, pc)
+    # every drawn pose is one of the table's start points, and many different ones are used
+    d = np.abs(pa[:, None, :] - pos[None, :, :]).sum(-1).min(1)
+    assert (d == 0).all() and len({tuple(p) for p in pa}) > 300
+    for e in (a, b, c):
+        e.close()
+
+
+def test_error_codes_and_messages():
+    from paintrl_amd import _lib, config
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = synthetic_tables('door_test')
+    dt = DeviceTables(tables)
+    with pytest.raises(_lib.PaintRLError, match='observation cells'):
+        BatchedPaintEnv(dt, 4, obs_mode='grid', obs_grad=5)           # part packed for 4x4 cells
+    with pytest.raises(_lib.PaintRLError, match='OBS_GRAD'):
+        BatchedPaintEnv(dt, 4, obs_mode='section', obs_grad=99)
+    with pytest.raises(_lib.PaintRLError, match='action_dim'):
+        BatchedPaintEnv(dt, 4, action_mode='continuous', action_dim=3)
+    with pytest.raises(_lib.PaintRLError, match='env_part_id'):
+        BatchedPaintEnv(dt, 4, env_part_id=[0, 0, 1, 0])
+    lib = _lib.load()
+    st = dt.c_struct()
+    st.n_samples_pad = dt.n_samples_pad + 1                           # not a multiple of 64
+    h = C.c_void_p()
+    assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -1 and b'sample counts' in lib.prl_last_error()
+    st = dt.c_struct()
+    st.adj_width = 0
+    assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -3
+    st = dt.c_struct()
+    st.n_samples, st.n_samples_pad = 64 * 64 * 4 + 64, 64 * 64 * 4 + 64    # beyond the register-resident limit
+    assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -3 and b'at most' in lib.prl_last_error()
+    assert lib.prl_batch_step(None, None, None, None, None, None, None, None, None) == -1
+    assert config.make_config().auto_reset == 0
+
+
+def test_episode_statistics_and_returns_payload():
+    """On done the kernel records return / length / coverage of the finished episode (the gather payload)."""
+    tables = synthetic_tables('door_test')
+    n = 64
+    env = _env(tables, n, auto_reset=True, seed=3)
+    orc = oracle.Oracle(tables, n)
+    start = np.arange(n) % 4
+    env.reset(start_idx=start)
+    orc.reset(start)
+    rng = np.random.RandomState(0)
+    seen = np.zeros(n, dtype=bool)
+    want_ret, want_len, want_cov = np.zeros(n), np.zeros(n, dtype=int), np.zeros(n, dtype=int)
+    for k in range(40):
+        a = rng.randint(0, 4, size=n)
+        nxt = rng.randint(0, 4, size=n)
+        _, _, d, _ = env.step(a, start_idx=nxt)
+        _, _, dd, _ = orc.step(a)
+        d = d.cpu().numpy()
+        assert np.array_equal(d, dd)
+        for e in np.nonzero(dd)[0]:
+            st = orc.state(e)
+            want_ret[e], want_len[e], want_cov[e] = st['total_return'], st['step_counter'], orc.painted_bits(e).sum()
+            seen[e] = True
+        if dd.any():
+            orc.reset(nxt, mask=dd)
+    st = env.state()
+    ret = env.episode_returns().cpu().numpy()
+    assert seen.sum() > 20
+    assert np.array_equal(ret[seen], want_ret[seen]) and np.array_equal(st['last_episode_len'][seen], want_len[seen])
+    assert np.array_equal(st['last_episode_painted'][seen], want_cov[seen])
+    env.close()
+
+
+def test_full_size_round_trip_properties():
+    """BASELINE size (4096 envs): size-independent properties instead of an oracle replay --
+    coverage only grows within an episode, reward*100 equals the coverage delta, info = (reward, penalty)."""
+    tables = synthetic_tables('door_test')
+    n = 4096
+    env = _env(tables, n)
+    start = np.arange(n) % 4
+    env.reset(start_idx=start)
+    rng = np.random.RandomState(1)
+    cov = np.zeros(n, dtype=np.int64)
+    for k in range(12):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        words = env.painted_words().cpu().numpy().view(np.uint64)
+        new_cov = np.unpackbits(words.view(np.uint8), axis=1).sum(1)
+        i = i.cpu().numpy()
+        assert (new_cov >= cov).all()
+        assert np.array_equal(np.rint(i[:, 0] * 100).astype(np.int64), new_cov - cov)
+        assert np.array_equal(r.cpu().numpy(), i[:, 0] - i[:, 1]) and (i[:, 1] == 0.2).all()
+        o = o.cpu().numpy()
+        assert (o >= 0).all() and (o <= 1).all()
+        cov = new_cov
+    # two envs with the same start and actions are identical (determinism, no cross-env coupling)
+    env2 = _env(tables, n)
+    env2.reset(start_idx=start)
+    rng = np.random.RandomState(1)
+    for k in range(12):
+        env2.step(rng.randint(0, 4, size=n))
+    assert np.array_equal(env.painted_words().cpu().numpy(), env2.painted_words().cpu().numpy())
+    env.close()
+    env2.close()
