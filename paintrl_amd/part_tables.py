@@ -615,3 +615,59 @@ def cone_beams(density):
         i += resolution
         j = -radius
     return np.asarray(out, dtype=np.float64).reshape(-1, 3)
+
+
+# ----------------------------------------------------------------------------
+# on-disk table format: one .npz per part
+# ----------------------------------------------------------------------------
+_ARRAY_FIELDS = ['vertices', 'tri_vidx', 'tri_side', 'tri_area', 'tri_area_valid', 'tri_center', 'tri_a', 'tri_v0',
+                 'tri_v1', 'tri_d00', 'tri_d01', 'tri_d11', 'tri_inv', 'tri_normal', 'sample_pix', 'sample_pos',
+                 'sample_cell', 'vertex_is_side', '_side_data', 'col_v0', 'col_e1', 'col_e2', 'grid_lo', 'grid_hi',
+                 'grid_range', 'beams', 'front_ids']
+_SCALAR_FIELDS = ['name', 'tex_w', 'tex_h', 'collision_mode', 'obs_grad', 'a0', 'a1', 'a2', 'lwr', 'max_grid_size',
+                  'density', 'n_hull_corrected', 'n_smoothed']
+TABLE_FORMAT_VERSION = 1
+
+
+def save_tables(t, path):
+    """Write a PartTables to ``path`` (.npz).  Everything build_part_tables produced is kept, so a
+    loaded table is interchangeable with a freshly built one."""
+    import json
+    data = {k: np.asarray(getattr(t, k)) for k in _ARRAY_FIELDS}
+    meta = {k: (getattr(t, k) if not isinstance(getattr(t, k), np.generic) else getattr(t, k).item())
+            for k in _SCALAR_FIELDS}
+    meta.update(format_version=TABLE_FORMAT_VERSION, ranges=t.ranges, vertices_mutated=[int(v) for v in t.vertices_mutated])
+    data['meta'] = np.array(json.dumps(meta))
+    for key in ('anchor_points', 'all_points', 'edge_points'):
+        data[key] = np.asarray(getattr(t, key), dtype=np.float64).reshape(-1, 2, 3)
+    off, flat = [0], []
+    for lst in t.vertex_adj:
+        flat.extend(lst)
+        off.append(len(flat))
+    data['vertex_adj_off'] = np.asarray(off, dtype=np.int64)
+    data['vertex_adj_tri'] = np.asarray(flat, dtype=np.int64)
+    data['normals'] = np.asarray([[float(c) for c in n] for n in t._normals], dtype=np.float64)
+    np.savez_compressed(path, **data)
+
+
+def load_tables(path):
+    """Inverse of save_tables."""
+    import json
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    if meta.get('format_version') != TABLE_FORMAT_VERSION:
+        raise ValueError('%s: table format %r, this build reads %d' % (path, meta.get('format_version'),
+                                                                       TABLE_FORMAT_VERSION))
+    t = PartTables()
+    for k in _ARRAY_FIELDS:
+        setattr(t, k, z[k])
+    for k in _SCALAR_FIELDS:
+        setattr(t, k, meta[k])
+    t.ranges = [list(r) for r in meta['ranges']]
+    t.vertices_mutated = list(meta['vertices_mutated'])
+    for key in ('anchor_points', 'all_points', 'edge_points'):
+        t.__dict__[key] = [[list(map(float, p[0])), list(map(float, p[1]))] for p in z[key]]
+    off, flat = z['vertex_adj_off'], z['vertex_adj_tri']
+    t.vertex_adj = [[int(v) for v in flat[off[i]:off[i + 1]]] for i in range(len(off) - 1)]
+    t._normals = [tuple(row) for row in z['normals']]
+    return t

@@ -157,3 +157,25 @@ def test_oracle_envs_are_independent(door_tables):
         of, rf, df, _ = full.step(acts[k])
         oh, rh, dh, _ = half.step(acts[k][n // 2:])
         assert np.array_equal(of[n // 2:], oh) and np.array_equal(rf[n // 2:], rh) and np.array_equal(df[n // 2:], dh)
+
+
+def test_tables_round_trip_on_disk(tmp_path, door_tables):
+    """The on-disk table format reproduces every field the device layout and the oracle consume."""
+    from paintrl_amd import preprocess
+    path = str(tmp_path / 'door.npz')
+    part_tables.save_tables(door_tables, path)
+    t2 = part_tables.load_tables(path)
+    d1, d2 = DeviceTables(door_tables), DeviceTables(t2)
+    for name in ('sample_xyz', 'vertex_xyz', 'col'):
+        for a, b in zip(getattr(d1, name), getattr(d2, name)):
+            assert np.array_equal(a, b)
+    for name in ('word_bbox', 'word_valid', 'sgrid_start', 'vertex_adj', 'tri_records', 'col_bbox', 'col_rank',
+                 'start_pos', 'start_quat', 'obs_cell_mask', 'beams', 'grid_lo', 'grid_hi'):
+        assert np.array_equal(getattr(d1, name), getattr(d2, name)), name
+    assert part_tables.start_points(t2, 'all') == part_tables.start_points(door_tables, 'all')
+    assert part_tables.start_points(t2, 'edge') == part_tables.start_points(door_tables, 'edge')
+    # the command-line tool writes the same file for the synthetic sheet
+    out = str(tmp_path / 'sheet.npz')
+    assert preprocess.main(['--synthetic', 'square', out]) == 0
+    t3 = part_tables.load_tables(out)
+    assert np.array_equal(t3.sample_pos, synthetic_tables('square').sample_pos)
