@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--envs', type=int, default=ENVS_PER_GPU, help='envs per GPU (default: the BASELINE config)')
     ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
+    ap.add_argument('--policy', default='random', choices=['random', 'mlp'],
+                    help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -117,9 +119,19 @@ def main():
     env.reset()
     stream_sync = torch.cuda.synchronize
 
+    policy = None
+    if args.policy == 'mlp':
+        from paintrl_amd.rollout import MLPPolicy
+        torch.manual_seed(1234)
+        policy = MLPPolicy(env.obs_dim, 4).to(device)
+
     def run(k0, k1):
         for k in range(k0, k1):
-            env.step_raw(actions[k])
+            if policy is None:
+                env.step_raw(actions[k])
+            else:
+                act, _, _ = policy.act(env.obs.to(torch.float32), gen)
+                env.step_raw(act)
             if world > 1 and (k + 1) % FRAGMENT == 0:
                 pdist.gather_returns(env.episode_returns())
 
@@ -156,7 +168,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
-                                   'random discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs),
+                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, 'policy-MLP (6-256-128-4, fp32)' if args.policy == 'mlp' else 'random'),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},
