@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
     ap.add_argument('--policy', default='random', choices=['random', 'mlp'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4)")
+    ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -125,8 +126,26 @@ def main():
         torch.manual_seed(1234)
         policy = MLPPolicy(env.obs_dim, 4).to(device)
 
+    graph = None
+    if policy is not None and args.graph:
+        # policy forward + sampling + env step captured once; the launch-bound inner loop becomes a replay
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # warm the allocator and the kernels on the side stream
+                act, _, _ = policy.act(env.obs.to(torch.float32))
+                env.step_raw(act)
+        torch.cuda.current_stream(device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            act, _, _ = policy.act(env.obs.to(torch.float32))
+            env.step_raw(act)
+
     def run(k0, k1):
         for k in range(k0, k1):
+            if graph is not None:
+                graph.replay()
+                continue
             if policy is None:
                 env.step_raw(actions[k])
             else:
