@@ -311,8 +311,44 @@ __device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, cons
            (s.hi[2] >= b.x);
 }
 
+// The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
+// running count + number of passing lanes below), then the float64 test runs ONCE over the list
+// with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
+__device__ __forceinline__ void mt_candidates(const PartDev &P, const int *cand, int n, int lane, const double o[3],
+                                              double d0, double d1, double d2, double tmax, double &best_t,
+                                              int &best_r) {
+    if (lane < n) {
+        const int i = cand[lane];
+        const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
+        const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
+        const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
+        const int rk = P.col_rank[i];
+        const double p0 = d1 * e22 - d2 * e21;
+        const double p1 = d2 * e20 - d0 * e22;
+        const double p2 = d0 * e21 - d1 * e20;
+        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+        if (fabs(det) >= RAY_EPS_DET) {
+            const double inv = 1.0 / det;
+            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+            const double q0 = s1 * e12 - s2 * e11;
+            const double q1 = s2 * e10 - s0 * e12;
+            const double q2 = s0 * e11 - s1 * e10;
+            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= tmax &&
+                (t < best_t || (t == best_t && rk < best_r))) {
+                best_t = t;
+                best_r = rk;
+            }
+        }
+    }
+}
+
 __device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
                                 double hit[3]) {
+    __shared__ int s_cand[4][64];
+    int *cand = s_cand[threadIdx.x >> 6];
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
     const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
     const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
@@ -326,6 +362,7 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
 #endif
         const double tmax = stage == 0 ? 0.125 : 1.0;
         const SegBox sb = seg_box(o3, d3, tmax);
+        int n_cand = 0;
         for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
             const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
             uint64_t cm = __ballot(box_overlap(sb, ca, cb));       // table is padded to 64 with empty boxes
@@ -333,41 +370,25 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
                 const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
                 cm &= cm - 1;
                 const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
-#ifdef PRL_PHASE_COUNTERS
-                {
-                    const uint64_t mt_ = __ballot(box_overlap(sb, ba, bb));
-                    if (lane == 0) {
-                        atomicAdd(&g_phase_cycles[12], 1ull);
-                        atomicAdd(&g_phase_cycles[13], (unsigned long long)__popcll(mt_));
-                    }
+                const bool pass = box_overlap(sb, ba, bb);
+                const uint64_t pm = __ballot(pass);
+                if (pm == 0) continue;
+                const int np = __popcll(pm);
+                if (n_cand + np > 64) {                            // list full: test what is queued first
+                    __builtin_amdgcn_wave_barrier();
+                    mt_candidates(P, cand, n_cand, lane, o, d0, d1, d2, tmax, best_t, best_r);
+                    __builtin_amdgcn_wave_barrier();
+                    n_cand = 0;
                 }
-#endif
-                const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
-                const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
-                const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
-                const int rk = P.col_rank[i];
-                if (box_overlap(sb, ba, bb)) {
-                    const double p0 = d1 * e22 - d2 * e21;
-                    const double p1 = d2 * e20 - d0 * e22;
-                    const double p2 = d0 * e21 - d1 * e20;
-                    const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-                    if (fabs(det) >= RAY_EPS_DET) {
-                        const double inv = 1.0 / det;
-                        const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-                        const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-                        const double q0 = s1 * e12 - s2 * e11;
-                        const double q1 = s2 * e10 - s0 * e12;
-                        const double q2 = s0 * e11 - s1 * e10;
-                        const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-                        const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-                        if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 &&
-                            t <= tmax && (t < best_t || (t == best_t && rk < best_r))) {
-                            best_t = t;
-                            best_r = rk;
-                        }
-                    }
-                }
+                if (pass)
+                    cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
+                n_cand += np;
             }
+        }
+        if (n_cand) {
+            __builtin_amdgcn_wave_barrier();
+            mt_candidates(P, cand, n_cand, lane, o, d0, d1, d2, tmax, best_t, best_r);
+            __builtin_amdgcn_wave_barrier();
         }
         if (__ballot(best_t < INFINITY)) break;
     }
