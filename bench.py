@@ -59,7 +59,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(tables, steps_sample=25, n_envs=ENVS_PER_GPU):
+def cpu_baseline(tables, steps_sample=60, n_envs=ENVS_PER_GPU):
     """The C oracle (a scalar float64 port of the reference step()) on all host cores."""
     import numpy as np
     import oracle
