@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--envs', type=int, default=ENVS_PER_GPU, help='envs per GPU (default: the BASELINE config)')
     ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
+    ap.add_argument('--mixed', action='store_true', help='config 5: door/sheet alternate, START_POINT_MODE all')
     ap.add_argument('--policy', default='random', choices=['random', 'mlp'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4)")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
@@ -111,8 +112,17 @@ def main():
                                            name='door_test')
     dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, 'anchor'))
     overlap = args.obs_mode == 'grid'
-    env = BatchedPaintEnv(dt, args.envs, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
-                          overlap_penalty=overlap, seed=pdist.rank_seed(5678, rank), max_possible_point=9148)
+    if args.mixed:
+        sheet = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('square'), tex_size=(240, 240),
+                                              name='square')
+        dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, 'all'))
+        dts = DeviceTables(sheet, obs_grad=4, start_points=part_tables.start_points(sheet, 'all'))
+        env = BatchedPaintEnv([dt, dts], args.envs, env_part_id=np.arange(args.envs) % 2, device=device,
+                              obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
+                              seed=pdist.rank_seed(5678, rank), max_possible_point=[9148, 14350])
+    else:
+        env = BatchedPaintEnv(dt, args.envs, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
+                              overlap_penalty=overlap, seed=pdist.rank_seed(5678, rank), max_possible_point=9148)
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     total = args.steps + args.warmup

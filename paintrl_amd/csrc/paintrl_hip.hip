@@ -397,7 +397,10 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
         return -1;
     }
     const double tmin = wave_min_d(best_t);
-    const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);   // equal t: lowest reference index
+    const uint64_t tie = __ballot(best_t == tmin);
+    int rmin;
+    if ((tie & (tie - 1)) == 0) rmin = __builtin_amdgcn_readlane(best_r, rfl(__builtin_ctzll(tie)));
+    else rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
     t_out = tmin;
     hit[0] = o[0] + tmin * d0;
     hit[1] = o[1] + tmin * d1;

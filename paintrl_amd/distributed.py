@@ -26,6 +26,8 @@ def init_process_group(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)       # RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -165,3 +165,41 @@ def test_gpu_mixed_part_batch():
         assert np.array_equal(r[0::2], r1) and np.array_equal(r[1::2], r2)
         assert np.array_equal(d[0::2], d1) and np.array_equal(d[1::2], d2)
     env.close()
+
+
+def test_gpu_trimesh_collision_mode_matches_oracle():
+    """collision_mode='trimesh': rays against every mesh triangle (5 344 on the sheet -> 100+ chunks,
+    i.e. more than one 64-chunk pass of the two-level cull)."""
+    from paintrl_amd import part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('square'), tex_size=(240, 240),
+                                           name='square', collision_mode='trimesh')
+    assert tables.col_v0.shape[0] == tables.tri_side.shape[0]
+    sp = start_points_for(tables, 'all')
+    dt = DeviceTables(tables, start_points=sp)
+    assert dt.n_col_chunks > 64
+    n, steps = 96, 25
+    env = BatchedPaintEnv(dt, n, max_possible_point=14350)
+    orc = oracle.Oracle(tables, n, start_points=sp, max_possible_point=14350, threads=8)
+    rng = np.random.RandomState(21)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr), 'step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd)
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = dt.mask_to_canonical(words)
+    assert all(np.array_equal(bits[e], orc.painted_bits(e)) for e in range(n))
+    # the rayTestBatch drop-in agrees with numpy on this triangle soup too
+    from paintrl_amd import geometry as geo
+    o3 = np.stack([rng.uniform(-0.3, 0.2, 500), rng.uniform(-0.7, 0.5, 500), rng.uniform(0.2, 1.3, 500)], axis=1)
+    e3 = o3 + np.stack([-rng.uniform(0.1, 1.0, 500), rng.normal(0, 0.1, 500), rng.normal(0, 0.1, 500)], axis=1)
+    idx, t, pos = geo.ray_closest_hit(tables.col_v0, tables.col_e1, tables.col_e2, o3, e3)
+    gi, gt, gp = env.ray_test_batch(o3, e3)
+    hit = idx >= 0
+    assert hit.sum() > 50 and np.array_equal(gi.cpu().numpy(), idx) and np.array_equal(gt.cpu().numpy()[hit], t[hit])
+    env.close()
