@@ -178,6 +178,9 @@ def table_digest(drv):
     lo = np.array([part.grid_dict[F][i][0] for i in range(100)], dtype=np.float64)
     hi = np.array([part.grid_dict[F][i][1] for i in range(100)], dtype=np.float64)
     sp = np.array(drv.all_points, dtype=np.float64)
+    n_anchor = 4
+    edge = np.array(drv.all_points[:n_anchor] + part._get_edge_start_points(drv.all_points[n_anchor:]),
+                    dtype=np.float64)           # what get_start_points(mode='edge') returns (bpw:775-778)
     kd = np.asarray(part.vertices_kd_tree[F].data, dtype=np.float64)
     gp = drv.bpw.GridObservation(part, 4)._grid_pixels[F]
     cell = {}
@@ -195,7 +198,7 @@ def table_digest(drv):
                 beams=np.array(env.robot._paint_plain, dtype=np.float64),
                 n_start_all=np.int32(len(drv.all_points)), start_points_head=sp[:40], start_points_tail=sp[-40:],
                 sha_pix=sha(pix), sha_pos=sha(pos), sha_sides=sha(sides), sha_front_normals=sha(fn),
-                sha_start_points=sha(sp), sha_side_vertices=sha(kd), sha_cells4=sha(cells),
+                sha_start_points=sha(sp), sha_start_points_edge=sha(edge), n_start_edge=np.int32(edge.shape[0]), sha_side_vertices=sha(kd), sha_cells4=sha(cells),
                 pix_head=pix[:32], pix_tail=pix[-32:], pos_head=pos[:32], pos_tail=pos[-32:],
                 normals_head=fn[:32], normals_tail=fn[-32:], construct_s=np.float64(drv.construct_s))
 

@@ -39,6 +39,9 @@ def test_tables_match_reference_digests(tag, name):
     assert str(g['sha_cells4']) == sha(part_tables.grid_observation_cells(t, 4).astype(np.int32))
     sp = np.array(part_tables.start_points(t, 'all'), dtype=np.float64)
     assert int(g['n_start_all']) == sp.shape[0] and str(g['sha_start_points']) == sha(sp)
+    se = np.array(part_tables.start_points(t, 'edge'), dtype=np.float64)
+    assert int(g['n_start_edge']) == se.shape[0] and str(g['sha_start_points_edge']) == sha(se)
+    assert len(part_tables.start_points(t, 'anchor')) == 4 and len(part_tables.start_points(t, 'fixed')) == 1
     assert np.array_equal(g['pos_head'], t.sample_pos[:32]) and np.array_equal(g['normals_tail'], t.tri_normal[front][-32:])
     assert len(t.vertices_mutated) == 0        # synthetic parts never trigger the sparse-row mutation
 
