@@ -42,7 +42,7 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
     static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sample_rank.nbytes + dt.sgrid_start.nbytes
               + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
               + dt.vgrid_start.nbytes + dt.tri_records.nbytes
-              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
+              + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_nbr.nbytes + dt.col_orient.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
               + dt.start_pos.nbytes + dt.start_quat.nbytes)
     return per_env, static, per_env * n_envs + static
 

@@ -83,6 +83,12 @@ typedef struct {
     const double *col_v0e1e2[9];     /* v0.xyz e1.xyz e2.xyz, [n_collision_pad] each */
     const float *col_bbox;           /* [n_collision_pad][8] outward-rounded box: lo,hi on axis1, axis2, axis0, 2 pad */
     const int32_t *col_rank;         /* [n_collision_pad] index in the reference (tie-break) order */
+    int32_t col_convex;              /* 1: the set is the boundary of a convex polytope (hull mode): enables the
+                                        neighbourhood-first ray path */
+    int32_t nbr_width;               /* <= 64 */
+    const int32_t *col_nbr;          /* [n_collision_pad][nbr_width] facets sharing a vertex, itself first, -1 = pad;
+                                        a row of -1 disables the fast path for that facet */
+    const int32_t *col_orient;       /* [n_collision_pad] +1/-1: orient * det > 0 <=> the segment enters through it */
     int32_t n_col_chunks;            /* n_collision_pad / 64 */
     const float *col_chunk_bbox;     /* [n_col_chunks padded to 64][8] union box of each 64-triangle chunk */
     /* grid rows (bpw grid_dict), extents, axes */

@@ -29,6 +29,7 @@ class PrlPartTables(C.Structure):
         ('vgrid_nx', C.c_int32), ('vgrid_ny', C.c_int32), ('vgrid_start', _ip),
         ('n_triangles', C.c_int32), ('tri_records', _dp),
         ('n_collision', C.c_int32), ('n_collision_pad', C.c_int32), ('col_v0e1e2', _dp * 9), ('col_bbox', _fp), ('col_rank', _ip),
+        ('col_convex', C.c_int32), ('nbr_width', C.c_int32), ('col_nbr', _ip), ('col_orient', _ip),
         ('n_col_chunks', C.c_int32), ('col_chunk_bbox', _fp),
         ('grid_lo', _dp), ('grid_hi', _dp),
         ('range1', C.c_double * 2), ('range2', C.c_double * 2), ('length_width_ratio', C.c_double),

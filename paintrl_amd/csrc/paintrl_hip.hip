@@ -85,6 +85,8 @@ struct PartDev {
     gdouble_p col[9];
     gfloat_p col_bbox;
     gint_p col_rank;
+    int col_convex, nbr_width;
+    gint_p col_nbr, col_orient;
     int n_col_chunks;
     gfloat_p col_chunk_bbox;
     gdouble_p grid_lo, grid_hi;
@@ -314,11 +316,11 @@ __device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, cons
 // The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
 // running count + number of passing lanes below), then the float64 test runs ONCE over the list
 // with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
-__device__ __forceinline__ void mt_candidates(const PartDev &P, const int *cand, int n, int lane, const double o[3],
-                                              double d0, double d1, double d2, double tmax, double &best_t,
-                                              int &best_r) {
-    if (lane < n) {
-        const int i = cand[lane];
+// One float64 Moller-Trumbore test per lane (triangle i, or none if i < 0); keeps the lane's best
+// (t, reference rank) and remembers which triangle and which determinant produced it.
+__device__ __forceinline__ void mt_one(const PartDev &P, int i, const double o[3], double d0, double d1, double d2,
+                                       double tmax, double &best_t, int &best_r, int &best_i, double &best_det) {
+    if (i >= 0) {
         const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
         const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
         const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
@@ -340,72 +342,117 @@ __device__ __forceinline__ void mt_candidates(const PartDev &P, const int *cand,
                 (t < best_t || (t == best_t && rk < best_r))) {
                 best_t = t;
                 best_r = rk;
+                best_i = i;
+                best_det = det;
             }
         }
     }
 }
 
+// Lane holding the wave's best (t, rank); -1 if no lane has a hit.
+__device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
+    if (__ballot(best_t < INFINITY) == 0) return -1;
+    tmin = wave_min_d(best_t);
+    const uint64_t tie = __ballot(best_t == tmin);
+    if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
+    const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
+    return __builtin_ctzll(__ballot(best_t == tmin && best_r == rmin));
+}
+
+// `hint` (in/out): collision-set position of the facet hit by the previous ray of this env, or -1.
+//
+// Convex fast path (collision set = boundary of a convex polytope, i.e. hull mode): a segment that
+// starts outside enters the polytope at one point, so every facet with a valid hit at or before the
+// entry parameter contains that point and therefore shares a vertex with any one of them.  If the
+// vertex-neighbourhood of `hint` holds a valid hit whose facet is ENTERED (orient * det > 0), the
+// closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
+// hit there, an exit hit, a facet without a neighbour list) takes the general search below.
 __device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
-                                double hit[3]) {
+                                double hit[3], int &hint) {
     __shared__ int s_cand[4][64];
     int *cand = s_cand[threadIdx.x >> 6];
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
-    const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
-    const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
-    double best_t = INFINITY;
-    int best_r = 0x7fffffff;
-    const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
-    const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
-    for (int stage = 0; stage < 2; ++stage) {
-#ifdef PRL_PHASE_COUNTERS
-        if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
-#endif
-        const double tmax = stage == 0 ? 0.125 : 1.0;
-        const SegBox sb = seg_box(o3, d3, tmax);
-        int n_cand = 0;
-        for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
-            const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
-            uint64_t cm = __ballot(box_overlap(sb, ca, cb));       // table is padded to 64 with empty boxes
-            while (cm) {
-                const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
-                cm &= cm - 1;
-                const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
-                const bool pass = box_overlap(sb, ba, bb);
-                const uint64_t pm = __ballot(pass);
-                if (pm == 0) continue;
-                const int np = __popcll(pm);
-                if (n_cand + np > 64) {                            // list full: test what is queued first
-                    __builtin_amdgcn_wave_barrier();
-                    mt_candidates(P, cand, n_cand, lane, o, d0, d1, d2, tmax, best_t, best_r);
-                    __builtin_amdgcn_wave_barrier();
-                    n_cand = 0;
+    double best_t = INFINITY, best_det = 0, tmin = INFINITY;
+    int best_r = 0x7fffffff, best_i = -1, win = -1;
+    if (P.col_convex && hint >= 0) {
+        const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
+        mt_one(P, i1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
+        win = ray_winner_lane(best_t, best_r, tmin);
+        if (win >= 0) {
+            const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
+            const double fdet = bcast_d(best_det, win);
+            const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
+            const bool entering = (double)P.col_orient[f] * fdet > 0;
+            if (entering && __ballot(i2 >= 0) != 0) {
+                if (f != hint) {
+                    mt_one(P, i2, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
+                    win = ray_winner_lane(best_t, best_r, tmin);
                 }
-                if (pass)
-                    cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
-                n_cand += np;
+            } else {
+                win = -1;
             }
         }
-        if (n_cand) {
-            __builtin_amdgcn_wave_barrier();
-            mt_candidates(P, cand, n_cand, lane, o, d0, d1, d2, tmax, best_t, best_r);
-            __builtin_amdgcn_wave_barrier();
+        if (win < 0) {
+            best_t = INFINITY;
+            best_r = 0x7fffffff;
+            best_i = -1;
         }
-        if (__ballot(best_t < INFINITY)) break;
     }
-    if (__ballot(best_t < INFINITY) == 0) {
+    if (win < 0) {
+        const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
+        const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
+        const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
+        const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
+        for (int stage = 0; stage < 2; ++stage) {
+#ifdef PRL_PHASE_COUNTERS
+            if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
+#endif
+            const double tmax = stage == 0 ? 0.125 : 1.0;
+            const SegBox sb = seg_box(o3, d3, tmax);
+            int n_cand = 0;
+            for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
+                const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
+                uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
+                while (cm) {
+                    const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+                    cm &= cm - 1;
+                    const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
+                    const bool pass = box_overlap(sb, ba, bb);
+                    const uint64_t pm = __ballot(pass);
+                    if (pm == 0) continue;
+                    const int np = __popcll(pm);
+                    if (n_cand + np > 64) {                        // list full: test what is queued first
+                        __builtin_amdgcn_wave_barrier();
+                        mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
+                        __builtin_amdgcn_wave_barrier();
+                        n_cand = 0;
+                    }
+                    if (pass)
+                        cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
+                    n_cand += np;
+                }
+            }
+            if (n_cand) {
+                __builtin_amdgcn_wave_barrier();
+                mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (__ballot(best_t < INFINITY)) break;
+        }
+        win = ray_winner_lane(best_t, best_r, tmin);
+    }
+    if (win < 0) {
         t_out = INFINITY;
+        hint = -1;
         return -1;
     }
-    const double tmin = wave_min_d(best_t);
-    const uint64_t tie = __ballot(best_t == tmin);
-    int rmin;
-    if ((tie & (tie - 1)) == 0) rmin = __builtin_amdgcn_readlane(best_r, rfl(__builtin_ctzll(tie)));
-    else rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
+    hint = __builtin_amdgcn_readlane(best_i, rfl(win));
     t_out = tmin;
     hit[0] = o[0] + tmin * d0;
     hit[1] = o[1] + tmin * d1;
     hit[2] = o[2] + tmin * d2;
-    return rmin;
+    return __builtin_amdgcn_readlane(best_r, rfl(win));
 }
 
 // ---------------------------------------------------------------- bpw:526 nearest same-side vertex
@@ -1182,6 +1229,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) cur_norm[k] = uni_d(cur_norm[k]);
     const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
+    int facet_hint = -1;                        // facet hit by the previous sub-shot's ray (convex fast path)
     uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
     uint32_t n_succeeded_l = 0;
     __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
@@ -1202,7 +1250,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         hit[1] = pt[1] + 0.1 * cur_norm[1];
         hit[2] = pt[2] + 0.1 * cur_norm[2];
 #else
-        bool on = ray_closest_wave(P, pt, end, lane, t, hit) >= 0;
+        bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint) >= 0;
 #endif
         STAMP(PH_RAY);
         if (on) on = hook_point_wave(P, hit, lane, pos, orn PROF_PASS);
@@ -1252,7 +1300,8 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             for (int bm = 0; bm < P.n_beams; ++bm) {
                 double dst[3], bt, bh[3];
                 transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
-                if (ray_closest_wave(P, pos, dst, lane, bt, bh) < 0) continue;
+                int beam_hint = -1;
+                if (ray_closest_wave(P, pos, dst, lane, bt, bh, beam_hint) < 0) continue;
                 ++beam_hits;
                 const int sidx = nearest_sample_wave(P, bh, lane);
                 if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
@@ -1391,7 +1440,8 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int
     const double o[3] = {from[3 * r], from[3 * r + 1], from[3 * r + 2]};
     const double e[3] = {to[3 * r], to[3 * r + 1], to[3 * r + 2]};
     double t, hit[3] = {0, 0, 0};
-    const int idx = ray_closest_wave(*part, o, e, lane, t, hit);
+    int hint = -1;
+    const int idx = ray_closest_wave(*part, o, e, lane, t, hit, hint);
     if (lane == 0) {
         tri[r] = idx;
         frac[r] = t;
@@ -1530,6 +1580,15 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     for (int k = 0; k < 9; ++k) UP(col[k], t->col_v0e1e2[k], d.n_col_pad);
     UP(col_bbox, t->col_bbox, (size_t)d.n_col_pad * 8);
     UP(col_rank, t->col_rank, d.n_col_pad);
+    d.col_convex = t->col_convex ? 1 : 0;
+    d.nbr_width = t->nbr_width;
+    if (d.col_convex) {
+        if (d.nbr_width < 1 || d.nbr_width > 64) return fail(PRL_E_INVALID, "nbr_width must be 1..64");
+        for (size_t k = 0; k < (size_t)d.n_col_pad * d.nbr_width; ++k)
+            if (t->col_nbr[k] < -1 || t->col_nbr[k] >= d.n_col_pad) return fail(PRL_E_INVALID, "col_nbr entry out of range");
+        UP(col_nbr, t->col_nbr, (size_t)d.n_col_pad * d.nbr_width);
+        UP(col_orient, t->col_orient, d.n_col_pad);
+    }
     d.n_col_chunks = t->n_col_chunks;
     if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
     UP(col_chunk_bbox, t->col_chunk_bbox, (size_t)((d.n_col_chunks + 63) / 64) * 64 * 8);

@@ -14,6 +14,7 @@ from . import _lib
 from . import part_tables as pt
 
 CELL = 0.052             # > PAINT_RADIUS, so a ball overlaps at most 3x3 cells
+NBR_WIDTH = 32           # facets sharing a vertex with a hull facet, itself included (door: <= 26)
 FAR = 1.0e15             # coordinate of padding samples
 
 
@@ -179,6 +180,37 @@ class DeviceTables(object):
         chunk[:, 6], chunk[:, 7] = 0.0, 0.0
         self.col_chunk_bbox, self.n_col_chunks = chunk, n_chunks
         self.n_collision, self.n_collision_pad = C0, c_pad
+        # convex-hull fast path: per facet, the facets sharing a vertex with it (itself first) and the
+        # sign that makes `orient * det > 0` mean "the segment enters the hull through this facet"
+        self.nbr_width = NBR_WIDTH
+        self.col_nbr = -np.ones((c_pad, NBR_WIDTH), dtype=np.int32)
+        self.col_orient = np.zeros(c_pad, dtype=np.int32)
+        self.col_convex = 0
+        if t.collision_mode == 'hull':
+            dev_of = -np.ones(C0, dtype=np.int64)
+            dev_of[corder] = np.nonzero(real)[0]
+            flat = corners.reshape(-1, 3)
+            _, vid = np.unique(flat, axis=0, return_inverse=True)
+            tri_v = vid.reshape(C0, 3)
+            by_vertex = {}
+            for ti, vs in enumerate(tri_v):
+                for v in vs:
+                    by_vertex.setdefault(int(v), []).append(ti)
+            centroid = flat.mean(axis=0)
+            ok = True
+            for ti in range(C0):
+                nb = sorted(set(by_vertex[int(tri_v[ti, 0])]) | set(by_vertex[int(tri_v[ti, 1])]) |
+                            set(by_vertex[int(tri_v[ti, 2])]))
+                nb.remove(ti)
+                if len(nb) + 1 > NBR_WIDTH:
+                    ok = False
+                    continue                       # no list: the kernel falls back to the full search here
+                self.col_nbr[dev_of[ti], 0] = dev_of[ti]
+                self.col_nbr[dev_of[ti], 1:1 + len(nb)] = dev_of[nb]
+            outward = np.einsum('ij,ij->i', nrm, cen - centroid[None, :])
+            self.col_orient[dev_of] = np.where(outward > 0, 1, -1)
+            self.col_convex = 1
+            self.col_nbr_complete = ok
         # ---- rows, start points, beams
         self.grid_lo = np.ascontiguousarray(t.grid_lo, dtype=np.float64)
         self.grid_hi = np.ascontiguousarray(t.grid_hi, dtype=np.float64)
@@ -226,6 +258,8 @@ class DeviceTables(object):
             s.col_v0e1e2[k] = dp(self.col[k])
         s.col_bbox = self.col_bbox.ctypes.data_as(_lib._fp)
         s.col_rank = ip(self.col_rank)
+        s.col_convex, s.nbr_width = self.col_convex, self.nbr_width
+        s.col_nbr, s.col_orient = ip(self.col_nbr), ip(self.col_orient)
         s.n_col_chunks = self.n_col_chunks
         s.col_chunk_bbox = self.col_chunk_bbox.ctypes.data_as(_lib._fp)
         s.grid_lo, s.grid_hi = dp(self.grid_lo), dp(self.grid_hi)
