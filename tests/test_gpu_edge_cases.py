@@ -167,3 +167,27 @@ def test_full_size_round_trip_properties():
     assert np.array_equal(env.painted_words().cpu().numpy(), env2.painted_words().cpu().numpy())
     env.close()
     env2.close()
+
+
+def test_full_size_batch_equals_oracle():
+    """The BASELINE batch (4096 envs, 'all' start points) against the oracle for a few steps: every
+    observation, reward, done flag and painted bit."""
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n, steps = 4096, 4
+    env = _env(tables, n, sp)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8)
+    rng = np.random.RandomState(77)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr), 'step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd) and np.array_equal(i.cpu().numpy(), ii)
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = env.parts[0].mask_to_canonical(words)
+    want = np.stack([orc.painted_bits(e) for e in range(n)])
+    assert np.array_equal(bits, want)
+    env.close()
