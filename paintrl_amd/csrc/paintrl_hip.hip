@@ -62,6 +62,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 struct PartDev {
     int n_samples, n_samples_pad, n_words;
     gdouble_p samp[3];
+    gdouble_p samp_a1, samp_a2;   // = samp[a1], samp[a2]: a dynamic index into samp[] would be a memory load of the pointer
     gdouble_p word_bbox;
     gu64_p word_valid;
     gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
@@ -887,7 +888,7 @@ __device__ __forceinline__ double py_floor_div(double vx, double wx) {
 template <int KW>
 __device__ void section_general_wave(const PartDev &P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
                                      int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
-    gdouble_p sx = P.samp[P.a1], sy = P.samp[P.a2];
+    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     cnt[lane] = 0;
     cnt[64 + lane] = 0;
     const double two_pi = 2 * PI, basis = two_pi / g;
@@ -978,7 +979,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
         return;
     } else {
     // section / discrete, 4-sector rule bpw:1034-1043
-    gdouble_p sx = P.samp[P.a1], sy = P.samp[P.a2];
+    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane
     uint32_t tot_u[4] = {0, 0, 0, 0}, und_u[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1605,6 +1606,8 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (d.a0 < 0 || d.a0 > 2 || d.a1 < 0 || d.a1 > 2 || d.a2 < 0 || d.a2 > 2 || d.a0 == d.a1 || d.a1 == d.a2 ||
         d.a0 == d.a2)
         return fail(PRL_E_INVALID, "axes must be a permutation of 0,1,2");
+    d.samp_a1 = d.samp[d.a1];
+    d.samp_a2 = d.samp[d.a2];
     d.n_start = t->n_start;
     if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
     UP(start_pos, t->start_pos, (size_t)d.n_start * 3);

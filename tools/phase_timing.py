@@ -12,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from paintrl_amd import build as hb  # noqa: E402
 
-NAMES = ['load', 'ray', 'vertex', 'bary', 'math', 'ball', 'apply', 'obs', 'store']
+NAMES = ['load', 'ray', 'vertex', 'bary', 'math', 'ball', 'apply', 'obs-rest', 'store', 'obs-classify', 'obs-straddle', 'obs-reduce']
 
 
 def main():
@@ -60,7 +60,7 @@ def main():
     print('cycles per env-step (wave lifetime, stamped build): %.0f' % per_wave)
     print('rays %d, second-stage rays %d (%.1f %%), chunks visited per ray %.2f, MT evaluations per ray %.2f' % (buf[10], buf[11], 100.0 * buf[11] / max(buf[10], 1), buf[12] / max(buf[10], 1), buf[13] / max(buf[10], 1)))
     for name, v in zip(NAMES, buf):
-        print('  %-7s %6.1f %%  %8.0f cyc/env-step' % (name, 100.0 * v / tot, v / (300 * n)))
+        print('  %-13s %6.1f %%  %8.0f cyc/env-step' % (name, 100.0 * v / tot, v / (300 * n)))
 
 
 if __name__ == '__main__':
