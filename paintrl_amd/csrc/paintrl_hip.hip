@@ -980,8 +980,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
     } else {
     // section / discrete, 4-sector rule bpw:1034-1043
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane
-    uint32_t tot_u[4] = {0, 0, 0, 0}, und_u[4] = {0, 0, 0, 0};
+    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * k;
@@ -1023,20 +1022,14 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!use[j]) continue;
+                // one sample per lane: classify it and add into the lane's packed 16-bit counters
                 const uint64_t pw = bcast_u64(painted[k], L[j]);
-                const uint64_t m0 = __ballot(xs[j] > x1 && ys[j] > x2) & vs[j];
-                const uint64_t m1 = __ballot(xs[j] < x1 && ys[j] > x2) & vs[j];
-                const uint64_t m2 = __ballot(xs[j] < x1 && ys[j] < x2) & vs[j];
-                const uint64_t skip = __ballot(xs[j] == x1 && ys[j] == x2);
-                const uint64_t m3 = vs[j] & ~(m0 | m1 | m2 | skip);
-                tot_u[0] += __popcll(m0);
-                tot_u[1] += __popcll(m1);
-                tot_u[2] += __popcll(m2);
-                tot_u[3] += __popcll(m3);
-                und_u[0] += __popcll(m0 & ~pw);
-                und_u[1] += __popcll(m1 & ~pw);
-                und_u[2] += __popcll(m2 & ~pw);
-                und_u[3] += __popcll(m3 & ~pw);
+                const bool cnt = ((vs[j] >> lane) & 1) && !(xs[j] == x1 && ys[j] == x2);
+                const bool gy = ys[j] > x2, lx = xs[j] < x1;
+                const int sh = (xs[j] > x1 && gy) ? 0 : ((lx && gy) ? 16 : ((lx && ys[j] < x2) ? 32 : 48));
+                const uint64_t one = cnt ? ((uint64_t)1 << sh) : 0;
+                tot_l += one;
+                und_l += ((pw >> lane) & 1) ? 0 : one;
             }
         }
     }
@@ -1044,8 +1037,8 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
     und_l = wave_sum_u64(und_l);
     if (lane == 0) {
         for (int q = 0; q < 4; ++q) {
-            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff) + tot_u[q];
-            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff) + und_u[q];
+            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
+            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
             out[q] = t == 0 ? 0.0 : (double)u / (double)t;
         }
         if (mode == PRL_OBS_SECTION) {
