@@ -153,6 +153,11 @@ int prl_batch_reset(PrlBatch *batch, const uint8_t *reset_mask, const int32_t *s
 int prl_batch_step(PrlBatch *batch, const void *actions, double *obs, double *reward, uint8_t *done, double *info,
                    double *final_obs, const int32_t *start_idx, void *stream);
 
+/* Replaces Robot.reset(pose) (rob:366-372, used by spiral.py:38): place env `env_index` at `pos` with tool
+ * quaternion `quat` (host pointers, xyzw) and clear its off-part bookkeeping (rob:208-212).  Coverage,
+ * step counter and reward accumulators are left as they are, like the reference.  Synchronous. */
+int prl_batch_set_pose(PrlBatch *batch, int env_index, const double *pos, const double *quat);
+
 /* Replaces get_job_status / get_texture_image style read-back (bpw:727-738): coverage bits in
  * device sample order, u64[N][mask_stride]. */
 int prl_batch_get_mask(PrlBatch *batch, uint64_t *painted, void *stream);

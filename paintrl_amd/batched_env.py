@@ -139,6 +139,13 @@ class BatchedPaintEnv(object):
     def vector_step(self, actions):
         return self.step(actions)
 
+    def set_pose(self, index, pose, orn):
+        """Robot.reset([pose, orn]) (rob:366-372) for one env: move the tool, clear off-part bookkeeping."""
+        from .part_tables import pose_orn_quaternion
+        pos = (C.c_double * 3)(*[float(v) for v in pose])
+        quat = (C.c_double * 4)(*pose_orn_quaternion([float(v) for v in orn]))
+        _lib.check(self.lib.prl_batch_set_pose(self._batch, int(index), pos, quat), 'prl_batch_set_pose')
+
     # ------------------------------------------------------------------ read-back
     def painted_words(self):
         """int64 tensor (N, mask_stride) holding the u64 coverage words in device sample order."""

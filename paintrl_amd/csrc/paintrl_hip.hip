@@ -1838,6 +1838,23 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     return PRL_OK;
 }
 
+int prl_batch_set_pose(PrlBatch *b, int env_index, const double *pos, const double *quat) {
+    if (!b || !pos || !quat || env_index < 0 || env_index >= b->n_envs) return fail(PRL_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    EnvState S;
+    double *rec = b->state + (size_t)env_index * PRL_STATE_DOUBLES;
+    HIP_TRY(hipMemcpy(&S, rec, sizeof S, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) S.pose[k] = pos[k];
+    for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];
+    S.terminate = 0;
+    S.terminate_counter = 0;
+    S.last_on_part = 1;
+    S.last_angle = 0;
+    HIP_TRY(hipMemcpy(rec, &S, sizeof S, hipMemcpyHostToDevice));
+    return PRL_OK;
+}
+
 int prl_batch_get_mask(PrlBatch *b, uint64_t *painted, void *stream) {
     if (!b || !painted) return fail(PRL_E_INVALID, "null argument");
     const size_t n = (size_t)b->n_envs * b->mask_stride;

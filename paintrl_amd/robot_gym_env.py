@@ -38,6 +38,10 @@ class _RobotView(object):
     def __init__(self, env):
         self._env = env
 
+    def reset(self, pose):
+        """Robot.reset([pose, orn_normal]) (rob:366-372), as spiral.py:38 uses it."""
+        self._env._batch.set_pose(0, pose[0], pose[1])
+
     def get_angle_diff(self):
         raise NotImplementedError('angle_diff is consumed inside the step kernel (TURNING_PENALTY)')
 

@@ -58,6 +58,42 @@ def test_gym_env_training_reset_follows_python_random(urdf_root):
     env.close()
 
 
+def test_robot_reset_places_the_tool_like_spiral_py(urdf_root):
+    """spiral.py:28-38: start from the centre of the anchor points via env.robot.reset([pose, orn])."""
+    import ctypes as C
+    import oracle
+    from conftest import synthetic_tables
+    from paintrl_amd import PaintGymEnv
+    from paintrl_amd.part_tables import pose_orn_quaternion
+    PaintGymEnv.change_action_mode(1, 'discrete', 4)
+    PaintGymEnv.change_obs_mode('simple', 4)
+    cfg = dict(PaintGymEnv.EXTRA_CONFIG, Part_NO=1, START_POINT_MODE='anchor')
+    env = PaintGymEnv(urdf_root, with_robot=False, rollout=True, extra_config=cfg)
+    sp = env._start_points
+    a1 = [p[0][1] for p in sp]
+    a2 = [p[0][2] for p in sp]
+    centre = [[sp[0][0][0], min(a1) + (max(a1) - min(a1)) / 2, min(a2) + (max(a2) - min(a2)) / 2], sp[0][1]]
+    env.robot.reset(centre)
+    tables = synthetic_tables('square')
+    orc = oracle.Oracle(tables, 1, obs_mode='simple', max_possible_point=14350, start_points=sp)
+    orc.reset([0])
+    orc.env[0].pose = (C.c_double * 3)(*centre[0])
+    orc.env[0].quat = (C.c_double * 4)(*pose_orn_quaternion(centre[1]))
+    direction, strait, cur = 0, 1, 1
+    for k in range(40):                                    # the outward spiral of spiral.py:44-52
+        cur -= 1
+        obs, r, done, _ = env.step(direction % 4)
+        oo, rr, dd, _ = orc.step([direction % 4])
+        assert np.array_equal(obs, oo[0]) and r == rr[0] and done == bool(dd[0])
+        if cur == 0:
+            strait += 1
+            direction += 1
+            cur = strait
+    assert env.get_job_status() > 1500
+    env.close()
+    PaintGymEnv.change_obs_mode('section', 4)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from paintrl_amd import _lib, build
     monkeypatch.setattr(_lib, '_lib', None)
