@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, 'csrc', 'paintrl_hip.hip')
 HEADER = os.path.join(_REPO, 'include', 'paintrl.h')
-LIBRARY = os.path.join(_HERE, 'libpaintrl_hip.so')
+# PAINTRL_LIB points the binding at another build of the same source (diagnostic builds of tools/)
+LIBRARY = os.environ.get('PAINTRL_LIB') or os.path.join(_HERE, 'libpaintrl_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17']
 
 

@@ -375,6 +375,9 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
     double best_t = INFINITY, best_det = 0, tmin = INFINITY;
     int best_r = 0x7fffffff, best_i = -1, win = -1;
+#ifdef PRL_FORCE_GENERAL_RAY                         // diagnostic build: never take the convex fast path
+    hint = -1;
+#endif
     if (P.col_convex && hint >= 0) {
         const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
         mt_one(P, i1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
@@ -568,6 +571,9 @@ __device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lan
         const double lim = ring * P.vg_accept;          // ring * 0.99 * cell
         exact = dmin <= lim * lim;
     }
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: exercise the whole-table scans
+    exact = false;
+#endif
     if (!exact) {
         best_d = INFINITY;
         best_rank = 0x7fffffff;
@@ -623,6 +629,9 @@ __device__ int nearest_sample_wave(const PartDev &P, const double pt[3], int lan
         const double lim = ring * P.vg_accept;
         exact = dmin <= lim * lim;
     }
+#ifdef PRL_FORCE_FULL_SCANS
+    exact = false;
+#endif
     if (!exact) {                                   // far from every sample: scan the whole table
         best_d = INFINITY;
         best_rank = 0x7fffffff;
@@ -791,6 +800,9 @@ __device__ bool paint_shots_union(const PartDev &P, const double *cen_lds, int l
         cy_lo = icy < cy_lo ? icy : cy_lo;
         cy_hi = icy > cy_hi ? icy : cy_hi;
     }
+#ifdef PRL_FORCE_PER_SHOT_PAINT                     // diagnostic build: exercise the general path in the parity tests
+    return false;
+#endif
     if (cy_hi - cy_lo > 1) return false;            // centres spread over > 2 cell rows: caller paints shot by shot
     // rows cy_lo-1 .. cy_hi+1 (<= 4), columns cx_lo-1 .. cx_hi+1: lanes 0..7 fetch the range bounds
     const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
