@@ -29,6 +29,7 @@ sys.path.insert(0, REPO)
 
 ENVS_PER_GPU = 4096
 FRAGMENT = 100                  # rollout fragment length (paint_ppo.py:190 sample_batch_size)
+TIMING_EVERY = 8                # HIP events around every 8th step launch (kernel time for the roofline)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -168,7 +169,7 @@ def main():
     stream_sync()
     pdist.barrier()
     stream_sync()
-    env.timing(True)
+    env.timing(TIMING_EVERY)
     t0 = time.perf_counter()
     run(args.warmup, total)
     stream_sync()
@@ -176,7 +177,7 @@ def main():
     stream_sync()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = env.timing_read()
-    env.timing(False)
+    env.timing(0)
     elapsed = pdist.max_over_ranks(elapsed, device)
 
     st = env.state()

@@ -173,9 +173,11 @@ int prl_batch_get_returns(PrlBatch *batch, double *episode_return, void *stream)
 int prl_ray_batch(PrlPart *part, int n, const double *from, const double *to, int32_t *tri, double *frac,
                   double *pos, void *stream);
 
-/* Wall-clock-free kernel timing for bench.py: HIP events recorded around every step launch on its stream. */
-int prl_batch_timing_enable(PrlBatch *batch, int enable);
-int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);   /* synchronises; resets counters */
+/* Kernel timing for bench.py: HIP events recorded on the launch stream around every `every`-th step launch
+ * (0 = off, 1 = every launch).  prl_batch_timing_read synchronises, returns the summed duration and the
+ * number of launches that were timed, and resets the counters. */
+int prl_batch_timing_enable(PrlBatch *batch, int every);
+int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

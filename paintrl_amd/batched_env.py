@@ -199,8 +199,9 @@ class BatchedPaintEnv(object):
                                               self._ptr(frac), self._ptr(pos), self._stream()), 'prl_ray_batch')
         return tri, frac, pos
 
-    def timing(self, enable):
-        _lib.check(self.lib.prl_batch_timing_enable(self._batch, int(bool(enable))), 'prl_batch_timing_enable')
+    def timing(self, every):
+        """HIP-event timing of the step kernel around every ``every``-th launch (0/False = off, 1/True = all)."""
+        _lib.check(self.lib.prl_batch_timing_enable(self._batch, int(every)), 'prl_batch_timing_enable')
 
     def timing_read(self):
         ms, n = C.c_double(0), C.c_int64(0)

@@ -1504,7 +1504,8 @@ struct PrlBatch {
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
     double *state = nullptr;
-    bool timing = false;
+    int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
+    long long launch_no = 0;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used = 0;
 };
@@ -1826,7 +1827,8 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     a.start_idx = start_idx;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL;
-    if (b->timing) {
+    const bool timed = b->timing_every > 0 && (b->launch_no++ % b->timing_every) == 0;
+    if (timed) {
         if (b->ev_used == b->ev_start.size()) {
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreate(&e0));
@@ -1843,7 +1845,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     default: launch_step<4>(a, normal, general_section(b->cfg), s); break;
     }
     HIP_TRY(hipGetLastError());
-    if (b->timing) {
+    if (timed) {
         HIP_TRY(hipEventRecord(b->ev_stop[b->ev_used], s));
         b->ev_used += 1;
     }
@@ -1915,7 +1917,8 @@ int prl_debug_phase_cycles(unsigned long long *out, int n) {
 
 int prl_batch_timing_enable(PrlBatch *b, int enable) {
     if (!b) return fail(PRL_E_INVALID, "null batch");
-    b->timing = enable != 0;
+    b->timing_every = enable < 0 ? 0 : enable;
+    b->launch_no = 0;
     b->ev_used = 0;
     return PRL_OK;
 }
