@@ -1531,6 +1531,14 @@ int upload(PrlPart *p, const T *host, size_t count, const T GAS **out) {
         if (rc_) return rc_;                                          \
     } while (0)
 
+// grid-cell start tables index the sorted arrays: a malformed one would send device loads out of bounds
+bool monotone_starts(const int32_t *start, size_t n, int limit) {
+    if (!start || n == 0 || start[0] < 0) return false;
+    for (size_t k = 1; k < n; ++k)
+        if (start[k] < start[k - 1]) return false;
+    return start[n - 1] <= limit;
+}
+
 int part_fill(PrlPart *p, const PrlPartTables *t) {
     PartDev &d = p->dev;
     if (t->n_samples <= 0 || t->n_samples_pad % 64 || t->n_samples_pad < t->n_samples)
@@ -1552,7 +1560,8 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     d.sg_ny = t->sgrid_ny;
     if (d.sg_nx <= 0 || d.sg_ny <= 0) return fail(PRL_E_INVALID, "empty sample grid");
     UP(sg_start, t->sgrid_start, (size_t)d.sg_nx * d.sg_ny + 1);
-    if (t->sgrid_start[(size_t)d.sg_nx * d.sg_ny] > t->n_samples_pad) return fail(PRL_E_INVALID, "sample grid overruns");
+    if (!monotone_starts(t->sgrid_start, (size_t)d.sg_nx * d.sg_ny + 1, t->n_samples_pad))
+        return fail(PRL_E_INVALID, "sample grid starts must be non-decreasing and within the padded sample count");
     d.n_obs_cells = t->n_obs_cells;
     if (d.n_obs_cells > 0) {
         UP(cell_mask, t->obs_cell_mask, (size_t)d.n_obs_cells * d.n_words);
@@ -1579,7 +1588,9 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     d.vg_ny = t->vgrid_ny;
     if (d.vg_nx <= 0 || d.vg_ny <= 0) return fail(PRL_E_INVALID, "empty vertex grid");
     UP(vg_start, t->vgrid_start, (size_t)d.vg_nx * d.vg_ny + 1);
-    if (t->vgrid_start[(size_t)d.vg_nx * d.vg_ny] != d.n_vertices) return fail(PRL_E_INVALID, "vertex grid mismatch");
+    if (!monotone_starts(t->vgrid_start, (size_t)d.vg_nx * d.vg_ny + 1, d.n_vertices) ||
+        t->vgrid_start[(size_t)d.vg_nx * d.vg_ny] != d.n_vertices)
+        return fail(PRL_E_INVALID, "vertex grid starts must be non-decreasing and end at n_vertices");
     UP(tri_rec, t->tri_records, (size_t)d.n_triangles * 16);
     d.n_col = t->n_collision;
     d.n_col_pad = t->n_collision_pad;

@@ -99,6 +99,11 @@ def test_error_codes_and_messages():
     st = dt.c_struct()
     st.n_samples, st.n_samples_pad = 64 * 64 * 4 + 64, 64 * 64 * 4 + 64    # beyond the register-resident limit
     assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -3 and b'at most' in lib.prl_last_error()
+    bad = dt.sgrid_start.copy()
+    bad[3] = bad[2] - 1                                                # not monotone
+    st = dt.c_struct()
+    st.sgrid_start = bad.ctypes.data_as(_lib._ip)
+    assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -1 and b'non-decreasing' in lib.prl_last_error()
     assert lib.prl_batch_step(None, None, None, None, None, None, None, None, None) == -1
     assert config.make_config().auto_reset == 0
 
