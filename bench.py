@@ -90,6 +90,9 @@ def main():
     ap.add_argument('--envs', type=int, default=ENVS_PER_GPU, help='envs per GPU (default: the BASELINE config)')
     ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
     ap.add_argument('--mixed', action='store_true', help='config 5: door/sheet alternate, START_POINT_MODE all')
+    ap.add_argument('--actions', default='random', choices=['random', 'sweep'],
+                    help="'sweep': every env follows an on-part serpentine with a random phase (SURVEY 8d item 2), so "
+                         'episodes run long instead of ending after ~17 random steps')
     ap.add_argument('--policy', default='random', choices=['random', 'mlp'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4)")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
@@ -111,7 +114,8 @@ def main():
 
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240),
                                            name='door_test')
-    dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, 'anchor'))
+    start_mode = 'all' if args.actions == 'sweep' else 'anchor'      # the sweep starts anywhere on the part
+    dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, start_mode))
     overlap = args.obs_mode == 'grid'
     if args.mixed:
         sheet = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('square'), tex_size=(240, 240),
@@ -128,6 +132,11 @@ def main():
     gen.manual_seed(1234 + rank)
     total = args.steps + args.warmup
     actions = torch.randint(0, 4, (total, args.envs), generator=gen, device=device, dtype=torch.int32)
+    if args.actions == 'sweep':
+        pattern = torch.tensor(([1] * 12 + [0] * 2 + [3] * 12 + [0] * 2), dtype=torch.int32, device=device)
+        phase = torch.randint(0, pattern.numel(), (args.envs,), generator=gen, device=device)
+        steps_idx = torch.arange(total, device=device).unsqueeze(1)
+        actions = pattern[(steps_idx + phase.unsqueeze(0)) % pattern.numel()].contiguous()
     env.reset()
     stream_sync = torch.cuda.synchronize
 
@@ -198,7 +207,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
-                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, 'policy-MLP (6-256-128-4, fp32)' if args.policy == 'mlp' else 'random'),
+                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, 'policy-MLP (6-256-128-4, fp32)' if args.policy == 'mlp' else ('on-part serpentine' if args.actions == 'sweep' else 'random')),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},
