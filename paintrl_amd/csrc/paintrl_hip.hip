@@ -993,6 +993,7 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
     // section / discrete, 4-sector rule bpw:1034-1043
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
+    uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * k;
@@ -1034,16 +1035,24 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!use[j]) continue;
-                // one sample per lane: classify it and add into the lane's packed 16-bit counters
+                // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
+                // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
+                // 64 straddling words)
                 const uint64_t pw = bcast_u64(painted[k], L[j]);
-                const bool cnt = ((vs[j] >> lane) & 1) && !(xs[j] == x1 && ys[j] == x2);
+                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs[j]) && !(xs[j] == x1 && ys[j] == x2);
                 const bool gy = ys[j] > x2, lx = xs[j] < x1;
-                const int sh = (xs[j] > x1 && gy) ? 0 : ((lx && gy) ? 16 : ((lx && ys[j] < x2) ? 32 : 48));
-                const uint64_t one = cnt ? ((uint64_t)1 << sh) : 0;
-                tot_l += one;
-                und_l += ((pw >> lane) & 1) ? 0 : one;
+                const uint32_t sh = (xs[j] > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys[j] < x2) ? 16u : 24u));
+                const uint32_t one = cnt ? (1u << sh) : 0u;
+                tot_s += one;
+                und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
             }
         }
+    }
+    // widen the 8-bit straddle counters into the 16-bit fields
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
+        und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
     }
     tot_l = wave_sum_u64(tot_l);
     und_l = wave_sum_u64(und_l);
