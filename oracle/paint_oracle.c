@@ -144,6 +144,9 @@ static void pose_orn_quat(const double *orn, double *q) {
     q[0] = x; q[1] = y; q[2] = z; q[3] = w;
 }
 
+/* exported so the Python wrapper builds start-point quaternions with the oracle's own arithmetic */
+void or_pose_orn_quat(const double *orn, double *q) { pose_orn_quat(orn, q); }
+
 /* rob:266-271 _get_tcp_orn_norm */
 static void tcp_orn_norm(const double *pose, const double *quat, double *n) {
     static const double zaxis[3] = {0.0, 0.0, 1.0};

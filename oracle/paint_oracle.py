@@ -125,9 +125,11 @@ class Oracle(object):
             cells = t.sample_cell
         if start_points is None:
             start_points = t.anchor_points
-        from paintrl_amd.part_tables import pose_orn_quaternion
         sp = _f64([p[0] for p in start_points]).reshape(-1, 3)
-        sq = _f64([pose_orn_quaternion(p[1]) for p in start_points]).reshape(-1, 4)
+        sq = np.zeros((sp.shape[0], 4), dtype=np.float64)
+        for k, p in enumerate(start_points):              # rob:93-100 through the oracle's own C routine
+            orn = _f64(p[1])
+            self.lib.or_pose_orn_quat(_ptr(orn), _ptr(sq[k]))
         keep.update(sample_pos=_f64(t.sample_pos), sample_cell=_i32(cells),
                     vertex_pos=_f64(t._side_data[side_ids]), adj_off=_i32(off), adj_tri=_i32(adj),
                     tri_a=_f64(t.tri_a[front_ids]), tri_v0=_f64(t.tri_v0[front_ids]), tri_v1=_f64(t.tri_v1[front_ids]),
