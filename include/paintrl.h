@@ -114,6 +114,8 @@ typedef struct {
     int32_t max_episode_len, expected_episode_len;
     int32_t auto_reset;              /* 1: a finished env is reset inside the step kernel */
     double switch_threshold;
+    double paint_radius, step_size;  /* PaintToolProfile.PAINT_RADIUS / STEP_SIZE (bpw:40-43), default 0.051 both;
+                                        the part must have been built and packed for the same radius */
     double max_possible_point[8];    /* Part_Dict[...][1] per part id (rge:106-117) */
     uint64_t seed;                   /* start-point RNG for auto_reset / reset without indices */
     /* discrete action -> (delta_axis1, delta_axis2, turning angle), evaluated on the host with the

@@ -84,6 +84,7 @@ typedef struct {
     int32_t paint_method;
     int32_t max_episode_len, expected_episode_len;
     double switch_threshold, max_possible_point;
+    double paint_radius, step_size;                      /* PaintToolProfile (bpw:40-43) */
     const double *act_delta1, *act_delta2, *act_angle;   /* [n_discrete] host table */
 } OrConfig;
 
@@ -281,8 +282,8 @@ static int apply_paint(int words, uint64_t *painted, uint64_t *last, const uint6
 }
 
 /* bpw:568-570 fast_paint: all samples with |x - c|^2 <= r^2 */
-static void ball_query(const OrPart *p, const double *c, uint64_t *cur) {
-    const double r2 = PAINT_RADIUS * PAINT_RADIUS;
+static void ball_query(const OrPart *p, double radius, const double *c, uint64_t *cur) {
+    const double r2 = radius * radius;
     for (int s = 0; s < p->n_samples; ++s) {
         const double *x = p->sample_pos + 3 * s;
         double dx = x[0] - c[0], dy = x[1] - c[1], dz = x[2] - c[2];
@@ -327,8 +328,8 @@ static int grid_index_2(const OrPart *p, double val) {
 static double clip01(double v) { return v < 0 ? 0.0 : (v > 1 ? 1.0 : v); }
 
 /* bpw:965-978 get_normalized_pose */
-static void normalized_pose(const OrPart *p, const double *pose, double *out) {
-    const double r = PAINT_RADIUS;
+static void normalized_pose(const OrPart *p, double radius, const double *pose, double *out) {
+    const double r = radius;
     double x1 = pose[p->a1], x2 = pose[p->a2];
     double in2 = (x2 - p->range2_min + r) / (p->range2_max - p->range2_min + 2 * r);
     int gi = grid_index_2(p, x2);
@@ -365,7 +366,7 @@ static double py_floor_div(double vx, double wx) {
 /* rge:306-319 _augmented_observation (+ bpw:1045-1061, 1126-1139) */
 static void observation(const OrPart *p, const OrConfig *c, const OrEnv *e, const uint64_t *painted, double *obs) {
     double npose[2];
-    normalized_pose(p, e->pose, npose);
+    normalized_pose(p, c->paint_radius, e->pose, npose);
     if (c->obs_mode == OBS_SIMPLE) { obs[0] = npose[0]; obs[1] = npose[1]; return; }
     if (c->obs_mode == OBS_GRID) {
         int h = c->obs_grad;
@@ -470,7 +471,7 @@ void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_a
                 a[k] = v;
             }
             direction(c, a, &dx, &dy);
-            delta1 = dx * STEP_SIZE; delta2 = dy * STEP_SIZE;
+            delta1 = dx * c->step_size; delta2 = dy * c->step_size;
             new_angle = delta1 != 0 ? atan(fabs(delta2 / delta1)) : M_PI / 2;
         }
         e->angle_diff = fabs(new_angle - e->last_turning_angle);   /* rob:352-358 */
@@ -503,7 +504,7 @@ void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_a
                 static const double tip[3] = {0.0, 0.0, 0.1};
                 double center[3];
                 transform_point(pos, quat, tip, center);        /* rob:277-278 */
-                ball_query(p, center, cur);
+                ball_query(p, c->paint_radius, center, cur);
                 succeeded += apply_paint(words, painted, last, cur, uni);
             } else if (cone_query(p, pos, quat, cur) > 0) {
                 succeeded += apply_paint(words, painted, last, cur, uni);

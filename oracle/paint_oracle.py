@@ -35,6 +35,7 @@ class OrConfig(C.Structure):
                 ('termination_mode', C.c_int32), ('turning_penalty', C.c_int32), ('overlap_penalty', C.c_int32),
                 ('paint_method', C.c_int32), ('max_episode_len', C.c_int32), ('expected_episode_len', C.c_int32),
                 ('switch_threshold', C.c_double), ('max_possible_point', C.c_double),
+                ('paint_radius', C.c_double), ('step_size', C.c_double),
                 ('act_delta1', _dp), ('act_delta2', _dp), ('act_angle', _dp)]
 
 
@@ -84,14 +85,14 @@ def _ptr(a):
     return a.ctypes.data_as(_dp if a.dtype == np.float64 else _ip)
 
 
-def discrete_action_table(n):
+def discrete_action_table(n, step_size=0.051):
     """rge:342-347 + rob:151-153, 396-397, 352-356 evaluated with the reference's own calls."""
     d1, d2, ang = [], [], []
     for a in range(n):
         v = 2 * (a - n / 2) / n
         phi = (v + 1) * np.pi
         x, y = 1 * np.cos(phi), 1 * np.sin(phi)
-        delta1, delta2 = x * 0.051, y * 0.051
+        delta1, delta2 = x * step_size, y * step_size
         d1.append(delta1)
         d2.append(delta2)
         ang.append(math.atan(abs(delta2 / delta1)) if delta1 != 0 else math.pi / 2)
@@ -104,7 +105,7 @@ class Oracle(object):
     def __init__(self, tables, n_envs, obs_mode='section', obs_grad=4, action_mode='discrete', action_dim=1,
                  n_discrete=4, termination_mode='late', turning_penalty=False, overlap_penalty=False,
                  paint_method='fast', max_episode_len=245, expected_episode_len=245, switch_threshold=0.9,
-                 max_possible_point=9148, start_points=None, threads=1):
+                 max_possible_point=9148, start_points=None, threads=1, paint_radius=None, step_size=0.051):
         self.lib = _load()
         t = tables
         self.tables = t
@@ -163,7 +164,9 @@ class Oracle(object):
         c.paint_method = PAINT_METHODS[paint_method]
         c.max_episode_len, c.expected_episode_len = max_episode_len, expected_episode_len
         c.switch_threshold, c.max_possible_point = switch_threshold, max_possible_point
-        self._act = discrete_action_table(n_discrete)
+        c.paint_radius = float(getattr(t, 'paint_radius', 0.051) if paint_radius is None else paint_radius)
+        c.step_size = float(step_size)
+        self._act = discrete_action_table(n_discrete, step_size)
         c.act_delta1, c.act_delta2, c.act_angle = (_ptr(a) for a in self._act)
         self.cfg = c
         self.discrete = action_mode == 'discrete'

@@ -4,10 +4,11 @@ translearn/PaintRL) behind the reference's Gym-facing API.
 Host side (numpy): part_tables (mesh -> static tables), device_tables (device layout), config.
 Device side: libpaintrl_hip.so (csrc/paintrl_hip.hip) through the C ABI of include/paintrl.h.
 """
-from .config import EXTRA_CONFIG, Part_Dict, make_config  # noqa: F401
+from .config import EXTRA_CONFIG, PaintToolProfile, Part_Dict, make_config  # noqa: F401
 from .param_test_env import ParamTestEnv  # noqa: F401
 
-__all__ = ['PaintGymEnv', 'BatchedPaintEnv', 'ParamTestEnv', 'Part_Dict', 'EXTRA_CONFIG', 'make_config']
+__all__ = ['PaintGymEnv', 'BatchedPaintEnv', 'ParamTestEnv', 'Part_Dict', 'EXTRA_CONFIG', 'PaintToolProfile',
+           'make_config']
 
 
 def __getattr__(name):            # torch-dependent classes are imported lazily

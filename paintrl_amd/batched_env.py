@@ -42,6 +42,8 @@ class BatchedPaintEnv(object):
             if not isinstance(p, DeviceTables):
                 raise TypeError('parts must be paintrl_amd.device_tables.DeviceTables')
         self.n_envs = int(n_envs)
+        cfg_kwargs = dict(cfg_kwargs)
+        cfg_kwargs.setdefault('paint_radius', self.parts[0].paint_radius)    # the radius the tables were built for
         self.cfg_kwargs = dict(cfg_kwargs)
         self.cfg = _config.make_config(**cfg_kwargs)
         self.obs_dim = self.lib.prl_obs_dim(C.byref(self.cfg))

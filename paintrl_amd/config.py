@@ -9,7 +9,13 @@ OBS_MODES = {'section': 0, 'grid': 1, 'simple': 2, 'discrete': 3}
 ACTION_MODES = {'discrete': 0, 'continuous': 1}
 TERMINATION_MODES = {'late': 0, 'early': 1, 'hybrid': 2}
 PAINT_METHODS = {'fast': 0, 'normal': 1}
-STEP_SIZE = 0.051
+
+
+class PaintToolProfile(object):
+    """The profile of the paint gun (bpw:40-43); read when an env is constructed, like the reference's class."""
+    PAINT_RADIUS = 0.051
+    STEP_SIZE = PAINT_RADIUS
+
 
 # rge:106-117 Part_Dict: part number -> [urdf file, max possible points]
 Part_Dict = {
@@ -26,7 +32,7 @@ EXTRA_CONFIG = {
 }
 
 
-def discrete_action_table(n):
+def discrete_action_table(n, step_size=0.051):
     """Discrete action a -> (delta_axis1, delta_axis2, turning angle).
 
     rge:342-347 (_preprocess_action), rob:151-153 (direction_normalize, 1-D), rob:396-397,
@@ -38,7 +44,7 @@ def discrete_action_table(n):
         v = 2 * (a - n / 2) / n
         phi = (v + 1) * np.pi
         x, y = 1 * np.cos(phi), 1 * np.sin(phi)
-        delta1, delta2 = x * STEP_SIZE, y * STEP_SIZE
+        delta1, delta2 = x * step_size, y * step_size
         d1.append(float(delta1))
         d2.append(float(delta2))
         ang.append(math.atan(abs(delta2 / delta1)) if delta1 != 0 else math.pi / 2)
@@ -48,7 +54,7 @@ def discrete_action_table(n):
 def make_config(obs_mode='section', obs_grad=4, action_mode='discrete', action_dim=1, n_discrete=4,
                 termination_mode='late', turning_penalty=False, overlap_penalty=False, paint_method='fast',
                 max_episode_len=245, expected_episode_len=245, switch_threshold=0.9, max_possible_point=9148,
-                auto_reset=False, seed=0):
+                auto_reset=False, seed=0, paint_radius=0.051, step_size=0.051):
     """Build the PrlConfig POD.  ``max_possible_point`` is a number or one number per part id."""
     c = _lib.PrlConfig()
     c.obs_mode, c.obs_grad = OBS_MODES[obs_mode], int(obs_grad)
@@ -59,6 +65,7 @@ def make_config(obs_mode='section', obs_grad=4, action_mode='discrete', action_d
     c.max_episode_len, c.expected_episode_len = int(max_episode_len), int(expected_episode_len)
     c.auto_reset = int(bool(auto_reset))
     c.switch_threshold = float(switch_threshold)
+    c.paint_radius, c.step_size = float(paint_radius), float(step_size)
     pts = list(np.atleast_1d(max_possible_point).astype(float))
     for k in range(8):
         c.max_possible_point[k] = pts[min(k, len(pts) - 1)]
@@ -66,7 +73,7 @@ def make_config(obs_mode='section', obs_grad=4, action_mode='discrete', action_d
     if c.action_mode == 0:
         if not 1 <= n_discrete <= _lib.MAX_DISCRETE:
             raise ValueError('DISCRETE_GRANULARITY must be 1..%d' % _lib.MAX_DISCRETE)
-        d1, d2, ang = discrete_action_table(n_discrete)
+        d1, d2, ang = discrete_action_table(n_discrete, step_size)
         for k in range(n_discrete):
             c.act_delta1[k], c.act_delta2[k], c.act_angle[k] = d1[k], d2[k], ang[k]
     return c

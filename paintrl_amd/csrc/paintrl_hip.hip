@@ -729,8 +729,9 @@ __device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b
 }
 
 template <int KW>
-__device__ void ball_query_wave(const PartDev &P, const double c[3], int lane, uint64_t cur[KW_MAX]) {
-    const double r2 = PAINT_RADIUS * PAINT_RADIUS;
+__device__ void ball_query_wave(const PartDev &P, double radius, const double c[3], int lane,
+                                uint64_t cur[KW_MAX]) {
+    const double r2 = radius * radius;
     const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
     const int icx = cell_coord(c1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(c2, P.sg_o2, P.sg_inv, P.sg_ny);
     const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
@@ -779,10 +780,11 @@ struct ShotCentres {
 };
 
 template <int KW>
-__device__ bool paint_shots_union(const PartDev &P, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
+__device__ bool paint_shots_union(const PartDev &P, double radius, const double *cen_lds, int lane,
+                                  uint64_t painted[KW_MAX],
                                   const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
                                   int &pixel_counter) {
-    const double r2 = PAINT_RADIUS * PAINT_RADIUS;
+    const double r2 = radius * radius;
     ShotCentres sc;
 #pragma unroll
     for (int k = 0; k < PAINT_PER_ACTION; ++k) {
@@ -933,7 +935,7 @@ template <int KW, bool GENSEC>
 __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const double pose[3],
                                  const uint64_t painted[KW_MAX], int lane, double *out) {
     // bpw:965-978 get_normalized_pose
-    const double r = PAINT_RADIUS;
+    const double r = C.paint_radius;
     const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
     const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
     const int gi = grid_index_2(P, x2);
@@ -1230,8 +1232,8 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
                 dy = mx * sin(phi);
             }
         }
-        delta1 = dx * STEP_SIZE;
-        delta2 = dy * STEP_SIZE;
+        delta1 = dx * C.step_size;
+        delta2 = dy * C.step_size;
         new_angle = delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2;
     }
     const double angle_diff = fabs(new_angle - S.last_angle);
@@ -1346,7 +1348,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
 #ifdef PRL_ABLATE_BALL
         if (true) {
 #else
-        if (paint_shots_union<KW>(P, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
+        if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
 #endif
 #pragma unroll
             for (int k = 0; k < KW; ++k) last[k] = new_last[k];
@@ -1356,7 +1358,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
                 uint64_t cur[KW_MAX] = {0, 0, 0, 0};
                 const double c3[3] = {cen[3 * shot], cen[3 * shot + 1], cen[3 * shot + 2]};
-                ball_query_wave<KW>(P, c3, lane, cur);
+                ball_query_wave<KW>(P, C.paint_radius, c3, lane, cur);
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
                     succeeded_l += __popcll(cur[k] & ~painted[k]);
@@ -1659,6 +1661,7 @@ int check_config(const PrlConfig *c) {
     if (c->termination_mode < 0 || c->termination_mode > 2) return fail(PRL_E_INVALID, "termination_mode");
     if (c->paint_method != PRL_PAINT_FAST && c->paint_method != PRL_PAINT_NORMAL) return fail(PRL_E_INVALID, "paint_method");
     if (c->max_episode_len < 1 || c->expected_episode_len < 1) return fail(PRL_E_INVALID, "episode lengths");
+    if (!(c->paint_radius > 0) || !(c->step_size > 0)) return fail(PRL_E_INVALID, "paint_radius and step_size must be positive");
     return PRL_OK;
 }
 
@@ -1755,6 +1758,9 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     for (int i = 0; i < n_parts; ++i) {
         if (!parts[i]) return fail(PRL_E_INVALID, "null part %d", i);
         if (parts[i]->device != parts[0]->device) return fail(PRL_E_INVALID, "parts live on different devices");
+        if (cfg->paint_radius * parts[i]->dev.sg_inv >= 1.0)
+            return fail(PRL_E_INVALID, "part %d: sample grid cell %.4f does not exceed the paint radius %.4f", i,
+                        1.0 / parts[i]->dev.sg_inv, cfg->paint_radius);
         if (cfg->paint_method == PRL_PAINT_NORMAL && parts[i]->dev.n_beams <= 0)
             return fail(PRL_E_INVALID, "part %d has no cone beams but PAINT_METHOD='normal' was requested", i);
         if (cfg->obs_mode == PRL_OBS_GRID && parts[i]->dev.n_obs_cells != cfg->obs_grad * cfg->obs_grad)

@@ -30,7 +30,9 @@ class DeviceTables(object):
         # word mixes the end of one row with the start of the next (such words would straddle the
         # tool in every observation)
         o1, o2 = float(t.sample_pos[:, a1].min()), float(t.sample_pos[:, a2].min())
-        inv = 1.0 / CELL
+        self.paint_radius = float(getattr(t, 'paint_radius', pt.PAINT_RADIUS))
+        self.cell = max(CELL, 1.02 * self.paint_radius)      # > radius, so a ball overlaps at most 3x3 cells
+        inv = 1.0 / self.cell
         cx = np.floor((t.sample_pos[:, a1] - o1) * inv).astype(np.int64)
         cy = np.floor((t.sample_pos[:, a2] - o2) * inv).astype(np.int64)
         nx, ny = int(cx.max()) + 1, int(cy.max()) + 1
@@ -107,7 +109,7 @@ class DeviceTables(object):
         self.vertex_rank = vorder.astype(np.int32)            # rank in the reference's vertex order
         self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
         self.vgrid = (vo1, vo2, inv, vnx, vny)
-        self.vgrid_accept = 0.99 * CELL
+        self.vgrid_accept = 0.99 * self.cell
         front_ids = np.nonzero(t.tri_side == pt.SIDE_FRONT)[0]
         compact = -np.ones(t.tri_side.shape[0], dtype=np.int64)
         compact[front_ids] = np.arange(front_ids.size)
@@ -134,7 +136,7 @@ class DeviceTables(object):
         nrm = np.cross(t.col_e1, t.col_e2)
         with np.errstate(all='ignore'):
             facing = nrm[:, t.a0] / np.linalg.norm(nrm, axis=1)
-        large = ((hi[:, a1] - lo[:, a1]) > 4 * CELL) | ((hi[:, a2] - lo[:, a2]) > 4 * CELL)
+        large = ((hi[:, a1] - lo[:, a1]) > 4 * self.cell) | ((hi[:, a2] - lo[:, a2]) > 4 * self.cell)
         facing = np.nan_to_num(facing)
         # chunks of 64: small facets bucketed by a coarse K x K grid over the principal plane (compact
         # chunk boxes), then large front-facing, large back-facing and large other facets, each group

@@ -131,7 +131,7 @@ def _side_of_normals(vn, a0):
 # the builder
 # ----------------------------------------------------------------------------
 def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, collision_mode='hull',
-                      base_position=obj_io.PART_BASE_POSITION, name=None, verbose=False):
+                      base_position=obj_io.PART_BASE_POSITION, name=None, verbose=False, paint_radius=PAINT_RADIUS):
     """Build the static tables of one part for painting its FRONT side.
 
     Either ``urdf_path`` (resolved like the reference does) or ``mesh``
@@ -150,6 +150,7 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
     t.tex_w, t.tex_h = W, H
     t.collision_mode = collision_mode
     t.obs_grad = int(obs_grad)
+    t.paint_radius = float(paint_radius)      # PaintToolProfile.PAINT_RADIUS at load time (bpw:42)
 
     # -- global frame, axes (bpw:1176-1182, 1294-1300, 498-500) ----------------
     V = np.asarray(base_position, dtype=np.float64)[None, :] + mesh.vertices
@@ -204,7 +205,7 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
 
     # -- ranges, anchor start points (uncorrected normals!) ----------------------
     t.ranges = _ranges(V, a1, a2)
-    corner_points = _corner_points(V, a1, a2)
+    corner_points = _corner_points(V, a1, a2, t.paint_radius)
     t._side_data = side_data
     t._normals = normals
     t.anchor_points = []
@@ -287,9 +288,9 @@ def _ranges(V, a1, a2):
     return [[float(V[:, a1].min()), float(V[:, a1].max())], [float(V[:, a2].min()), float(V[:, a2].max())]]
 
 
-def _corner_points(V, a1, a2):
+def _corner_points(V, a1, a2, radius=PAINT_RADIUS):
     """_get_corner_points_ranges (1256-1286): stable-sort extremes of a1+a2 and a1-a2."""
-    shrink = PAINT_RADIUS / 2
+    shrink = radius / 2
     s = V[:, a1] + V[:, a2]
     d = V[:, a1] - V[:, a2]
     first_min = lambda k: int(np.argmin(k))                       # noqa: E731
@@ -355,7 +356,7 @@ def grid_index_2(t, val_axis_2):
 
 def normalized_pose(t, pose):
     """Part.get_normalized_pose (965-978)."""
-    r = PAINT_RADIUS
+    r = t.paint_radius
     x1 = pose[t.a1]
     x2 = pose[t.a2]
     in2 = (x2 - t.ranges[1][0] + r) / (t.ranges[1][1] - t.ranges[1][0] + 2 * r)
@@ -508,7 +509,7 @@ def _smooth_with_neighbours(t, front_ids):
                 continue
             ang = included_angle(normals[b], normals[ti])
             if abs(ang) > np.pi / 18:
-                near = tree.query_ball_point(t.tri_center[ti], PAINT_RADIUS)
+                near = tree.query_ball_point(t.tri_center[ti], t.paint_radius)
                 weighted = []
                 for bi in near:
                     if bi != ti:
@@ -546,7 +547,7 @@ def grid_observation_cells(t, h):
 
 def _all_start_points(t, front_ids):
     """The 'all' candidates of Part.get_start_points (749-773), file order, corrected normals."""
-    shrink = PAINT_RADIUS / 2
+    shrink = t.paint_radius / 2
     a1, a2 = t.a1, t.a2
     ax2 = [p[0][a2] for p in t.anchor_points]
     ax2_max, ax2_min = max(ax2), min(ax2)
@@ -624,7 +625,7 @@ _ARRAY_FIELDS = ['vertices', 'tri_vidx', 'tri_side', 'tri_area', 'tri_area_valid
                  'tri_v1', 'tri_d00', 'tri_d01', 'tri_d11', 'tri_inv', 'tri_normal', 'sample_pix', 'sample_pos',
                  'sample_cell', 'vertex_is_side', '_side_data', 'col_v0', 'col_e1', 'col_e2', 'grid_lo', 'grid_hi',
                  'grid_range', 'beams', 'front_ids']
-_SCALAR_FIELDS = ['name', 'tex_w', 'tex_h', 'collision_mode', 'obs_grad', 'a0', 'a1', 'a2', 'lwr', 'max_grid_size',
+_SCALAR_FIELDS = ['name', 'tex_w', 'tex_h', 'collision_mode', 'obs_grad', 'paint_radius', 'a0', 'a1', 'a2', 'lwr', 'max_grid_size',
                   'density', 'n_hull_corrected', 'n_smoothed']
 TABLE_FORMAT_VERSION = 1
 

@@ -20,15 +20,17 @@ import numpy as np
 from . import config as _config
 from . import part_tables as _pt
 from . import spaces
-from .config import EXTRA_CONFIG as _DEFAULT_EXTRA, Part_Dict
+from .config import EXTRA_CONFIG as _DEFAULT_EXTRA, PaintToolProfile, Part_Dict
 
 _urdf_cache = {}          # (path, mtime, collision_mode) -> PartTables, like bpw._urdf_cache
 
 
-def load_part_tables(path, collision_mode='hull', obs_grad=4):
-    key = (os.path.abspath(path), os.path.getmtime(path), collision_mode)
+def load_part_tables(path, collision_mode='hull', obs_grad=4, paint_radius=None):
+    radius = PaintToolProfile.PAINT_RADIUS if paint_radius is None else paint_radius
+    key = (os.path.abspath(path), os.path.getmtime(path), collision_mode, radius)
     if key not in _urdf_cache:
-        _urdf_cache[key] = _pt.build_part_tables(path, obs_grad=obs_grad, collision_mode=collision_mode)
+        _urdf_cache[key] = _pt.build_part_tables(path, obs_grad=obs_grad, collision_mode=collision_mode,
+                                                 paint_radius=radius)
     return _urdf_cache[key]
 
 
@@ -112,7 +114,8 @@ class PaintGymEnv(spaces.Env):
             termination_mode=self.TERMINATION_MODE, turning_penalty=self.TURNING_PENALTY,
             overlap_penalty=self.OVERLAP_PENALTY, paint_method='fast', max_episode_len=self.EPISODE_MAX_LENGTH,
             expected_episode_len=self.Expected_Episode_Length, switch_threshold=self.SWITCH_THRESHOLD,
-            max_possible_point=self._max_possible_point)
+            max_possible_point=self._max_possible_point, paint_radius=PaintToolProfile.PAINT_RADIUS,
+            step_size=PaintToolProfile.STEP_SIZE)
         self.robot = _RobotView(self)
         self.reset()
 

@@ -18,13 +18,14 @@ def pytest_configure(config):
 _TABLES = {}
 
 
-def synthetic_tables(name):
+def synthetic_tables(name, paint_radius=0.051):
     """Session cache of PartTables for the synthetic parts ('door_test' | 'square')."""
-    if name not in _TABLES:
+    key = (name, paint_radius)
+    if key not in _TABLES:
         from paintrl_amd import part_tables, synth_parts
-        _TABLES[name] = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(name),
-                                                      tex_size=(240, 240), name=name)
-    return _TABLES[name]
+        _TABLES[key] = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(name), tex_size=(240, 240),
+                                                     name=name, paint_radius=paint_radius)
+    return _TABLES[key]
 
 
 @pytest.fixture(scope='session')
@@ -55,7 +56,8 @@ def env_kwargs_from_cfg(cfg):
                 termination_mode=cfg['termination_mode'], turning_penalty=cfg['turning_penalty'],
                 overlap_penalty=cfg['overlap_penalty'], paint_method=cfg['paint_method'],
                 max_episode_len=cfg['max_episode_len'], expected_episode_len=cfg['expected_episode_len'],
-                switch_threshold=cfg['switch_threshold'], max_possible_point=cfg['max_possible_point'])
+                switch_threshold=cfg['switch_threshold'], max_possible_point=cfg['max_possible_point'],
+                paint_radius=cfg.get('paint_radius', 0.051), step_size=cfg.get('step_size', 0.051))
 
 
 def start_points_for(tables, mode):

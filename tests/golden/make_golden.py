@@ -40,7 +40,12 @@ def sha(a):
 class RefDriver(object):
     """One constructed reference env (START_POINT_MODE='all'), re-configured in place per episode."""
 
-    def __init__(self, root, part_no):
+    def __init__(self, root, part_no, paint_radius=None, step_size=None):
+        ref_import.load_reference('hull')
+        prof = sys.modules['bullet_paint_wrapper'].PaintToolProfile
+        prof.PAINT_RADIUS = 0.051 if paint_radius is None else paint_radius
+        prof.STEP_SIZE = prof.PAINT_RADIUS if step_size is None else step_size
+        self.tool = (prof.PAINT_RADIUS, prof.STEP_SIZE)
         t0 = time.time()
         self.env, self.part = ref_import.make_env(root, part_no=part_no, obs_mode='section', obs_grad=4,
                                                   extra={'START_POINT_MODE': 'all'})
@@ -78,7 +83,8 @@ class RefDriver(object):
                         turning_penalty=turning, termination_mode=termination, paint_method=paint_method,
                         action_mode=mode, action_dim=shape, n_discrete=gran, max_episode_len=max_len,
                         expected_episode_len=env.Expected_Episode_Length, switch_threshold=env.SWITCH_THRESHOLD,
-                        max_possible_point=env._max_possible_point, part_no=self.part_no)
+                        max_possible_point=env._max_possible_point, part_no=self.part_no,
+                        paint_radius=self.tool[0], step_size=self.tool[1])
 
     def reset(self, seed):
         random.seed(seed)
@@ -314,6 +320,19 @@ def main():
     sheet.configure('section', 4, 'fixed', paint_method='normal', rollout=True)
     eps['g6_normal'] = sheet.episode(0, zigzag_policy(-1, 2), max_steps=20)
     save_episodes('sheet', eps)
+
+    # ---------------- sheet with a non-default tool profile (README "Change the paint tool profile") ----------------
+    sheet.env.close()
+    tool = RefDriver(root, 1, paint_radius=0.04, step_size=0.03)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_sheet_r040.npz'), **table_digest(tool))
+    eps = {}
+    tool.configure('section', 4, 'anchor', overlap=True)
+    eps['g10_tool_profile'] = tool.episode(500, zigzag_policy(-1, 2), max_steps=60, want_idx=0)
+    tool.configure('grid', 4, 'all')
+    eps['g10_tool_profile_grid'] = tool.episode(501, random_policy(90), max_steps=40)
+    save_episodes('sheet_tool', eps)
+    sys.modules['bullet_paint_wrapper'].PaintToolProfile.PAINT_RADIUS = 0.051
+    sys.modules['bullet_paint_wrapper'].PaintToolProfile.STEP_SIZE = 0.051
 
     meta['timings'] = timings
     meta['ray_seconds_total'] = float(stub.RAY_SECONDS[0])

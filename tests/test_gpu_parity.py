@@ -23,7 +23,7 @@ DEVICE_CASES = CASES
 def test_gpu_replays_reference_episode(tag, name):
     ep = load_episodes(tag)[name]
     cfg = ep['cfg']
-    tables = synthetic_tables(PART[tag])
+    tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
     env = _gpu_env(tables, 1, start_points_for(tables, cfg['start_mode']), **env_kwargs_from_cfg(cfg))
     continuous = cfg['action_mode'] == 'continuous'
 

@@ -18,11 +18,13 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize('tag,name', [('door', 'door_test'), ('sheet', 'square')])
-def test_tables_match_reference_digests(tag, name):
-    """G0: every static table equals what the reference built for the same synthetic mesh."""
+@pytest.mark.parametrize('tag,name,radius', [('door', 'door_test', 0.051), ('sheet', 'square', 0.051),
+                                             ('sheet_r040', 'square', 0.04)])
+def test_tables_match_reference_digests(tag, name, radius):
+    """G0: every static table equals what the reference built for the same synthetic mesh (the last case
+    with PaintToolProfile.PAINT_RADIUS = 0.04)."""
     g = np.load(os.path.join(GOLDEN, 'g0_tables_%s.npz' % tag))
-    t = synthetic_tables(name)
+    t = synthetic_tables(name, radius)
     front = t.tri_side == 1
     assert int(g['P']) == t.sample_pos.shape[0] and int(g['T']) == t.tri_side.shape[0]
     assert int(g['V']) == t.vertices.shape[0]
@@ -44,6 +46,7 @@ def test_tables_match_reference_digests(tag, name):
     assert len(part_tables.start_points(t, 'anchor')) == 4 and len(part_tables.start_points(t, 'fixed')) == 1
     assert np.array_equal(g['pos_head'], t.sample_pos[:32]) and np.array_equal(g['normals_tail'], t.tri_normal[front][-32:])
     assert len(t.vertices_mutated) == 0        # synthetic parts never trigger the sparse-row mutation
+    assert t.paint_radius == radius
 
 
 @pytest.mark.parametrize('size,driver,steps,total', [(22, zigzag, 399, 320.2), (20, spiral, 323, 259.4),

@@ -6,8 +6,8 @@ import pytest
 import oracle
 from conftest import env_kwargs_from_cfg, load_episodes, start_points_for, synthetic_tables
 
-CASES = [('door', n) for n in sorted(load_episodes('door'))] + [('sheet', n) for n in sorted(load_episodes('sheet'))]
-PART = {'door': 'door_test', 'sheet': 'square'}
+CASES = [(tag, n) for tag in ('door', 'sheet', 'sheet_tool') for n in sorted(load_episodes(tag))]
+PART = {'door': 'door_test', 'sheet': 'square', 'sheet_tool': 'square'}
 
 
 def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
@@ -36,7 +36,7 @@ def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
 def test_oracle_replays_reference_episode(tag, name):
     ep = load_episodes(tag)[name]
     cfg = ep['cfg']
-    tables = synthetic_tables(PART[tag])
+    tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
     orc = oracle.Oracle(tables, 1, start_points=start_points_for(tables, cfg['start_mode']),
                         **env_kwargs_from_cfg(cfg))
     continuous = cfg['action_mode'] == 'continuous'
