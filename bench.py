@@ -109,6 +109,8 @@ def main():
     rank, local_rank, world = pdist.init_process_group()
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if os.environ.get('PAINTRL_SINGLE_DEVICE'):          # testing aid: all ranks share GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 

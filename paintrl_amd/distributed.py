@@ -25,7 +25,8 @@ def init_process_group(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # PAINTRL_DIST_BACKEND=gloo is a testing aid (several ranks on one GPU; RCCL refuses that)
+            backend = os.environ.get('PAINTRL_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)       # RCCL binds the communicator to the current device
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -52,6 +53,11 @@ def gather_returns(local_returns):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local_returns.clone()
     world = dist.get_world_size()
+    if dist.get_backend() == 'gloo' and local_returns.is_cuda:        # gloo moves host memory
+        host = local_returns.detach().cpu().contiguous()
+        out = torch.empty(world * host.numel(), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(local_returns.device)
     out = torch.empty(world * local_returns.numel(), dtype=local_returns.dtype, device=local_returns.device)
     dist.all_gather_into_tensor(out, local_returns.contiguous())
     return out
@@ -61,6 +67,8 @@ def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (used for the timed region of bench.py)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() == 'gloo':
+        device = 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
