@@ -199,7 +199,8 @@ def main():
         achieved = per_launch / avg_kernel_s / 1e9
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-        if os.path.isfile(tpath):
+        # the committed PMC measurement is for the default workload only
+        if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random':
             with open(tpath) as f:
                 traffic = json.load(f).get('bytes_per_launch_%s' % args.obs_mode)
         value = world * args.steps / elapsed
