@@ -196,3 +196,36 @@ def test_full_size_batch_equals_oracle():
     want = np.stack([orc.painted_bits(e) for e in range(n)])
     assert np.array_equal(bits, want)
     env.close()
+
+
+def test_hostile_continuous_actions_do_not_disturb_other_envs():
+    """NaN / inf / huge continuous actions in some envs: the launch completes, and every env that was
+    fed finite actions still matches the oracle exactly in done flags and painted sets (observations
+    and rewards to 1e-9: continuous actions go through libm on both sides)."""
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n, steps = 128, 15
+    kw = dict(action_mode='continuous', action_dim=2, obs_mode='section')
+    env = _env(tables, n, sp, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, **kw)
+    rng = np.random.RandomState(13)
+    start = rng.randint(0, len(sp), size=n)
+    env.reset(start_idx=start)
+    orc.reset(start)
+    bad = np.zeros(n, dtype=bool)
+    bad[::7] = True
+    alive = ~bad
+    for k in range(steps):
+        a = rng.uniform(-1.5, 1.5, size=(n, 2))
+        a[bad, 0] = [np.nan, np.inf, -np.inf, 1e300][k % 4]
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        np.testing.assert_allclose(o[alive], oo[alive], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(r[alive], rr[alive], rtol=0, atol=1e-9)
+        assert np.array_equal(d[alive], dd[alive])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = env.parts[0].mask_to_canonical(words)
+    for e in np.nonzero(alive)[0]:
+        assert np.array_equal(bits[e], orc.painted_bits(e))
+    env.close()
