@@ -99,6 +99,13 @@ struct PartDev {
     gdouble_p beams;
 };
 
+// The part descriptor and the batch configuration are read-only for every kernel: typed as constant
+// address space so that their fields are fetched with scalar loads (s_load through the K$) instead
+// of wave-uniform vector loads the compiler has to assume the kernel's own stores may clobber.
+#define CAS __attribute__((address_space(4)))
+typedef const PartDev CAS &PartRef;
+typedef const PrlConfig CAS &CfgRef;
+
 struct StepArgs {
     const PartDev *parts;
     const PrlConfig *cfg;
@@ -112,6 +119,16 @@ struct StepArgs {
     const int *start_idx;
     const uint8_t *reset_mask;
 };
+
+#ifdef PRL_WAVE_TIMES      // per-wave trip counters of the data-dependent loops (diagnostic build only)
+__device__ uint32_t g_wcnt[1 << 16][8];
+#define WCNT(slot, v)                                                                        \
+    do {                                                                                     \
+        if ((threadIdx.x & 63) == 0) g_wcnt[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 0xffff][slot] += (v); \
+    } while (0)
+#else
+#define WCNT(slot, v)
+#endif
 
 // ---------------------------------------------------------------- diagnostic build only (-DPRL_PHASE_TIMING)
 // Per-phase s_memtime deltas summed over all waves into a buffer nothing else reads
@@ -319,7 +336,7 @@ __device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, cons
 // with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
 // One float64 Moller-Trumbore test per lane (triangle i, or none if i < 0); keeps the lane's best
 // (t, reference rank) and remembers which triangle and which determinant produced it.
-__device__ __forceinline__ void mt_one(const PartDev &P, int i, const double o[3], double d0, double d1, double d2,
+__device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], double d0, double d1, double d2,
                                        double tmax, double &best_t, int &best_r, int &best_i, double &best_det) {
     if (i >= 0) {
         const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
@@ -368,7 +385,7 @@ __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double
 // vertex-neighbourhood of `hint` holds a valid hit whose facet is ENTERED (orient * det > 0), the
 // closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
 // hit there, an exit hit, a facet without a neighbour list) takes the general search below.
-__device__ int ray_closest_wave(const PartDev &P, const double o[3], const double e[3], int lane, double &t_out,
+__device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3], int lane, double &t_out,
                                 double hit[3], int &hint) {
     __shared__ int s_cand[4][64];
     int *cand = s_cand[threadIdx.x >> 6];
@@ -403,6 +420,7 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
         }
     }
     if (win < 0) {
+        WCNT(0, 1);
         const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
         const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
         const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
@@ -412,12 +430,14 @@ __device__ int ray_closest_wave(const PartDev &P, const double o[3], const doubl
             if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
 #endif
             const double tmax = stage == 0 ? 0.125 : 1.0;
+            if (stage == 1) WCNT(1, 1);
             const SegBox sb = seg_box(o3, d3, tmax);
             int n_cand = 0;
             for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
                 const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
                 uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
                 while (cm) {
+                    WCNT(2, 1);
                     const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
                     cm &= cm - 1;
                     const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
@@ -481,7 +501,7 @@ __device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int ic
     return out;
 }
 
-__device__ __forceinline__ void nv_scan(const PartDev &P, int begin, int end, const double pt[3], int lane,
+__device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const double pt[3], int lane,
                                         double &best_d, int &best_rank, int &best_idx) {
     for (int b = begin; b < end; b += 128) {                   // two batches per trip: eight loads in flight
         const int v0 = b + lane, v1 = v0 + 64;
@@ -525,7 +545,7 @@ __device__ __forceinline__ void nv_scan(const PartDev &P, int begin, int end, co
 // scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
 // outside the block is at least k cells away in the principal plane, so the result is exact once the
 // best distance is within k * 0.99 * cell.  After ring 3 the whole table is scanned.
-__device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lane) {
+__device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
     double best_d = INFINITY, dmin = INFINITY;
@@ -550,7 +570,9 @@ __device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lan
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
+        if (ring > 1) WCNT(4, 1);
         for (int c0 = 0; c0 < total; c0 += 64) {
+            WCNT(3, 1);
             const int c = c0 + lane;
             if (c < total) {
                 int v = rbeg[0] + c;
@@ -592,7 +614,7 @@ __device__ int nearest_vertex_wave(const PartDev &P, const double pt[3], int lan
 // ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1): nearest sample
 // Same exact expanding-ring search as for vertices, over the sample grid; equal distances resolve
 // to the lowest reference-order index.  Returns the device position of the sample, or -1.
-__device__ int nearest_sample_wave(const PartDev &P, const double pt[3], int lane) {
+__device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(h2, P.sg_o2, P.sg_inv, P.sg_ny);
     double best_d = INFINITY, dmin = INFINITY;
@@ -656,7 +678,7 @@ __device__ int nearest_sample_wave(const PartDev &P, const double pt[3], int lan
 }
 
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
-__device__ bool hook_point_wave(const PartDev &P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
+__device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
 #ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
     const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
 #else
@@ -729,7 +751,7 @@ __device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b
 }
 
 template <int KW>
-__device__ void ball_query_wave(const PartDev &P, double radius, const double c[3], int lane,
+__device__ void ball_query_wave(PartRef P, double radius, const double c[3], int lane,
                                 uint64_t cur[KW_MAX]) {
     const double r2 = radius * radius;
     const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
@@ -780,7 +802,7 @@ struct ShotCentres {
 };
 
 template <int KW>
-__device__ bool paint_shots_union(const PartDev &P, double radius, const double *cen_lds, int lane,
+__device__ bool paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane,
                                   uint64_t painted[KW_MAX],
                                   const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
                                   int &pixel_counter) {
@@ -823,6 +845,7 @@ __device__ bool paint_shots_union(const PartDev &P, double radius, const double 
         if (re[r] <= rb[r]) continue;
         const int wlast = (re[r] - 1) >> 6;
         for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
+            WCNT(5, 1);
             const int s = (w << 6) + lane;
             const double x = P.samp[0][s], y = P.samp[1][s], z = P.samp[2][s];
             const bool in = (s >= rb[0] && s < re[0]) || (s >= rb[1] && s < re[1]) || (s >= rb[2] && s < re[2]) ||
@@ -867,7 +890,7 @@ __device__ bool paint_shots_union(const PartDev &P, double radius, const double 
 }
 
 // ---------------------------------------------------------------- observation (rge:306-319)
-__device__ __forceinline__ int grid_index_2(const PartDev &P, double val) {
+__device__ __forceinline__ int grid_index_2(PartRef P, double val) {
     const double rel = (val - P.r2min) / (P.r2max - P.r2min);
     const double g = rel * GRID_GRANULARITY;
     int gi;
@@ -900,7 +923,7 @@ __device__ __forceinline__ double py_floor_div(double vx, double wx) {
 // bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
 // is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
 template <int KW>
-__device__ void section_general_wave(const PartDev &P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
+__device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
                                      int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     cnt[lane] = 0;
@@ -932,7 +955,7 @@ __device__ void section_general_wave(const PartDev &P, int g, double x1, double 
 // GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
 // its registers or code.
 template <int KW, bool GENSEC>
-__device__ void observation_wave(const PartDev &P, const PrlConfig &C, const double pose[3],
+__device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
                                  const uint64_t painted[KW_MAX], int lane, double *out) {
     // bpw:965-978 get_normalized_pose
     const double r = C.paint_radius;
@@ -1016,38 +1039,23 @@ __device__ void observation_wave(const PartDev &P, const PrlConfig &C, const dou
 #ifdef PRL_ABLATE_STRADDLE
         sm = 0;
 #endif
-        while (sm) {                                // wave-uniform loop over the words that straddle the tool,
-            int L[4];                               // four per trip so eight loads are in flight
-            bool use[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                use[j] = sm != 0;
-                L[j] = use[j] ? __builtin_ctzll(sm) : L[0];
-                sm &= sm - (use[j] ? 1 : 0);
-            }
-            double xs[4], ys[4];
-            uint64_t vs[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int w2 = L[j] + 64 * k;
-                xs[j] = sx[(w2 << 6) + lane];
-                ys[j] = sy[(w2 << 6) + lane];
-                vs[j] = P.word_valid[w2];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!use[j]) continue;
-                // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
-                // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
-                // 64 straddling words)
-                const uint64_t pw = bcast_u64(painted[k], L[j]);
-                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs[j]) && !(xs[j] == x1 && ys[j] == x2);
-                const bool gy = ys[j] > x2, lx = xs[j] < x1;
-                const uint32_t sh = (xs[j] > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys[j] < x2) ? 16u : 24u));
-                const uint32_t one = cnt ? (1u << sh) : 0u;
-                tot_s += one;
-                und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
-            }
+        while (sm) {                                // wave-uniform loop over the words that straddle the tool
+            WCNT(6, 1);
+            const int L = __builtin_ctzll(sm);
+            sm &= sm - 1;
+            const int w2 = L + 64 * k;
+            const double xs = sx[(w2 << 6) + lane], ys = sy[(w2 << 6) + lane];
+            const uint64_t vs = P.word_valid[w2];
+            // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
+            // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
+            // 64 straddling words)
+            const uint64_t pw = bcast_u64(painted[k], L);
+            const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs) && !(xs == x1 && ys == x2);
+            const bool gy = ys > x2, lx = xs < x1;
+            const uint32_t sh = (xs > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys < x2) ? 16u : 24u));
+            const uint32_t one = cnt ? (1u << sh) : 0u;
+            tot_s += one;
+            und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
         }
     }
     // widen the 8-bit straddle counters into the 16-bit fields
@@ -1107,7 +1115,7 @@ __device__ __forceinline__ void store_state(double *dst, const EnvState &S, int 
     if (lane < PRL_STATE_DOUBLES) dst[lane] = v;
 }
 
-__device__ __forceinline__ void reset_state(const PartDev &P, EnvState &S, int start) {   // rge:370-387, rob:366-372
+__device__ __forceinline__ void reset_state(PartRef P, EnvState &S, int start) {   // rge:370-387, rob:366-372
     S.pose[0] = P.start_pos[3 * start];
     S.pose[1] = P.start_pos[3 * start + 1];
     S.pose[2] = P.start_pos[3 * start + 2];
@@ -1150,12 +1158,12 @@ __device__ __forceinline__ void store_masks(const StepArgs &a, int env, int n_wo
     }
 }
 
-__host__ __device__ inline int obs_dim_of(const PrlConfig &c) {          // rge:166-173
-    switch (c.obs_mode) {
-    case PRL_OBS_SECTION: return c.obs_grad + 2;
-    case PRL_OBS_GRID: return c.obs_grad * c.obs_grad;
+__host__ __device__ inline int obs_dim_of(int obs_mode, int obs_grad) {          // rge:166-173
+    switch (obs_mode) {
+    case PRL_OBS_SECTION: return obs_grad + 2;
+    case PRL_OBS_GRID: return obs_grad * obs_grad;
     case PRL_OBS_SIMPLE: return 2;
-    default: return c.obs_grad + 1;
+    default: return obs_grad + 1;
     }
 }
 
@@ -1166,8 +1174,8 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     if (a.reset_mask && !a.reset_mask[env]) return;
-    const PartDev &P = a.parts[a.env_part ? a.env_part[env] : 0];
-    const PrlConfig &C = *a.cfg;
+    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
@@ -1175,7 +1183,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C));
+    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad));
 }
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
@@ -1187,11 +1195,16 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     if (env >= a.n_envs) return;
 #ifdef PRL_WAVE_TIMES
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wave_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int part_id = a.env_part ? a.env_part[env] : 0;
-    const PartDev &P = a.parts[part_id];
-    const PrlConfig &C = *a.cfg;
-    const int od = obs_dim_of(C);
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    const int od = obs_dim_of(C.obs_mode, C.obs_grad);
+#ifdef PRL_REPEAT          // diagnostic build: PRL_REPEAT whole steps per launch (cold-start vs steady-state cost)
+  for (int prl_rep = 0; prl_rep < PRL_REPEAT; ++prl_rep) {
+    __threadfence();
+#endif
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
 #ifdef PRL_PHASE_TIMING
@@ -1438,13 +1451,27 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
 #ifdef PRL_WAVE_TIMES      // diagnostic build: wave lifetime and on-part shot count into final_obs[env][0..1]
     if (lane == 0 && a.final_obs) {
         a.final_obs[(size_t)env * od] = (double)(__builtin_amdgcn_s_memtime() - wave_t0);
-        a.final_obs[(size_t)env * od + 1] = (double)(S.terminate_counter - counter_before);
+        uint32_t *wc = g_wcnt[env & 0xffff];       // misses:3 dn:1 | general rays:4 | stage 1:4 | chunk tests:6 |
+        const uint64_t packed =                    // vertex batches:8 | extra rings:4 | paint words:8 | straddle words:8
+            (uint64_t)(S.terminate_counter - counter_before) | ((uint64_t)dn << 3) | ((uint64_t)(wc[0] & 15) << 4) |
+            ((uint64_t)(wc[1] & 15) << 8) | ((uint64_t)(wc[2] & 63) << 12) | ((uint64_t)(wc[3] & 255) << 18) |
+            ((uint64_t)(wc[4] & 15) << 26) | ((uint64_t)(wc[5] & 255) << 30) | ((uint64_t)(wc[6] & 255) << 38);
+        for (int k = 0; k < 8; ++k) wc[k] = 0;
+        a.final_obs[(size_t)env * od + 1] = (double)packed;
         a.final_obs[(size_t)env * od + 2] = (double)dn;
+        a.final_obs[(size_t)env * od + 3] = (double)wave_r0;                              // 100 MHz wall clock
+        a.final_obs[(size_t)env * od + 4] = (double)__builtin_amdgcn_s_memrealtime();
+        a.final_obs[(size_t)env * od + 5] =                                               // HW_ID + 2^32 * XCC_ID
+            (double)(((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
+                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
     }
 #endif
 #ifdef PRL_PHASE_TIMING
     if (lane == 0)
         for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], prof.acc[k]);
+#endif
+#ifdef PRL_REPEAT
+  }
 #endif
 }
 
@@ -1458,7 +1485,7 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int
     const double e[3] = {to[3 * r], to[3 * r + 1], to[3 * r + 2]};
     double t, hit[3] = {0, 0, 0};
     int hint = -1;
-    const int idx = ray_closest_wave(*part, o, e, lane, t, hit, hint);
+    const int idx = ray_closest_wave(*(const PartDev CAS *)part, o, e, lane, t, hit, hint);
     if (lane == 0) {
         tri[r] = idx;
         frac[r] = t;
@@ -1708,7 +1735,7 @@ const char *prl_last_error(void) { return g_error; }
 
 int prl_obs_dim(const PrlConfig *cfg) {
     if (!cfg) return fail(PRL_E_INVALID, "null config");
-    return obs_dim_of(*cfg);
+    return obs_dim_of(cfg->obs_mode, cfg->obs_grad);
 }
 
 int prl_struct_sizes(int *config_bytes, int *part_tables_bytes) {
