@@ -47,7 +47,10 @@ typedef struct PrlBatch PrlBatch;   /* N environments: coverage masks + scalar s
  * All arrays are host pointers, copied by prl_part_create.
  */
 typedef struct {
-    /* coverage samples in device order (sorted by sample-grid cell), padded to a multiple of 64 */
+    /* coverage samples in device order, padded to a multiple of 64: sorted by sample-grid cell row, then
+       ascending on axis a1 (which also orders a row by cell).  prl_part_create rejects a table in which the
+       64 samples of a word do not ascend on axis a1: the 4-sector observation finds the samples left and
+       right of the tool by binary search in the word. */
     int32_t n_samples;            /* real samples (bpw Part.get_job_limit) */
     int32_t n_samples_pad;
     const double *sample_xyz[3];  /* world x, y, z, [n_samples_pad]; pads are far away */

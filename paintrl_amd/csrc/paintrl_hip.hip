@@ -55,6 +55,7 @@ typedef const double GAS *gdouble_p;
 typedef const float GAS *gfloat_p;
 typedef const int GAS *gint_p;
 typedef const uint64_t GAS *gu64_p;
+typedef const uint8_t GAS *gu8_p;
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -66,6 +67,7 @@ struct PartDev {
     gdouble_p word_bbox;
     gu64_p word_valid;
     gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
+    gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     double sg_o1, sg_o2, sg_inv;
     int sg_nx, sg_ny;
     gint_p sg_start;
@@ -1019,23 +1021,76 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
     uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
+    // Pass 1, one word per lane and slot: a word whose box lies in one sector is counted whole.  A word
+    // that straddles only the vertical line x1 (its row is clear of x2) is resolved by its own lane
+    // below; only the rest -- the words of the row that x2 crosses -- is classified sample by sample.
+    bool vline[KW_MAX] = {false, false, false, false}, above[KW_MAX] = {false, false, false, false};
+    uint64_t valid[KW_MAX] = {0, 0, 0, 0}, smask[KW_MAX] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * k;
         bool straddle = false;
         if (w < P.n_words) {
             const f64x4 bb = reinterpret_cast<const f64x4 GAS *>(P.word_bbox)[w];
-            const uint64_t valid = P.word_valid[w];
+            valid[k] = P.word_valid[w];
             const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
             if ((xg || xl) && (yg || yl)) {
                 const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
-                tot_l += (uint64_t)__popcll(valid) << (16 * idx);
-                und_l += (uint64_t)__popcll(valid & ~painted[k]) << (16 * idx);
-            } else {
-                straddle = valid != 0;
+                tot_l += (uint64_t)__popcll(valid[k]) << (16 * idx);
+                und_l += (uint64_t)__popcll(valid[k] & ~painted[k]) << (16 * idx);
+            } else if (valid[k] != 0) {
+                vline[k] = yg || yl;
+                above[k] = yg;
+                straddle = !vline[k];
             }
         }
-        uint64_t sm = __ballot(straddle);
+        smask[k] = __ballot(straddle);
+    }
+#ifndef PRL_ABLATE_STRADDLE
+    // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
+    // { xs > x1 } a suffix of the word: a 7-probe lower bound by the owning lane, all rows at once.
+    // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
+    {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) any = any || vline[k];
+        if (__ballot(any)) {
+            int base[KW_MAX], pos[KW_MAX];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                base[k] = vline[k] ? (lane + 64 * k) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
+                pos[k] = 0;
+            }
+#pragma unroll
+            for (int step = 32; step >= 0; step = step > 1 ? step >> 1 : step - 1) {   // 32 .. 1, then the closing probe
+                double probe[KW_MAX];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) probe[k] = sx[base[k] + pos[k] + (step ? step - 1 : 0)];
+                __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip per step
+#pragma unroll
+                for (int k = 0; k < KW; ++k) pos[k] += probe[k] < x1 ? (step ? step : 1) : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int at = base[k] + (pos[k] < 64 ? pos[k] : 63);
+                int ub = (pos[k] < 64 && sx[at] == x1) ? (int)P.samp_ub[at] : pos[k];
+                if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
+                if (vline[k]) {
+                    const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
+                    const uint64_t ng = ub >= 64 ? ~0ull : ((1ull << ub) - 1);
+                    const uint64_t v = valid[k], u = valid[k] & ~painted[k];
+                    const uint64_t vg = __popcll(v & ~ng), vl = __popcll(v & lt), ve = __popcll(v) - vg - vl;
+                    const uint64_t ug = __popcll(u & ~ng), ul = __popcll(u & lt), ue = __popcll(u) - ug - ul;
+                    tot_l += above[k] ? (vg | (vl << 16) | (ve << 48)) : ((vl << 32) | ((vg + ve) << 48));
+                    und_l += above[k] ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
+                }
+            }
+        }
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        uint64_t sm = smask[k];
 #ifdef PRL_ABLATE_STRADDLE
         sm = 0;
 #endif
@@ -1663,6 +1718,22 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         return fail(PRL_E_INVALID, "axes must be a permutation of 0,1,2");
     d.samp_a1 = d.samp[d.a1];
     d.samp_a2 = d.samp[d.a2];
+    {   // the samples of a word ascend on axis a1 (paintrl.h); derive the equal-run ends the observation uses
+        const double *x = t->sample_xyz[d.a1];
+        std::vector<uint8_t> ub((size_t)t->n_samples_pad);
+        for (int w = 0; w < d.n_words; ++w) {
+            const double *xw = x + (size_t)w * 64;
+            for (int j = 1; j < 64; ++j)
+                if (!(xw[j - 1] <= xw[j]))
+                    return fail(PRL_E_INVALID, "samples of word %d do not ascend on axis %d", w, d.a1);
+            int end = 64;
+            for (int j = 63; j >= 0; --j) {
+                if (j < 63 && xw[j] != xw[j + 1]) end = j + 1;
+                ub[(size_t)w * 64 + j] = (uint8_t)end;
+            }
+        }
+        UP(samp_ub, ub.data(), ub.size());
+    }
     d.n_start = t->n_start;
     if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
     UP(start_pos, t->start_pos, (size_t)d.n_start * 3);

@@ -37,7 +37,10 @@ class DeviceTables(object):
         cy = np.floor((t.sample_pos[:, a2] - o2) * inv).astype(np.int64)
         nx, ny = int(cx.max()) + 1, int(cy.max()) + 1
         cell = cy * nx + cx
-        order = np.argsort(cell, kind='stable')
+        # within a cell row the samples ascend on axis a1 (which also orders them by cell): the samples
+        # left / right of a vertical section line are then a prefix / suffix of every word of the row,
+        # found by binary search instead of a per-sample pass (observation of the 4-sector rule)
+        order = np.lexsort((np.arange(P), t.sample_pos[:, a1], cy))
         per_cell = np.bincount(cell, minlength=nx * ny)
         starts = np.zeros(nx * ny + 1, dtype=np.int64)
         pos = 0

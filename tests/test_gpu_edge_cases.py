@@ -104,6 +104,11 @@ def test_error_codes_and_messages():
     st = dt.c_struct()
     st.sgrid_start = bad.ctypes.data_as(_lib._ip)
     assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -1 and b'non-decreasing' in lib.prl_last_error()
+    shuffled = dt.sample_xyz[tables.a1].copy()                        # a word whose samples do not ascend on a1
+    shuffled[[0, 1]] = shuffled[[1, 0]] if shuffled[0] != shuffled[1] else (shuffled[1] + 1.0, shuffled[1])
+    st = dt.c_struct()
+    st.sample_xyz[tables.a1] = shuffled.ctypes.data_as(_lib._dp)
+    assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -1 and b'do not ascend' in lib.prl_last_error()
     assert lib.prl_batch_step(None, None, None, None, None, None, None, None, None) == -1
     assert config.make_config().auto_reset == 0
 

@@ -104,6 +104,12 @@ def test_device_layout_invariants(name):
     assert int(np.unpackbits(d.word_valid.view(np.uint8)).sum()) == P
     o1, o2, inv, nx, ny = d.sgrid
     assert (d.sgrid_start[::nx][:ny] % 64 == 0).all()          # every cell row starts on a word
+    # the samples of a word ascend on axis a1, pads (far away) last: the observation's binary search and
+    # prl_part_create's validation rely on it
+    xw = d.sample_xyz[t.a1].reshape(d.n_words, 64)
+    assert (np.diff(xw, axis=1) >= 0).all()
+    vw = valid.reshape(d.n_words, 64)
+    assert (vw[:, :-1] | ~vw[:, 1:]).all()                      # no real sample after a pad
     # every sample within the paint radius of a random centre lies in the 3x3 cell block the kernel scans
     rng = np.random.RandomState(0)
     xyz = np.stack(d.sample_xyz, axis=1)
