@@ -167,8 +167,10 @@ int prl_batch_set_pose(PrlBatch *batch, int env_index, const double *pos, const 
  * device sample order, u64[N][mask_stride]. */
 int prl_batch_get_mask(PrlBatch *batch, uint64_t *painted, void *stream);
 /* Per-env scalar state f64[N][PRL_STATE_DOUBLES]: pose[3] quat[4] last_turning_angle total_reward
- * total_return {i32 terminate, terminate_counter} {i32 last_on_part, step_counter} episode_count(u64)
- * last_episode_return last_episode_reward {i32 last_episode_len, last_episode_painted}. */
+ * total_return {i32 terminate, terminate_counter} {i32 last_on_part, step_counter}
+ * {u32 episode_count, i32 facet_hint} last_episode_return last_episode_reward
+ * {i32 last_episode_len, last_episode_painted}.  facet_hint is a cache (the collision triangle the
+ * previous ray hit, -1 = none), not reference state: any value gives the same results. */
 int prl_batch_get_state(PrlBatch *batch, double *state, void *stream);
 /* Episode returns (rge:359-360 _total_return of the last finished episode) -- the RCCL gather payload. */
 int prl_batch_get_returns(PrlBatch *batch, double *episode_return, void *stream);

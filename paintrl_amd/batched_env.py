@@ -174,7 +174,7 @@ class BatchedPaintEnv(object):
                 'total_reward': r[:, 8].copy(), 'total_return': r[:, 9].copy(),
                 'terminate': ints[:, 20].copy(), 'terminate_counter': ints[:, 21].copy(),
                 'last_on_part': ints[:, 22].copy(), 'step_counter': ints[:, 23].copy(),
-                'episode': r[:, 12].view(np.uint64).copy(),
+                'episode': ints[:, 24].view(np.uint32).astype(np.uint64), 'facet_hint': ints[:, 25].copy(),
                 'last_episode_return': r[:, 13].copy(), 'last_episode_reward': r[:, 14].copy(),
                 'last_episode_len': ints[:, 30].copy(), 'last_episode_painted': ints[:, 31].copy()}
 

@@ -1155,7 +1155,8 @@ struct EnvState {                 // PRL_STATE_DOUBLES record
     double pose[3], quat[4];
     double last_angle, total_reward, total_return;
     int terminate, terminate_counter, last_on_part, step_counter;
-    uint64_t episode;
+    uint32_t episode;
+    int facet_hint;               // collision triangle the last ray of the previous step hit (-1: none); a cache
     double last_ep_return, last_ep_reward;
     int last_ep_len, last_ep_painted;
 };
@@ -1186,6 +1187,7 @@ __device__ __forceinline__ void reset_state(PartRef P, EnvState &S, int start) {
     S.last_on_part = 1;
     S.step_counter = 0;
     S.episode += 1;
+    S.facet_hint = -1;
 }
 
 template <int KW>
@@ -1314,7 +1316,8 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) cur_norm[k] = uni_d(cur_norm[k]);
     const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
-    int facet_hint = -1;                        // facet hit by the previous sub-shot's ray (convex fast path)
+    // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
+    int facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
     uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
     uint32_t n_succeeded_l = 0;
     __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
@@ -1443,6 +1446,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         }
     }
     STAMP(PH_BALL);
+    S.facet_hint = facet_hint;
     const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
 
@@ -1989,6 +1993,7 @@ int prl_batch_set_pose(PrlBatch *b, int env_index, const double *pos, const doub
     S.terminate_counter = 0;
     S.last_on_part = 1;
     S.last_angle = 0;
+    S.facet_hint = -1;
     HIP_TRY(hipMemcpy(rec, &S, sizeof S, hipMemcpyHostToDevice));
     return PRL_OK;
 }
