@@ -51,6 +51,7 @@ constexpr double PI = 3.141592653589793;
 // space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
 // (address space 1) gives global_load with counted vmcnt waits.
 #define GAS __attribute__((address_space(1)))
+#define CAS __attribute__((address_space(4)))
 typedef const double GAS *gdouble_p;
 typedef const float GAS *gfloat_p;
 typedef const int GAS *gint_p;
@@ -90,6 +91,7 @@ struct PartDev {
     gint_p col_rank;
     int col_convex, nbr_width;
     gint_p col_nbr, col_orient;
+    gdouble_p col_rec;            // convex sets: [n_col_pad][12] v0 e1 e2 | edge margin | |e1 x e2|^2 | orient (derived in part_fill)
     int n_col_chunks;
     gfloat_p col_chunk_bbox;
     gdouble_p grid_lo, grid_hi;
@@ -104,7 +106,6 @@ struct PartDev {
 // The part descriptor and the batch configuration are read-only for every kernel: typed as constant
 // address space so that their fields are fetched with scalar loads (s_load through the K$) instead
 // of wave-uniform vector loads the compiler has to assume the kernel's own stores may clobber.
-#define CAS __attribute__((address_space(4)))
 typedef const PartDev CAS &PartRef;
 typedef const PrlConfig CAS &CfgRef;
 
@@ -305,6 +306,8 @@ __device__ __forceinline__ int cell_coord(double x, double origin, double inv, i
 }
 
 // ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
+#define FACET_EDGE_MARGIN 1.0e-6     // metres from every edge of the entered facet (single-facet fast path)
+#define FACET_MIN_COS2 0.01          // squared cosine between segment and facet normal: no grazing entries
 // Cull before the float64 Moller-Trumbore test:
 //   * 3-D float boxes (rounded outward) per triangle and per 64-triangle chunk; lane c tests chunk c,
 //     only surviving chunks are visited (one triangle per lane, boxes + 9 doubles in one round trip);
@@ -398,6 +401,43 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
     hint = -1;
 #endif
     if (P.col_convex && hint >= 0) {
+        // (1) The previous facet alone, wave-uniform on scalar-loaded data.  If the segment ENTERS the hull
+        // through it at a point at least FACET_EDGE_MARGIN away from its edges, and not at a grazing
+        // angle, no other facet can report a hit at or before that point: a second hit there would lie
+        // in the other facet's 1e-9 tolerance fringe, i.e. within nanometres of an edge of the entered
+        // facet.  The result is then this facet's own Moller-Trumbore value, arithmetic as in mt_one.
+        {
+            const int h = rfl(hint);
+            const double CAS *r = reinterpret_cast<const double CAS *>((uint64_t)P.col_rec) + (size_t)h * 12;
+            const double e10 = r[3], e11 = r[4], e12 = r[5], e20 = r[6], e21 = r[7], e22 = r[8];
+            const double p0 = d1 * e22 - d2 * e21;
+            const double p1 = d2 * e20 - d0 * e22;
+            const double p2 = d0 * e21 - d1 * e20;
+            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+            bool inside = false;
+            double t = 0;
+            if (fabs(det) >= RAY_EPS_DET) {
+                const double inv = 1.0 / det;
+                const double s0 = o[0] - r[0], s1 = o[1] - r[1], s2 = o[2] - r[2];
+                const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+                const double q0 = s1 * e12 - s2 * e11;
+                const double q1 = s2 * e10 - s0 * e12;
+                const double q2 = s0 * e11 - s1 * e10;
+                const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+                t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+                const double m = r[9], dd = (d0 * d0 + d1 * d1) + d2 * d2;
+                inside = u >= m && v >= m && (u + v) <= 1.0 - m && t >= 0.0 && t <= 1.0 && r[11] * det > 0 &&
+                         det * det >= FACET_MIN_COS2 * dd * r[10];
+            }
+            if (rfl(inside)) {
+                t_out = t;
+                hit[0] = o[0] + t * d0;
+                hit[1] = o[1] + t * d1;
+                hit[2] = o[2] + t * d2;
+                return reinterpret_cast<const int CAS *>((uint64_t)P.col_rank)[h];
+            }
+        }
+        // (2) the facets that share a vertex with it
         const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
         mt_one(P, i1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
         win = ray_winner_lane(best_t, best_r, tmin);
@@ -1703,6 +1743,27 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             if (t->col_nbr[k] < -1 || t->col_nbr[k] >= d.n_col_pad) return fail(PRL_E_INVALID, "col_nbr entry out of range");
         UP(col_nbr, t->col_nbr, (size_t)d.n_col_pad * d.nbr_width);
         UP(col_orient, t->col_orient, d.n_col_pad);
+        // per-facet record of the single-facet fast path (ray_closest_wave): geometry, the barycentric
+        // margin that keeps a hit FACET_EDGE_MARGIN away from every edge, |e1 x e2|^2, orientation
+        std::vector<double> rec((size_t)d.n_col_pad * 12, 0.0);
+        for (int i = 0; i < d.n_col_pad; ++i) {
+            double *r = rec.data() + (size_t)i * 12;
+            for (int k = 0; k < 9; ++k) r[k] = t->col_v0e1e2[k][i];
+            const double *e1 = r + 3, *e2 = r + 6;
+            const double n0 = e1[1] * e2[2] - e1[2] * e2[1], n1 = e1[2] * e2[0] - e1[0] * e2[2],
+                         n2 = e1[0] * e2[1] - e1[1] * e2[0];
+            const double nn = n0 * n0 + n1 * n1 + n2 * n2;
+            const double l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+            const double l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+            const double f0 = e2[0] - e1[0], f1 = e2[1] - e1[1], f2 = e2[2] - e1[2];
+            const double l3 = f0 * f0 + f1 * f1 + f2 * f2;
+            const double lmax = std::max(l1, std::max(l2, l3));
+            const double hmin = lmax > 0 ? std::sqrt(nn / lmax) : 0.0;          // smallest height of the facet
+            r[9] = hmin > 0 ? FACET_EDGE_MARGIN / hmin : INFINITY;              // never met by a sliver
+            r[10] = nn;
+            r[11] = (double)t->col_orient[i];                                   // 0 for pads: never entered
+        }
+        UP(col_rec, rec.data(), rec.size());
     }
     d.n_col_chunks = t->n_col_chunks;
     if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
