@@ -372,6 +372,43 @@ __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], doub
     }
 }
 
+// The same test on the facet record of a convex set (one 96-byte gather per lane instead of ten
+// strided loads); `interior` reports a hit that meets the single-facet criterion of ray_closest_wave.
+__device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
+                                       double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
+    interior = false;
+    if (i >= 0) {
+        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec + (size_t)i * 12);
+        const f64x2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+        const int rk = P.col_rank[i];
+        const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
+        const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
+        const double p0 = d1 * e22 - d2 * e21;
+        const double p1 = d2 * e20 - d0 * e22;
+        const double p2 = d0 * e21 - d1 * e20;
+        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+        if (fabs(det) >= RAY_EPS_DET) {
+            const double inv = 1.0 / det;
+            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+            const double q0 = s1 * e12 - s2 * e11;
+            const double q1 = s2 * e10 - s0 * e12;
+            const double q2 = s0 * e11 - s1 * e10;
+            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= 1.0 &&
+                (t < best_t || (t == best_t && rk < best_r))) {
+                best_t = t;
+                best_r = rk;
+                best_i = i;
+                best_det = det;
+                interior = u >= m && v >= m && (u + v) <= 1.0 - m && orient * det > 0 &&
+                           det * det >= FACET_MIN_COS2 * dd * nn;
+            }
+        }
+    }
+}
+
 // Lane holding the wave's best (t, rank); -1 if no lane has a hit.
 __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
     if (__ballot(best_t < INFINITY) == 0) return -1;
@@ -430,6 +467,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
                          det * det >= FACET_MIN_COS2 * dd * r[10];
             }
             if (rfl(inside)) {
+                WCNT(7, 1);
                 t_out = t;
                 hit[0] = o[0] + t * d0;
                 hit[1] = o[1] + t * d1;
@@ -437,22 +475,36 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
                 return reinterpret_cast<const int CAS *>((uint64_t)P.col_rank)[h];
             }
         }
-        // (2) the facets that share a vertex with it
+        // (2) The facets that share a vertex with it, one per lane.  A lane whose facet is entered at an
+        // interior point holds the closest hit of the whole set by the same argument (there is at most
+        // one such lane): no reduction, no second round.
+        WCNT(4, 1);
+        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
         const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
-        mt_one(P, i1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
-        win = ray_winner_lane(best_t, best_r, tmin);
-        if (win >= 0) {
-            const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
-            const double fdet = bcast_d(best_det, win);
-            const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
-            const bool entering = (double)P.col_orient[f] * fdet > 0;
-            if (entering && __ballot(i2 >= 0) != 0) {
-                if (f != hint) {
-                    mt_one(P, i2, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
-                    win = ray_winner_lane(best_t, best_r, tmin);
+        bool interior;
+        mt_rec(P, i1, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+        const uint64_t im = __ballot(interior);
+        if (im) {
+            win = __builtin_ctzll(im);
+            tmin = bcast_d(best_t, win);
+        } else {
+            // (3) otherwise the closest hit there, if it enters the hull, decides after a look at its own
+            // neighbourhood
+            win = ray_winner_lane(best_t, best_r, tmin);
+            if (win >= 0) {
+                const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
+                const double fdet = bcast_d(best_det, win);
+                const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
+                const bool entering = (double)P.col_orient[f] * fdet > 0;
+                if (entering && __ballot(i2 >= 0) != 0) {
+                    if (f != hint) {
+                        WCNT(4, 16);
+                        mt_rec(P, i2, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+                        win = ray_winner_lane(best_t, best_r, tmin);
+                    }
+                } else {
+                    win = -1;
                 }
-            } else {
-                win = -1;
             }
         }
         if (win < 0) {
@@ -612,7 +664,6 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
-        if (ring > 1) WCNT(4, 1);
         for (int c0 = 0; c0 < total; c0 += 64) {
             WCNT(3, 1);
             const int c = c0 + lane;
@@ -1378,9 +1429,24 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         hit[1] = pt[1] + 0.1 * cur_norm[1];
         hit[2] = pt[2] + 0.1 * cur_norm[2];
 #else
+#ifdef PRL_DOUBLE_RAY                       // diagnostic build: the phase runs twice, the first result is discarded
+        {
+            double t2, h2[3] = {0, 0, 0};
+            int hint2 = facet_hint;
+            const int r2 = ray_closest_wave(P, pt, end, lane, t2, h2, hint2);
+            asm volatile("" ::"v"(t2), "v"(h2[0]), "v"(h2[1]), "v"(h2[2]), "s"(r2), "s"(hint2));
+        }
+#endif
         bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint) >= 0;
 #endif
         STAMP(PH_RAY);
+#ifdef PRL_DOUBLE_HOOK
+        if (on) {
+            double p2[3] = {0, 0, 0}, o2[3] = {0, 0, 0};
+            const bool b2 = hook_point_wave(P, hit, lane, p2, o2 PROF_PASS);
+            asm volatile("" ::"v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(o2[0]), "v"(o2[1]), "v"(o2[2]), "s"((int)b2));
+        }
+#endif
         if (on) on = hook_point_wave(P, hit, lane, pos, orn PROF_PASS);
         if (!on) {
             orn[0] = cur_norm[0];
@@ -1459,6 +1525,15 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
 #ifdef PRL_ABLATE_BALL
         if (true) {
 #else
+#ifdef PRL_DOUBLE_BALL
+        {
+            uint64_t p2[KW_MAX], l2[KW_MAX] = {0, 0, 0, 0};
+            int s2 = 0, c2 = 0;
+            for (int k = 0; k < KW_MAX; ++k) p2[k] = painted[k];
+            const bool b2 = paint_shots_union<KW>(P, C.paint_radius, cen, lane, p2, last, l2, s2, c2);
+            asm volatile("" ::"v"(p2[0]), "v"(l2[0]), "v"(p2[1]), "v"(l2[1]), "v"(p2[2]), "v"(l2[2]), "s"(s2), "s"(c2), "s"((int)b2));
+        }
+#endif
         if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
 #endif
 #pragma unroll
@@ -1515,6 +1590,10 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     double *obs_row = a.obs + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
 #ifndef PRL_ABLATE_OBS
+#ifdef PRL_DOUBLE_OBS
+    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
     if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
 #endif
     if (lane == 0) {
@@ -1554,7 +1633,8 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         const uint64_t packed =                    // vertex batches:8 | extra rings:4 | paint words:8 | straddle words:8
             (uint64_t)(S.terminate_counter - counter_before) | ((uint64_t)dn << 3) | ((uint64_t)(wc[0] & 15) << 4) |
             ((uint64_t)(wc[1] & 15) << 8) | ((uint64_t)(wc[2] & 63) << 12) | ((uint64_t)(wc[3] & 255) << 18) |
-            ((uint64_t)(wc[4] & 15) << 26) | ((uint64_t)(wc[5] & 255) << 30) | ((uint64_t)(wc[6] & 255) << 38);
+            ((uint64_t)(wc[4] & 15) << 26) | ((uint64_t)(wc[5] & 255) << 30) | ((uint64_t)(wc[6] & 255) << 38) |
+            ((uint64_t)(wc[7] & 15) << 46) | ((uint64_t)((wc[4] >> 4) & 15) << 50);
         for (int k = 0; k < 8; ++k) wc[k] = 0;
         a.final_obs[(size_t)env * od + 1] = (double)packed;
         a.final_obs[(size_t)env * od + 2] = (double)dn;

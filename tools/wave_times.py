@@ -36,7 +36,7 @@ for k in range(300):
         pk = f[:, 1].astype(np.int64)
         M.append((pk & 7).astype(np.float64))
         K.append(np.stack([(pk >> 4) & 15, (pk >> 8) & 15, (pk >> 12) & 63, (pk >> 18) & 255, (pk >> 26) & 15,
-                           (pk >> 30) & 255, (pk >> 38) & 255], axis=1).astype(np.float64))
+                           (pk >> 30) & 255, (pk >> 38) & 255, (pk >> 46) & 15, (pk >> 50) & 15], axis=1).astype(np.float64))
         D.append(f[:, 2].copy())
         R.append(f[:, 3:6].copy())
 mx = np.array([t.max() for t in T])
@@ -69,7 +69,8 @@ if len(T) > 1:
     print('  corr of an env\'s lifetime between consecutive sampled launches: %.2f' % np.corrcoef(T[0], T[1])[0, 1])
 T, M, D = np.concatenate(T), np.concatenate(M), np.concatenate(D)
 K = np.concatenate(K)
-names = ['general rays', 'ray stage 1', 'chunk tests', 'vertex batches', 'extra rings', 'paint words', 'straddle words']
+names = ['general rays', 'ray stage 1', 'chunk tests', 'vertex batches', 'nbr-path rays', 'paint words', 'straddle words',
+         'single-facet rays', '2nd nbr rounds']
 sel = D == 0
 A = np.column_stack([K[sel], np.ones(sel.sum())])
 coef, *_ = np.linalg.lstsq(A, T[sel], rcond=None)
