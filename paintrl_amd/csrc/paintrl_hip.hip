@@ -741,7 +741,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
             }
         }
         dmin = wave_min_d(best_d);
-        const double lim = ring * P.vg_accept;
+        const double lim = ring * (0.99 / P.sg_inv);        // ring * 0.99 * sample cell
         exact = dmin <= lim * lim;
     }
 #ifdef PRL_FORCE_FULL_SCANS
@@ -775,6 +775,12 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
 #ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
     const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
 #else
+#ifdef PRL_DOUBLE_VERTEX
+    {
+        const int v2 = nearest_vertex_wave(P, pt, lane);
+        asm volatile("" ::"s"(v2));
+    }
+#endif
     const int vidx = nearest_vertex_wave(P, pt, lane);
 #endif
     STAMP(PH_VERTEX);
@@ -962,14 +968,15 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
                     lw = bcast_u64(last[k], owner);
                 }
             if (any == 0 && lw == 0) continue;       // nothing to record for this word
-            uint64_t uw = 0;
+            // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
+            // affected), folded: the newly painted samples of the five shots are the union minus what was
+            // painted before, and each shot's valid set only looks one shot back
+            succeeded += __popcll(any & ~pw);
+            pw |= any;
+            uint64_t uw = b[0] & ~lw;
 #pragma unroll
-            for (int k = 0; k < PAINT_PER_ACTION; ++k) {             // scalar-unit bookkeeping, shot by shot
-                succeeded += __popcll(b[k] & ~pw);
-                pw |= b[k];
-                uw |= b[k] & ~lw;
-                lw = b[k];
-            }
+            for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
+            lw = b[PAINT_PER_ACTION - 1];
             pixel_counter += __popcll(uw);
 #pragma unroll
             for (int k = 0; k < KW; ++k)

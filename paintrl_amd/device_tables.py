@@ -103,6 +103,13 @@ class DeviceTables(object):
         side_ids = np.nonzero(t.vertex_is_side)[0]
         vpos = t._side_data[side_ids]
         vo1, vo2 = float(vpos[:, a1].min()), float(vpos[:, a2].min())
+        # The vertex grid has its own cell parameter but uses the sample cell: the query points are ray hits
+        # on the collision set (in hull mode up to centimetres above the surface), and the ring search
+        # accepts a block only when the 3-D distance of the best vertex is within ring * 0.99 * cell.  A
+        # cell sized to the vertex density alone (0.03 on the door) sends most searches to rings 2-3
+        # (measured: 58.6 -> 85.6 us per step).
+        self.vcell = self.cell
+        inv = 1.0 / self.vcell
         vcx = np.floor((vpos[:, a1] - vo1) * inv).astype(np.int64)
         vcy = np.floor((vpos[:, a2] - vo2) * inv).astype(np.int64)
         vnx, vny = int(vcx.max()) + 1, int(vcy.max()) + 1
@@ -112,7 +119,7 @@ class DeviceTables(object):
         self.vertex_rank = vorder.astype(np.int32)            # rank in the reference's vertex order
         self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
         self.vgrid = (vo1, vo2, inv, vnx, vny)
-        self.vgrid_accept = 0.99 * self.cell
+        self.vgrid_accept = 0.99 * self.vcell
         front_ids = np.nonzero(t.tri_side == pt.SIDE_FRONT)[0]
         compact = -np.ones(t.tri_side.shape[0], dtype=np.int64)
         compact[front_ids] = np.arange(front_ids.size)
