@@ -1481,10 +1481,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             S.pose[k] = pos[k];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            quat[k] = uni_d(quat[k]);
-            S.quat[k] = quat[k];
-        }
+        for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];       // stays in vector registers: scalar registers are the scarce kind
         // rob:277-278 shot centre; painting is deferred until all five centres are known
         double center[3];
         transform_point(pos, quat, 0.0, 0.0, 0.1, center);
