@@ -44,7 +44,9 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
               + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
               + dt.vgrid_start.nbytes + dt.tri_records.nbytes
               + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_nbr.nbytes + dt.col_orient.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
-              + dt.start_pos.nbytes + dt.start_quat.nbytes)
+              + dt.start_pos.nbytes + dt.start_quat.nbytes
+              + dt.n_samples_pad                                                # equal-run ends (u8), derived on upload
+              + (dt.n_collision_pad * 96 if dt.col_convex else 0))              # hull facet records, derived on upload
     return per_env, static, per_env * n_envs + static
 
 
