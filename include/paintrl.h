@@ -162,6 +162,9 @@ int prl_batch_step(PrlBatch *batch, const void *actions, double *obs, double *re
  * quaternion `quat` (host pointers, xyzw) and clear its off-part bookkeeping (rob:208-212).  Coverage,
  * step counter and reward accumulators are left as they are, like the reference.  Synchronous. */
 int prl_batch_set_pose(PrlBatch *batch, int env_index, const double *pos, const double *quat);
+/* rge:306-319 _augmented_observation of the current state (no state change): obs f64[N][obs_dim], device.
+ * What PaintGymEnv.reset() returns after env.robot.reset(pose) in the reference's scripts (spiral.py:38). */
+int prl_batch_observe(PrlBatch *batch, double *obs, void *stream);
 
 /* Replaces get_job_status / get_texture_image style read-back (bpw:727-738): coverage bits in
  * device sample order, u64[N][mask_stride]. */

@@ -434,6 +434,12 @@ void or_reset(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted,
     }
 }
 
+/* rge:306-319 _augmented_observation of the current state (test hook: poses set from outside) */
+void or_observe(const OrPart *p, const OrConfig *c, const OrEnv *env, const uint64_t *painted, int n, double *obs) {
+    int words = or_mask_words(p), od = or_obs_dim(c);
+    for (int i = 0; i < n; ++i) observation(p, c, env + i, painted + (size_t)i * words, obs + (size_t)i * od);
+}
+
 /* rob:151-160 direction_normalize for continuous actions (libm; tolerance-level parity) */
 static void direction(const OrConfig *c, const double *a, double *x, double *y) {
     if (c->action_dim == 1) {

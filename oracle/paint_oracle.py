@@ -208,6 +208,24 @@ class Oracle(object):
                          _ptr(obs), _ptr(rew), done.ctypes.data_as(C.c_void_p), _ptr(info))
         return obs, rew, done.astype(bool), info
 
+    def set_pose(self, i, pose, orn):
+        """Robot.reset([pose, orn]) (rob:366-372) for env i: move the tool, clear the off-part bookkeeping."""
+        e = self.env[i]
+        q = (C.c_double * 4)()
+        o = (C.c_double * 3)(*[float(v) for v in orn])
+        self.lib.or_pose_orn_quat(o, q)
+        for k in range(3):
+            e.pose[k] = float(pose[k])
+        for k in range(4):
+            e.quat[k] = q[k]
+        e.terminate, e.terminate_counter, e.last_on_part, e.last_turning_angle = 0, 0, 1, 0.0
+
+    def observe(self):
+        obs = np.zeros((self.n, self.obs_dim), dtype=np.float64)
+        self.lib.or_observe(C.byref(self.part), C.byref(self.cfg), self.env, self.painted.ctypes.data_as(C.c_void_p),
+                            C.c_int(self.n), _ptr(obs))
+        return obs
+
     def painted_bits(self, i=0):
         """bool[P] in canonical sample order."""
         b = np.unpackbits(self.painted[i].view(np.uint8), bitorder='little')

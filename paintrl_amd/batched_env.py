@@ -148,6 +148,14 @@ class BatchedPaintEnv(object):
         quat = (C.c_double * 4)(*pose_orn_quaternion([float(v) for v in orn]))
         _lib.check(self.lib.prl_batch_set_pose(self._batch, int(index), pos, quat), 'prl_batch_set_pose')
 
+    def observe(self):
+        """_augmented_observation (rge:306-319) of the current state of every env, without stepping."""
+        torch = _torch()
+        obs = torch.empty((self.n_envs, self.obs_dim), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.prl_batch_observe(self._batch, self._ptr(obs), self._stream()), 'prl_batch_observe')
+        return obs
+
     # ------------------------------------------------------------------ read-back
     def painted_words(self):
         """int64 tensor (N, mask_stride) holding the u64 coverage words in device sample order."""

@@ -1341,6 +1341,20 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad));
 }
 
+// ---------------------------------------------------------------- observation of the current state (rge:306-319)
+template <int KW, bool GENSEC>
+__global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    load_masks<KW>(a, env, P.n_words, lane, painted, last);
+    observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad));
+}
+
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
 template <int KW, bool NORMAL, bool GENSEC>
@@ -1928,6 +1942,13 @@ void launch_reset(const StepArgs &a, bool gensec, hipStream_t s) {
     else hipLaunchKernelGGL((reset_kernel<KW, false>), grid, block, 0, s, a);
 }
 
+template <int KW>
+void launch_observe(const StepArgs &a, bool gensec, hipStream_t s) {
+    const dim3 grid((a.n_envs + 3) / 4), block(256);
+    if (gensec) hipLaunchKernelGGL((observe_kernel<KW, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((observe_kernel<KW, false>), grid, block, 0, s, a);
+}
+
 bool general_section(const PrlConfig &c) {
     return (c.obs_mode == PRL_OBS_SECTION || c.obs_mode == PRL_OBS_DISCRETE) && c.obs_grad != 4;
 }
@@ -2082,6 +2103,21 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
     case 2: launch_reset<2>(a, general_section(b->cfg), s); break;
     case 3: launch_reset<3>(a, general_section(b->cfg), s); break;
     default: launch_reset<4>(a, general_section(b->cfg), s); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_batch_observe(PrlBatch *b, double *obs, void *stream) {
+    if (!b || !obs) return fail(PRL_E_INVALID, "null argument");
+    StepArgs a = base_args(b);
+    a.obs = obs;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (b->kw) {
+    case 1: launch_observe<1>(a, general_section(b->cfg), s); break;
+    case 2: launch_observe<2>(a, general_section(b->cfg), s); break;
+    case 3: launch_observe<3>(a, general_section(b->cfg), s); break;
+    default: launch_observe<4>(a, general_section(b->cfg), s); break;
     }
     HIP_TRY(hipGetLastError());
     return PRL_OK;

@@ -234,3 +234,47 @@ def test_hostile_continuous_actions_do_not_disturb_other_envs():
     for e in np.nonzero(alive)[0]:
         assert np.array_equal(bits[e], orc.painted_bits(e))
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('obs_mode', ['section', 'discrete', 'grid'])
+def test_observation_at_exact_sample_coordinates(obs_mode):
+    """Tools parked exactly on sample coordinates after some painting: whole texel columns / rows then
+    compare EQUAL to the tool position (the 4-sector rule sends them to sector 3 and skips the sample the
+    tool sits on, bpw:1034-1061) -- the case the in-lane binary search resolves with its equal-run table."""
+    tables = synthetic_tables('door_test')
+    n = 96
+    env = _env(tables, n, obs_mode=obs_mode)
+    orc = oracle.Oracle(tables, n, obs_mode=obs_mode)
+    start = np.arange(n) % 4
+    env.reset(start_idx=start)
+    orc.reset(start)
+    rng = np.random.RandomState(11)
+    for _ in range(12):
+        a = rng.randint(0, 4, size=n)
+        env.step(a)
+        orc.step(a)
+    pos = tables.sample_pos
+    a0 = [k for k in range(3) if k not in (tables.a1, tables.a2)][0]
+    orn = [0.0, 0.0, 0.0]
+    orn[a0] = -1.0
+    pick = rng.randint(0, pos.shape[0], size=(n, 2))
+    for i in range(n):
+        p = pos[pick[i, 0]].copy()
+        kind = i % 4
+        if kind == 1:
+            p[tables.a2] = pos[pick[i, 1], tables.a2]          # x of one sample, y of another
+        elif kind == 2:
+            p[tables.a1] += 1e-9                               # just off the column
+        elif kind == 3:
+            p[tables.a1] = pos[:, tables.a1].min() - 0.2       # left of everything, y exact
+        env.set_pose(i, p, orn)
+        orc.set_pose(i, p, orn)
+    got, want = env.observe().cpu().numpy(), orc.observe()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, env.observe().cpu().numpy())   # observing changes nothing
+    a = rng.randint(0, 4, size=n)                               # and the envs step on identically
+    o1, r1, d1, _ = env.step(a)
+    o2, r2, d2, _ = orc.step(a)
+    assert np.array_equal(o1.cpu().numpy(), o2) and np.array_equal(r1.cpu().numpy(), r2)
+    env.close()
