@@ -226,10 +226,23 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Wave-wide sum the same way; a lane without a source contributes 0 (old = 0).  Used on packed
+// 16-bit counters too: partial sums never carry across fields as long as the totals fit.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o);
-    return v;
+    v += dpp0_u64<0x111, 0xf>(v);
+    v += dpp0_u64<0x112, 0xf>(v);
+    v += dpp0_u64<0x114, 0xf>(v);
+    v += dpp0_u64<0x118, 0xf>(v);
+    v += dpp0_u64<0x142, 0xa>(v);
+    v += dpp0_u64<0x143, 0xc>(v);
+    return bcast_u64(v, 63);
 }
 
 // A wave-uniform double computed by the vector ALU sits in a VGPR pair; moving it to scalar
@@ -1076,27 +1089,32 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         return;
     }
     if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
+        // 16 cells per pass: four packed accumulators (4 x 16-bit per u64), four DPP sums, then lane j
+        // finishes cell j (one division per lane, one coalesced store)
         const int cells = P.n_obs_cells;
-        for (int c0 = 0; c0 < cells; c0 += 4) {
-            uint64_t acc = 0;
+        for (int c0 = 0; c0 < cells; c0 += 16) {
+            uint64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const int w = lane + 64 * k;
                 if (w < P.n_words) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + q < cells)
-                            acc += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + q) * P.n_words + w])
-                                   << (16 * q);
+                    for (int j = 0; j < 16; ++j)
+                        if (c0 + j < cells)
+                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + j) * P.n_words + w])
+                                           << (16 * (j & 3));
                 }
             }
-            acc = wave_sum_u64(acc);
-            if (lane == 0) {
-                for (int q = 0; q < 4 && c0 + q < cells; ++q) {
-                    const int num = P.cell_count[c0 + q];
-                    const int dn = (int)((acc >> (16 * q)) & 0xffff);
-                    out[c0 + q] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
-                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = wave_sum_u64(acc[g]);
+            const int cell = c0 + lane;
+            if (lane < 16 && cell < cells) {
+                uint64_t a4 = acc[0];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
+                const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
+                const int num = P.cell_count[cell];
+                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
             }
         }
         return;

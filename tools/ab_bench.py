@@ -40,7 +40,8 @@ def main():
     for src in srcs:
         hb.LIBRARY = build(src, flags)
         _lib._lib = None
-        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678)
+        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, obs_mode=os.environ.get('PRL_OBS', 'section'),
+                              overlap_penalty=os.environ.get('PRL_OBS', 'section') == 'grid')
         env.reset()
         for k in range(100):
             env.step_raw(acts[k])
