@@ -197,8 +197,9 @@ def main():
     episodes = int(st['episode'].sum()) - args.envs
     if rank == 0:
         per_env, static, per_launch = algorithmic_bytes(dt, args.envs, env.obs_dim)
-        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        achieved = per_launch / avg_kernel_s / 1e9
+        # inside a captured HIP graph (--graph) the per-launch events are not recorded: no kernel time then
+        avg_kernel_s = kernel_ms / launches / 1e3 if launches and kernel_ms > 0 else None
+        achieved = per_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         # the committed PMC measurement is for the default workload only
@@ -217,9 +218,9 @@ def main():
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
                          'algorithmic_bytes_per_env_step': per_env, 'static_table_bytes': static,
-                         'bytes_per_launch': per_launch, 'avg_kernel_us': avg_kernel_s * 1e6,
+                         'bytes_per_launch': per_launch, 'avg_kernel_us': avg_kernel_s * 1e6 if avg_kernel_s else None,
                          'launches_timed': int(launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
