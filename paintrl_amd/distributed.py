@@ -76,4 +76,7 @@ def max_over_ranks(value, device):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == 'nccl':             # name the device: RCCL otherwise guesses (and warns)
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
