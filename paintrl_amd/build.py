@@ -9,7 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
-SOURCE = os.path.join(_HERE, 'csrc', 'paintrl_hip.hip')
+CSRC = os.path.join(_HERE, 'csrc')                      # paintrl_hip.hip + the prl_*.hpp it includes
+SOURCE = os.path.join(CSRC, 'paintrl_hip.hip')
 HEADER = os.path.join(_REPO, 'include', 'paintrl.h')
 # PAINTRL_LIB points the binding at another build of the same source (diagnostic builds of tools/)
 LIBRARY = os.environ.get('PAINTRL_LIB') or os.path.join(_HERE, 'libpaintrl_hip.so')
@@ -27,13 +28,15 @@ def is_stale():
     if not os.path.isfile(LIBRARY):
         return True
     built = os.path.getmtime(LIBRARY)
-    return any(os.path.getmtime(p) > built for p in (SOURCE, HEADER))
+    import glob
+    sources = [SOURCE, HEADER] + glob.glob(os.path.join(CSRC, '*.hpp'))
+    return any(os.path.getmtime(p) > built for p in sources)
 
 
 def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIBRARY
-    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), SOURCE, '-o', LIBRARY]
+    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, '-o', LIBRARY]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

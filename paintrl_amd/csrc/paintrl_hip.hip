@@ -23,6 +23,10 @@
 // oracle/paint_oracle.c for the scalar statement; numpy.dot -> explicit fma chain,
 // everything else unfused: this file must be compiled with -ffp-contract=off).
 // No MFMA: this is gather / scan / bit work.
+//
+// Layout of the translation unit: the device code lives in the prl_*.hpp headers next to this file
+// (prl_device: descriptor + wave helpers + reference arithmetic, prl_ray, prl_search, prl_paint,
+// prl_observe, prl_state); this file holds the kernels and the host side of the C ABI.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -34,1311 +38,14 @@
 
 #include "paintrl.h"
 
+#include "prl_device.hpp"
+#include "prl_ray.hpp"
+#include "prl_search.hpp"
+#include "prl_paint.hpp"
+#include "prl_observe.hpp"
+#include "prl_state.hpp"
+
 namespace {
-
-constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples
-constexpr double PAINT_RADIUS = 0.051;          // bpw:42
-constexpr double STEP_SIZE = 0.051;             // bpw:43
-constexpr double HOOK_DISTANCE = 0.1;           // bpw:443
-constexpr int GRID_GRANULARITY = 100;           // bpw:447
-constexpr int PAINT_PER_ACTION = 5;             // rob:165
-constexpr int NOT_ON_PART_TERMINATE = 1000;     // rob:167
-constexpr double RAY_EPS_DET = 1e-12;
-constexpr double RAY_EPS_BARY = 1e-9;
-constexpr double PI = 3.141592653589793;
-
-// Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
-// space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
-// (address space 1) gives global_load with counted vmcnt waits.
-#define GAS __attribute__((address_space(1)))
-#define CAS __attribute__((address_space(4)))
-typedef const double GAS *gdouble_p;
-typedef const float GAS *gfloat_p;
-typedef const int GAS *gint_p;
-typedef const uint64_t GAS *gu64_p;
-typedef const uint8_t GAS *gu8_p;
-typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-struct PartDev {
-    int n_samples, n_samples_pad, n_words;
-    gdouble_p samp[3];
-    gdouble_p samp_a1, samp_a2;   // = samp[a1], samp[a2]: a dynamic index into samp[] would be a memory load of the pointer
-    gdouble_p word_bbox;
-    gu64_p word_valid;
-    gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
-    gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
-    double sg_o1, sg_o2, sg_inv;
-    int sg_nx, sg_ny;
-    gint_p sg_start;
-    int n_obs_cells;
-    gu64_p cell_mask;
-    gint_p cell_count;
-    int n_vertices;
-    gdouble_p vert[3];
-    gint_p vert_rank;
-    int adj_width;
-    gint_p vadj;
-    double vg_o1, vg_o2, vg_inv, vg_accept;
-    int vg_nx, vg_ny;
-    gint_p vg_start;
-    int n_triangles;
-    gdouble_p tri_rec;
-    int n_col, n_col_pad;
-    gdouble_p col[9];
-    gfloat_p col_bbox;
-    gint_p col_rank;
-    int col_convex, nbr_width;
-    gint_p col_nbr, col_orient;
-    gdouble_p col_rec;            // convex sets: [n_col_pad][12] v0 e1 e2 | edge margin | |e1 x e2|^2 | orient (derived in part_fill)
-    int n_col_chunks;
-    gfloat_p col_chunk_bbox;
-    gdouble_p grid_lo, grid_hi;
-    double r1min, r1max, r2min, r2max, lwr;
-    int a0, a1, a2;
-    int n_start;
-    gdouble_p start_pos, start_quat;
-    int n_beams;
-    gdouble_p beams;
-};
-
-// The part descriptor and the batch configuration are read-only for every kernel: typed as constant
-// address space so that their fields are fetched with scalar loads (s_load through the K$) instead
-// of wave-uniform vector loads the compiler has to assume the kernel's own stores may clobber.
-typedef const PartDev CAS &PartRef;
-typedef const PrlConfig CAS &CfgRef;
-
-struct StepArgs {
-    const PartDev *parts;
-    const PrlConfig *cfg;
-    const int *env_part;          // device, or nullptr
-    int n_envs, mask_stride;
-    uint64_t *painted, *last;
-    double *state;
-    const void *actions;
-    double *obs, *reward, *info, *final_obs;
-    uint8_t *done;
-    const int *start_idx;
-    const uint8_t *reset_mask;
-};
-
-#ifdef PRL_WAVE_TIMES      // per-wave trip counters of the data-dependent loops (diagnostic build only)
-__device__ uint32_t g_wcnt[1 << 16][8];
-#define WCNT(slot, v)                                                                        \
-    do {                                                                                     \
-        if ((threadIdx.x & 63) == 0) g_wcnt[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 0xffff][slot] += (v); \
-    } while (0)
-#else
-#define WCNT(slot, v)
-#endif
-
-// ---------------------------------------------------------------- diagnostic build only (-DPRL_PHASE_TIMING)
-// Per-phase s_memtime deltas summed over all waves into a buffer nothing else reads
-// (cdna_hip_programming.md "In-kernel stamps").  The product build contains no stamp.
-#ifdef PRL_PHASE_TIMING
-enum { PH_LOAD = 0, PH_RAY, PH_VERTEX, PH_BARY, PH_MATH, PH_BALL, PH_APPLY, PH_OBS, PH_STORE, PH_COUNT };
-__device__ unsigned long long g_phase_cycles[16];
-struct Prof {
-    unsigned long long acc[PH_COUNT];
-    unsigned long long prev;
-};
-#define PROF_ARG , Prof &prof
-#define PROF_PASS , prof
-#define STAMP(ph)                                                         \
-    do {                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                \
-        __builtin_amdgcn_s_waitcnt(0);                                    \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
-        prof.acc[ph] += now_ - prof.prev;                                 \
-        prof.prev = now_;                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                \
-    } while (0)
-#else
-#define PROF_ARG
-#define PROF_PASS
-#define STAMP(ph) \
-    do {          \
-    } while (0)
-#endif
-
-// ---------------------------------------------------------------- wave helpers
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ double bcast_d(double v, int src) {
-    src = rfl(src);
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
-    src = rfl(src);
-    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-
-// Wave-wide min/max by DPP row shifts + row broadcasts (VALU speed) instead of ds_bpermute chains.
-// After the six steps lane 63 holds the reduction of all 64 lanes; it is broadcast with readlane.
-// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.  Lanes with no source
-// (bound_ctrl off) keep `old`, which is the lane's own value -- harmless for idempotent min/max.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_d(double v) {
-    const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-#define WAVE_REDUCE_DPP(T, v, OP, DPPF)               \
-    do {                                              \
-        T x_;                                         \
-        x_ = DPPF<0x111, 0xf>(v); v = OP(x_, v);      \
-        x_ = DPPF<0x112, 0xf>(v); v = OP(x_, v);      \
-        x_ = DPPF<0x114, 0xf>(v); v = OP(x_, v);      \
-        x_ = DPPF<0x118, 0xf>(v); v = OP(x_, v);      \
-        x_ = DPPF<0x142, 0xa>(v); v = OP(x_, v);      \
-        x_ = DPPF<0x143, 0xc>(v); v = OP(x_, v);      \
-    } while (0)
-
-#define OP_MIN(x, y) ((x) < (y) ? (x) : (y))
-#define OP_MAX(x, y) ((x) > (y) ? (x) : (y))
-
-__device__ __forceinline__ double wave_min_d(double v) {
-    WAVE_REDUCE_DPP(double, v, OP_MIN, dpp_d);
-    return bcast_d(v, 63);
-}
-
-__device__ __forceinline__ double wave_max_d(double v) {
-    WAVE_REDUCE_DPP(double, v, OP_MAX, dpp_d);
-    return bcast_d(v, 63);
-}
-
-__device__ __forceinline__ int wave_min_i(int v) {
-    WAVE_REDUCE_DPP(int, v, OP_MIN, dpp_i);
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// Wave-wide sum the same way; a lane without a source contributes 0 (old = 0).  Used on packed
-// 16-bit counters too: partial sums never carry across fields as long as the totals fit.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-    v += dpp0_u64<0x111, 0xf>(v);
-    v += dpp0_u64<0x112, 0xf>(v);
-    v += dpp0_u64<0x114, 0xf>(v);
-    v += dpp0_u64<0x118, 0xf>(v);
-    v += dpp0_u64<0x142, 0xa>(v);
-    v += dpp0_u64<0x143, 0xc>(v);
-    return bcast_u64(v, 63);
-}
-
-// A wave-uniform double computed by the vector ALU sits in a VGPR pair; moving it to scalar
-// registers frees vector registers for the per-lane work (masks, Moller-Trumbore temporaries).
-__device__ __forceinline__ double uni_d(double v) {
-    return __hiloint2double(rfl(__double2hiint(v)), rfl(__double2loint(v)));
-}
-
-__device__ __forceinline__ double sel3(double x, double y, double z, int axis) {
-    return axis == 0 ? x : (axis == 1 ? y : z);
-}
-
-// ---------------------------------------------------------------- reference arithmetic
-// numpy.dot on 3-vectors = OpenBLAS ddot = fused chain (oracle/paint_oracle.c dot3_np)
-__device__ __forceinline__ double dot3_np(double a0, double a1, double a2, double b0, double b1, double b2) {
-    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
-}
-
-// this project's multiplyTransforms rotation (paintrl_amd/geometry.py quat_rotate)
-__device__ __forceinline__ void quat_rotate(const double q[4], double v0, double v1, double v2, double o[3]) {
-    double t0 = 2.0 * (q[1] * v2 - q[2] * v1);
-    double t1 = 2.0 * (q[2] * v0 - q[0] * v2);
-    double t2 = 2.0 * (q[0] * v1 - q[1] * v0);
-    o[0] = (v0 + q[3] * t0) + (q[1] * t2 - q[2] * t1);
-    o[1] = (v1 + q[3] * t1) + (q[2] * t0 - q[0] * t2);
-    o[2] = (v2 + q[3] * t2) + (q[0] * t1 - q[1] * t0);
-}
-
-__device__ __forceinline__ void transform_point(const double pos[3], const double q[4], double v0, double v1,
-                                                double v2, double o[3]) {
-    double r[3];
-    quat_rotate(q, v0, v1, v2, r);
-    o[0] = pos[0] + r[0];
-    o[1] = pos[1] + r[1];
-    o[2] = pos[2] + r[2];
-}
-
-// rob:93-100 get_pose_orn + bpw:32-37 normalize
-__device__ __forceinline__ void pose_orn_quat(const double orn[3], double q[4]) {
-    double x = 0.0 * orn[2] - 1.0 * orn[1];
-    double y = 1.0 * orn[0] - 0.0 * orn[2];
-    double z = 0.0 * orn[1] - 0.0 * orn[0];
-    double w = 1.0 + __builtin_fma(1.0, orn[2], __builtin_fma(0.0, orn[1], 0.0 * orn[0]));
-    double mag2 = (((0.0 + x * x) + y * y) + z * z) + w * w;
-    if (fabs(mag2 - 1.0) > 0.00001) {
-        double mag = sqrt(mag2);
-        x /= mag;
-        y /= mag;
-        z /= mag;
-        w /= mag;
-    }
-    q[0] = x;
-    q[1] = y;
-    q[2] = z;
-    q[3] = w;
-}
-
-// rob:266-271 _get_tcp_orn_norm
-__device__ __forceinline__ void tcp_orn_norm(const double pose[3], const double quat[4], double n[3]) {
-    double along[3];
-    transform_point(pose, quat, 0.0, 0.0, 1.0, along);
-    double v0 = along[0] - pose[0], v1 = along[1] - pose[1], v2 = along[2] - pose[2];
-    double norm = sqrt(dot3_np(v0, v1, v2, v0, v1, v2));
-    n[0] = v0 / norm;
-    n[1] = v1 / norm;
-    n[2] = v2 / norm;
-}
-
-__device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {
-    double f = floor((x - origin) * inv);
-    f = f < -2.0 ? -2.0 : f;                       // NaN stays NaN -> comparison below sends it out of range
-    f = f > (double)(n + 1) ? (double)(n + 1) : f;
-    return (f == f) ? (int)f : -2;
-}
-
-// ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
-#define FACET_EDGE_MARGIN 1.0e-6     // metres from every edge of the entered facet (single-facet fast path)
-#define FACET_MIN_COS2 0.01          // squared cosine between segment and facet normal: no grazing entries
-// Cull before the float64 Moller-Trumbore test:
-//   * 3-D float boxes (rounded outward) per triangle and per 64-triangle chunk; lane c tests chunk c,
-//     only surviving chunks are visited (one triangle per lane, boxes + 9 doubles in one round trip);
-//   * two stages: first only the near part of the segment, t <= 0.125 (the tool hovers 0.1 above
-//     the part, so this is where the hit almost always is, and the short box excludes back and side
-//     facets); the whole segment only if nothing was hit.  The closest hit of the whole segment is
-//     the closest hit of the near part whenever the latter exists, so the result is unchanged.
-// Equal t resolves to the lowest reference-order index (col_rank), as in paintrl_amd/geometry.py.
-struct SegBox {
-    float lo[3], hi[3];      // axis1, axis2, axis0
-};
-
-__device__ __forceinline__ SegBox seg_box(const double o3[3], const double d3[3], double tmax) {
-    SegBox b;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double e = o3[k] + tmax * d3[k];
-        b.lo[k] = nextafterf((float)fmin(o3[k], e), -INFINITY);
-        b.hi[k] = nextafterf((float)fmax(o3[k], e), INFINITY);
-    }
-    return b;
-}
-
-__device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, const f32x4 b) {
-    return (s.lo[0] <= a.y) && (s.hi[0] >= a.x) && (s.lo[1] <= a.w) && (s.hi[1] >= a.z) && (s.lo[2] <= b.y) &&
-           (s.hi[2] >= b.x);
-}
-
-// The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
-// running count + number of passing lanes below), then the float64 test runs ONCE over the list
-// with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
-// One float64 Moller-Trumbore test per lane (triangle i, or none if i < 0); keeps the lane's best
-// (t, reference rank) and remembers which triangle and which determinant produced it.
-__device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], double d0, double d1, double d2,
-                                       double tmax, double &best_t, int &best_r, int &best_i, double &best_det) {
-    if (i >= 0) {
-        const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
-        const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
-        const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
-        const int rk = P.col_rank[i];
-        const double p0 = d1 * e22 - d2 * e21;
-        const double p1 = d2 * e20 - d0 * e22;
-        const double p2 = d0 * e21 - d1 * e20;
-        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-        if (fabs(det) >= RAY_EPS_DET) {
-            const double inv = 1.0 / det;
-            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-            const double q0 = s1 * e12 - s2 * e11;
-            const double q1 = s2 * e10 - s0 * e12;
-            const double q2 = s0 * e11 - s1 * e10;
-            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= tmax &&
-                (t < best_t || (t == best_t && rk < best_r))) {
-                best_t = t;
-                best_r = rk;
-                best_i = i;
-                best_det = det;
-            }
-        }
-    }
-}
-
-// The same test on the facet record of a convex set (one 96-byte gather per lane instead of ten
-// strided loads); `interior` reports a hit that meets the single-facet criterion of ray_closest_wave.
-__device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
-                                       double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
-    interior = false;
-    if (i >= 0) {
-        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec + (size_t)i * 12);
-        const f64x2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-        const int rk = P.col_rank[i];
-        const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
-        const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
-        const double p0 = d1 * e22 - d2 * e21;
-        const double p1 = d2 * e20 - d0 * e22;
-        const double p2 = d0 * e21 - d1 * e20;
-        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-        if (fabs(det) >= RAY_EPS_DET) {
-            const double inv = 1.0 / det;
-            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-            const double q0 = s1 * e12 - s2 * e11;
-            const double q1 = s2 * e10 - s0 * e12;
-            const double q2 = s0 * e11 - s1 * e10;
-            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= 1.0 &&
-                (t < best_t || (t == best_t && rk < best_r))) {
-                best_t = t;
-                best_r = rk;
-                best_i = i;
-                best_det = det;
-                interior = u >= m && v >= m && (u + v) <= 1.0 - m && orient * det > 0 &&
-                           det * det >= FACET_MIN_COS2 * dd * nn;
-            }
-        }
-    }
-}
-
-// Lane holding the wave's best (t, rank); -1 if no lane has a hit.
-__device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
-    if (__ballot(best_t < INFINITY) == 0) return -1;
-    tmin = wave_min_d(best_t);
-    const uint64_t tie = __ballot(best_t == tmin);
-    if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
-    const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
-    return __builtin_ctzll(__ballot(best_t == tmin && best_r == rmin));
-}
-
-// `hint` (in/out): collision-set position of the facet hit by the previous ray of this env, or -1.
-//
-// Convex fast path (collision set = boundary of a convex polytope, i.e. hull mode): a segment that
-// starts outside enters the polytope at one point, so every facet with a valid hit at or before the
-// entry parameter contains that point and therefore shares a vertex with any one of them.  If the
-// vertex-neighbourhood of `hint` holds a valid hit whose facet is ENTERED (orient * det > 0), the
-// closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
-// hit there, an exit hit, a facet without a neighbour list) takes the general search below.
-__device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3], int lane, double &t_out,
-                                double hit[3], int &hint) {
-    __shared__ int s_cand[4][64];
-    int *cand = s_cand[threadIdx.x >> 6];
-    const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
-    double best_t = INFINITY, best_det = 0, tmin = INFINITY;
-    int best_r = 0x7fffffff, best_i = -1, win = -1;
-#ifdef PRL_FORCE_GENERAL_RAY                         // diagnostic build: never take the convex fast path
-    hint = -1;
-#endif
-    if (P.col_convex && hint >= 0) {
-        // (1) The previous facet alone, wave-uniform on scalar-loaded data.  If the segment ENTERS the hull
-        // through it at a point at least FACET_EDGE_MARGIN away from its edges, and not at a grazing
-        // angle, no other facet can report a hit at or before that point: a second hit there would lie
-        // in the other facet's 1e-9 tolerance fringe, i.e. within nanometres of an edge of the entered
-        // facet.  The result is then this facet's own Moller-Trumbore value, arithmetic as in mt_one.
-        {
-            const int h = rfl(hint);
-            const double CAS *r = reinterpret_cast<const double CAS *>((uint64_t)P.col_rec) + (size_t)h * 12;
-            const double e10 = r[3], e11 = r[4], e12 = r[5], e20 = r[6], e21 = r[7], e22 = r[8];
-            const double p0 = d1 * e22 - d2 * e21;
-            const double p1 = d2 * e20 - d0 * e22;
-            const double p2 = d0 * e21 - d1 * e20;
-            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-            bool inside = false;
-            double t = 0;
-            if (fabs(det) >= RAY_EPS_DET) {
-                const double inv = 1.0 / det;
-                const double s0 = o[0] - r[0], s1 = o[1] - r[1], s2 = o[2] - r[2];
-                const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-                const double q0 = s1 * e12 - s2 * e11;
-                const double q1 = s2 * e10 - s0 * e12;
-                const double q2 = s0 * e11 - s1 * e10;
-                const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-                t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-                const double m = r[9], dd = (d0 * d0 + d1 * d1) + d2 * d2;
-                inside = u >= m && v >= m && (u + v) <= 1.0 - m && t >= 0.0 && t <= 1.0 && r[11] * det > 0 &&
-                         det * det >= FACET_MIN_COS2 * dd * r[10];
-            }
-            if (rfl(inside)) {
-                WCNT(7, 1);
-                t_out = t;
-                hit[0] = o[0] + t * d0;
-                hit[1] = o[1] + t * d1;
-                hit[2] = o[2] + t * d2;
-                return reinterpret_cast<const int CAS *>((uint64_t)P.col_rank)[h];
-            }
-        }
-        // (2) The facets that share a vertex with it, one per lane.  A lane whose facet is entered at an
-        // interior point holds the closest hit of the whole set by the same argument (there is at most
-        // one such lane): no reduction, no second round.
-        WCNT(4, 1);
-        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
-        const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
-        bool interior;
-        mt_rec(P, i1, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
-        const uint64_t im = __ballot(interior);
-        if (im) {
-            win = __builtin_ctzll(im);
-            tmin = bcast_d(best_t, win);
-        } else {
-            // (3) otherwise the closest hit there, if it enters the hull, decides after a look at its own
-            // neighbourhood
-            win = ray_winner_lane(best_t, best_r, tmin);
-            if (win >= 0) {
-                const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
-                const double fdet = bcast_d(best_det, win);
-                const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
-                const bool entering = (double)P.col_orient[f] * fdet > 0;
-                if (entering && __ballot(i2 >= 0) != 0) {
-                    if (f != hint) {
-                        WCNT(4, 16);
-                        mt_rec(P, i2, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
-                        win = ray_winner_lane(best_t, best_r, tmin);
-                    }
-                } else {
-                    win = -1;
-                }
-            }
-        }
-        if (win < 0) {
-            best_t = INFINITY;
-            best_r = 0x7fffffff;
-            best_i = -1;
-        }
-    }
-    if (win < 0) {
-        WCNT(0, 1);
-        const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
-        const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
-        const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
-        const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
-        for (int stage = 0; stage < 2; ++stage) {
-#ifdef PRL_PHASE_COUNTERS
-            if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
-#endif
-            const double tmax = stage == 0 ? 0.125 : 1.0;
-            if (stage == 1) WCNT(1, 1);
-            const SegBox sb = seg_box(o3, d3, tmax);
-            int n_cand = 0;
-            for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
-                const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
-                uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
-                while (cm) {
-                    WCNT(2, 1);
-                    const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
-                    cm &= cm - 1;
-                    const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
-                    const bool pass = box_overlap(sb, ba, bb);
-                    const uint64_t pm = __ballot(pass);
-                    if (pm == 0) continue;
-                    const int np = __popcll(pm);
-                    if (n_cand + np > 64) {                        // list full: test what is queued first
-                        __builtin_amdgcn_wave_barrier();
-                        mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
-                        __builtin_amdgcn_wave_barrier();
-                        n_cand = 0;
-                    }
-                    if (pass)
-                        cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
-                    n_cand += np;
-                }
-            }
-            if (n_cand) {
-                __builtin_amdgcn_wave_barrier();
-                mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (__ballot(best_t < INFINITY)) break;
-        }
-        win = ray_winner_lane(best_t, best_r, tmin);
-    }
-    if (win < 0) {
-        t_out = INFINITY;
-        hint = -1;
-        return -1;
-    }
-    hint = __builtin_amdgcn_readlane(best_i, rfl(win));
-    t_out = tmin;
-    hit[0] = o[0] + tmin * d0;
-    hit[1] = o[1] + tmin * d1;
-    hit[2] = o[2] + tmin * d2;
-    return __builtin_amdgcn_readlane(best_r, rfl(win));
-}
-
-// ---------------------------------------------------------------- bpw:526 nearest same-side vertex
-// Grid rows cy-1..cy+1 of a uniform grid: each row's three cells are one contiguous index range.
-// Lanes 0..5 fetch the six range bounds in one load; `rows` returns them wave-uniform.
-struct Rows3 {
-    int begin[3], count[3];
-};
-
-__device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int icx, int icy, int lane) {
-    const int r = lane >> 1, cy = icy - 1 + r;
-    const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > nx - 1 ? nx - 1 : icx + 1;
-    const bool ok = lane < 6 && cy >= 0 && cy < ny && cx0 <= cx1;
-    const int v = ok ? start[cy * nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
-    Rows3 out;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int b = __builtin_amdgcn_readlane(v, 2 * k), e = __builtin_amdgcn_readlane(v, 2 * k + 1);
-        out.begin[k] = b;
-        out.count[k] = e - b;
-    }
-    return out;
-}
-
-__device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const double pt[3], int lane,
-                                        double &best_d, int &best_rank, int &best_idx) {
-    for (int b = begin; b < end; b += 128) {                   // two batches per trip: eight loads in flight
-        const int v0 = b + lane, v1 = v0 + 64;
-        const bool k0 = v0 < end, k1 = v1 < end;
-        double x0 = 0, y0 = 0, z0 = 0, x1 = 0, y1 = 0, z1 = 0;
-        int r0 = 0, r1 = 0;
-        if (k0) {
-            x0 = P.vert[0][v0];
-            y0 = P.vert[1][v0];
-            z0 = P.vert[2][v0];
-            r0 = P.vert_rank[v0];
-        }
-        if (k1) {
-            x1 = P.vert[0][v1];
-            y1 = P.vert[1][v1];
-            z1 = P.vert[2][v1];
-            r1 = P.vert_rank[v1];
-        }
-        if (k0) {
-            const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
-            const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && r0 < best_rank)) {
-                best_d = dd;
-                best_rank = r0;
-                best_idx = v0;
-            }
-        }
-        if (k1) {
-            const double dx = x1 - pt[0], dy = y1 - pt[1], dz = z1 - pt[2];
-            const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && r1 < best_rank)) {
-                best_d = dd;
-                best_rank = r1;
-                best_idx = v1;
-            }
-        }
-    }
-}
-
-// Exact nearest neighbour by expanding rings: the (2k+1)^2 cell block around the query's cell is
-// scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
-// outside the block is at least k cells away in the principal plane, so the result is exact once the
-// best distance is within k * 0.99 * cell.  After ring 3 the whole table is scanned.
-__device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
-    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
-    const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
-    double best_d = INFINITY, dmin = INFINITY;
-    int best_rank = 0x7fffffff, best_idx = -1;
-    bool exact = false;
-    for (int ring = 1; ring <= 3 && !exact; ++ring) {
-        const int nrows = 2 * ring + 1;
-        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
-        const int rcy = icy - ring + (lane >> 1);
-        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
-        const int bound = okr ? P.vg_start[rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
-        // per-row begin and exclusive prefix of counts, wave-uniform (<= 7 rows)
-        int rbeg[7], rpre[8];
-        rpre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
-            rbeg[r] = b0;
-            rpre[r + 1] = rpre[r] + ((r < nrows) ? e0 - b0 : 0);
-        }
-        const int total = rpre[7];
-        best_d = INFINITY;
-        best_rank = 0x7fffffff;
-        best_idx = -1;
-        for (int c0 = 0; c0 < total; c0 += 64) {
-            WCNT(3, 1);
-            const int c = c0 + lane;
-            if (c < total) {
-                int v = rbeg[0] + c;
-#pragma unroll
-                for (int r = 1; r < 7; ++r)
-                    if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
-                const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const int rk = P.vert_rank[v];
-                if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                    best_d = dd;
-                    best_rank = rk;
-                    best_idx = v;
-                }
-            }
-        }
-        dmin = wave_min_d(best_d);
-        const double lim = ring * P.vg_accept;          // ring * 0.99 * cell
-        exact = dmin <= lim * lim;
-    }
-#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: exercise the whole-table scans
-    exact = false;
-#endif
-    if (!exact) {
-        best_d = INFINITY;
-        best_rank = 0x7fffffff;
-        best_idx = -1;
-        nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
-        dmin = wave_min_d(best_d);
-    }
-    const uint64_t tie = __ballot(best_d == dmin);
-    if (tie == 0) return -1;                                        // NaN query point
-    if ((tie & (tie - 1)) == 0) return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(tie)));
-    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
-    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
-    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
-}
-
-// ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1): nearest sample
-// Same exact expanding-ring search as for vertices, over the sample grid; equal distances resolve
-// to the lowest reference-order index.  Returns the device position of the sample, or -1.
-__device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
-    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
-    const int icx = cell_coord(h1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(h2, P.sg_o2, P.sg_inv, P.sg_ny);
-    double best_d = INFINITY, dmin = INFINITY;
-    int best_rank = 0x7fffffff, best_idx = -1;
-    bool exact = false;
-    for (int ring = 1; ring <= 3 && !exact; ++ring) {
-        const int nrows = 2 * ring + 1;
-        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.sg_nx - 1 ? P.sg_nx - 1 : icx + ring;
-        const int rcy = icy - ring + (lane >> 1);
-        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
-        const int bound = okr ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
-        best_d = INFINITY;
-        best_rank = 0x7fffffff;
-        best_idx = -1;
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
-            if (r >= nrows) continue;
-            for (int s0 = b0; s0 < e0; s0 += 64) {
-                const int sidx = s0 + lane;
-                if (sidx < e0) {
-                    const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    const int rk = P.samp_rank[sidx];
-                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                        best_d = dd;
-                        best_rank = rk;
-                        best_idx = sidx;
-                    }
-                }
-            }
-        }
-        dmin = wave_min_d(best_d);
-        const double lim = ring * (0.99 / P.sg_inv);        // ring * 0.99 * sample cell
-        exact = dmin <= lim * lim;
-    }
-#ifdef PRL_FORCE_FULL_SCANS
-    exact = false;
-#endif
-    if (!exact) {                                   // far from every sample: scan the whole table
-        best_d = INFINITY;
-        best_rank = 0x7fffffff;
-        best_idx = -1;
-        for (int s0 = 0; s0 < P.n_samples_pad; s0 += 64) {
-            const int sidx = s0 + lane;
-            const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
-            const double dd = (dx * dx + dy * dy) + dz * dz;
-            const int rk = P.samp_rank[sidx];
-            if (rk != 0x7fffffff && (dd < best_d || (dd == best_d && rk < best_rank))) {
-                best_d = dd;
-                best_rank = rk;
-                best_idx = sidx;
-            }
-        }
-        dmin = wave_min_d(best_d);
-    }
-    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
-    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin && best_idx >= 0);
-    if (win == 0) return -1;
-    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
-}
-
-// ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
-__device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
-#ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
-    const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
-#else
-#ifdef PRL_DOUBLE_VERTEX
-    {
-        const int v2 = nearest_vertex_wave(P, pt, lane);
-        asm volatile("" ::"s"(v2));
-    }
-#endif
-    const int vidx = nearest_vertex_wave(P, pt, lane);
-#endif
-    STAMP(PH_VERTEX);
-    if (vidx < 0) return false;
-    const int ti = lane < P.adj_width ? P.vadj[vidx * P.adj_width + lane] : -1;   // file order, -1 = pad
-    if (__ballot(ti >= 0) == 0) return false;
-    bool inside = false, ok = false;
-    double m = -INFINITY, n0 = 0, n1 = 0, n2 = 0;
-    if (ti >= 0) {
-        gdouble_p r = P.tri_rec + (size_t)ti * 16;
-        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(r);
-        const f64x2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
-        // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
-        const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
-        const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
-        const double d21 = dot3_np(x0, x1, x2, q3.x, q3.y, q4.x);
-        const double inv = q6.x;
-        double v = (q5.y * d20 - q5.x * d21) * inv;
-        double w = (q4.y * d21 - q5.x * d20) * inv;
-        double u = 1.0 - v - w;
-        if (inv == 0) {
-            u = -1;
-            v = -1;
-            w = -1;
-        }
-        inside = 0 <= u && u <= 1 && 0 <= v && v <= 1 && 0 <= w && w <= 1;
-        m = v < u ? v : u;
-        m = w < m ? w : m;
-        ok = m >= -1.0;
-        n0 = q6.y;
-        n1 = q7.x;
-        n2 = q7.y;
-    }
-    int j;
-    const uint64_t in_mask = __ballot(inside);
-    if (in_mask) {
-        j = __builtin_ctzll(in_mask);                               // first triangle containing the point
-    } else {
-        const uint64_t ok_mask = __ballot(ok);
-        if (ok_mask == 0) {
-            j = 0;                                                   // nothing beat -1: the first candidate stays
-        } else {
-            const double mx = wave_max_d(ok ? m : -INFINITY);
-            j = 63 - __builtin_clzll(__ballot(ok && m == mx));       // last one reaching the maximum
-        }
-    }
-    n0 = bcast_d(n0, j);
-    n1 = bcast_d(n1, j);
-    n2 = bcast_d(n2, j);
-    pose[0] = pt[0] + n0 * HOOK_DISTANCE;
-    pose[1] = pt[1] + n1 * HOOK_DISTANCE;
-    pose[2] = pt[2] + n2 * HOOK_DISTANCE;
-    orn[0] = -n0;
-    orn[1] = -n1;
-    orn[2] = -n2;
-    STAMP(PH_BARY);
-    return true;
-}
-
-// ---------------------------------------------------------------- bpw:568-570 fast_paint (ball query)
-template <int KW>
-__device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b, int lane) {
-    const int owner = w & 63, slot = w >> 6;
-#pragma unroll
-    for (int k = 0; k < KW; ++k)
-        if (k == slot && lane == owner) cur[k] |= b;
-}
-
-template <int KW>
-__device__ void ball_query_wave(PartRef P, double radius, const double c[3], int lane,
-                                uint64_t cur[KW_MAX]) {
-    const double r2 = radius * radius;
-    const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
-    const int icx = cell_coord(c1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(c2, P.sg_o2, P.sg_inv, P.sg_ny);
-    const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int begin = R.begin[r], end = begin + R.count[r];
-        if (R.count[r] <= 0) continue;
-        const int wlast = (end - 1) >> 6;
-        for (int w = begin >> 6; w <= wlast; w += 2) {            // two words per trip: six loads in flight
-            const int s0 = (w << 6) + lane, s1 = s0 + 64;
-            const bool two = w + 1 <= wlast;
-            const double x0 = P.samp[0][s0], y0 = P.samp[1][s0], z0 = P.samp[2][s0];
-            double x1 = 0, y1 = 0, z1 = 0;
-            if (two) {
-                x1 = P.samp[0][s1];
-                y1 = P.samp[1][s1];
-                z1 = P.samp[2][s1];
-            }
-            {
-                const double dx = x0 - c[0], dy = y0 - c[1], dz = z0 - c[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const uint64_t b = __ballot(s0 >= begin && s0 < end && dd <= r2);
-                if (b) set_word<KW>(cur, w, b, lane);
-            }
-            if (two) {
-                const double dx = x1 - c[0], dy = y1 - c[1], dz = z1 - c[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const uint64_t b = __ballot(s1 >= begin && s1 < end && dd <= r2);
-                if (b) set_word<KW>(cur, w + 1, b, lane);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- the five shots of one step, painted together
-// The five shot centres of a step are 0.0102 apart, so their 3x3 neighbourhoods overlap almost
-// entirely.  Each candidate sample is loaded once and tested against all five centres; the per-word
-// hit ballots b_0..b_4 are wave-uniform, so the reference's shot-by-shot bookkeeping (bpw:572-577:
-// count newly painted, paint, valid = affected minus last shot, last = affected) runs on the scalar
-// unit for that word and is written back to the lane that owns the word.  Words outside the
-// neighbourhood have no hits in any shot: painted is unchanged and their last-shot bits become 0.
-// The centres are written to LDS by the shot loop (a register array indexed by the runtime shot
-// number would live in scratch) and read back wave-uniformly here.
-struct ShotCentres {
-    double c[PAINT_PER_ACTION][3];
-};
-
-template <int KW>
-__device__ bool paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane,
-                                  uint64_t painted[KW_MAX],
-                                  const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
-                                  int &pixel_counter) {
-    const double r2 = radius * radius;
-    ShotCentres sc;
-#pragma unroll
-    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-        sc.c[k][0] = cen_lds[3 * k];
-        sc.c[k][1] = cen_lds[3 * k + 1];
-        sc.c[k][2] = cen_lds[3 * k + 2];
-    }
-    int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-        const int icx = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a1), P.sg_o1, P.sg_inv, P.sg_nx);
-        const int icy = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a2), P.sg_o2, P.sg_inv, P.sg_ny);
-        cx_lo = icx < cx_lo ? icx : cx_lo;
-        cx_hi = icx > cx_hi ? icx : cx_hi;
-        cy_lo = icy < cy_lo ? icy : cy_lo;
-        cy_hi = icy > cy_hi ? icy : cy_hi;
-    }
-#ifdef PRL_FORCE_PER_SHOT_PAINT                     // diagnostic build: exercise the general path in the parity tests
-    return false;
-#endif
-    if (cy_hi - cy_lo > 1) return false;            // centres spread over > 2 cell rows: caller paints shot by shot
-    // rows cy_lo-1 .. cy_hi+1 (<= 4), columns cx_lo-1 .. cx_hi+1: lanes 0..7 fetch the range bounds
-    const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
-    const int rcy = cy_lo - 1 + (lane >> 1);
-    const bool ok = lane < 8 && rcy <= cy_hi + 1 && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
-    const int bound = ok ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
-    int rb[4], re[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rb[r] = __builtin_amdgcn_readlane(bound, 2 * r);
-        re[r] = __builtin_amdgcn_readlane(bound, 2 * r + 1);
-    }
-    int done_w = -1;                                 // a word shared by two rows' ranges is handled once
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (re[r] <= rb[r]) continue;
-        const int wlast = (re[r] - 1) >> 6;
-        for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
-            WCNT(5, 1);
-            const int s = (w << 6) + lane;
-            const double x = P.samp[0][s], y = P.samp[1][s], z = P.samp[2][s];
-            const bool in = (s >= rb[0] && s < re[0]) || (s >= rb[1] && s < re[1]) || (s >= rb[2] && s < re[2]) ||
-                            (s >= rb[3] && s < re[3]);
-            uint64_t b[PAINT_PER_ACTION];
-            uint64_t any = 0;
-#pragma unroll
-            for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-                const double dx = x - sc.c[k][0], dy = y - sc.c[k][1], dz = z - sc.c[k][2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                b[k] = __ballot(in && dd <= r2);
-                any |= b[k];
-            }
-            done_w = w;
-            const int owner = w & 63, slot = w >> 6;
-            uint64_t pw = 0, lw = 0;
-#pragma unroll
-            for (int k = 0; k < KW; ++k)
-                if (k == slot) {
-                    pw = bcast_u64(painted[k], owner);
-                    lw = bcast_u64(last[k], owner);
-                }
-            if (any == 0 && lw == 0) continue;       // nothing to record for this word
-            // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
-            // affected), folded: the newly painted samples of the five shots are the union minus what was
-            // painted before, and each shot's valid set only looks one shot back
-            succeeded += __popcll(any & ~pw);
-            pw |= any;
-            uint64_t uw = b[0] & ~lw;
-#pragma unroll
-            for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
-            lw = b[PAINT_PER_ACTION - 1];
-            pixel_counter += __popcll(uw);
-#pragma unroll
-            for (int k = 0; k < KW; ++k)
-                if (k == slot && lane == owner) {
-                    painted[k] = pw;
-                    new_last[k] = lw;
-                }
-        }
-    }
-    return true;
-}
-
-// ---------------------------------------------------------------- observation (rge:306-319)
-__device__ __forceinline__ int grid_index_2(PartRef P, double val) {
-    const double rel = (val - P.r2min) / (P.r2max - P.r2min);
-    const double g = rel * GRID_GRANULARITY;
-    int gi;
-    if (!(g > -2147483648.0 && g < 2147483648.0)) gi = g > 0 ? GRID_GRANULARITY - 1 : 0;
-    else gi = (int)g;
-    return gi < 0 ? 0 : (gi > GRID_GRANULARITY - 1 ? GRID_GRANULARITY - 1 : gi);
-}
-
-__device__ __forceinline__ double clip01(double v) { return v < 0 ? 0.0 : (v > 1 ? 1.0 : v); }
-
-__device__ __forceinline__ int handle_pos(double v) {        // rge:92-98
-    if (v == 0) return 0;
-    if (v == 1) return 21;
-    return (int)(v * 20) + 1;
-}
-
-// CPython float_floor_div, the `//` of bpw:1030 (exact floor of the true quotient)
-__device__ __forceinline__ double py_floor_div(double vx, double wx) {
-    const double mod = fmod(vx, wx);
-    double div = (vx - mod) / wx;
-    if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
-    if (div != 0.0) {
-        double fl = floor(div);
-        if (div - fl > 0.5) fl += 1.0;
-        return fl;
-    }
-    return copysign(0.0, vx / wx);
-}
-
-// bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
-// is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
-template <int KW>
-__device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
-                                     int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
-    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    cnt[lane] = 0;
-    cnt[64 + lane] = 0;
-    const double two_pi = 2 * PI, basis = two_pi / g;
-    for (int w = 0; w < P.n_words; ++w) {
-        const uint64_t vw = P.word_valid[w];
-        uint64_t pw = 0;
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
-        if (!((vw >> lane) & 1)) continue;
-        const int s = (w << 6) + lane;
-        const double rx = sx[s] - x1, ry = sy[s] - x2;
-        if (rx == 0 && ry == 0) continue;
-        double ang = atan2(ry, rx);
-        if (ang < 0) ang = two_pi + ang;
-        int idx = (int)py_floor_div(ang, basis);
-        idx = idx > g - 1 ? g - 1 : (idx < 0 ? 0 : idx);
-        atomicAdd(&cnt[idx], 1);
-        if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
-    }
-    if (lane < g) {
-        const int t = cnt[lane], u = cnt[64 + lane];
-        out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
-    }
-}
-
-// GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
-// its registers or code.
-template <int KW, bool GENSEC>
-__device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
-                                 const uint64_t painted[KW_MAX], int lane, double *out) {
-    // bpw:965-978 get_normalized_pose
-    const double r = C.paint_radius;
-    const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
-    const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
-    const int gi = grid_index_2(P, x2);
-    const double lo = P.grid_lo[gi], hi = P.grid_hi[gi];
-    double in1;
-    if (hi - lo == 0) in1 = 0;
-    else in1 = (x1 - lo + r) / (hi - lo + 2 * r);
-    const double np0 = clip01(in1), np1 = clip01(in2);
-    const int mode = C.obs_mode;
-    if (mode == PRL_OBS_SIMPLE) {
-        if (lane == 0) {
-            out[0] = np0;
-            out[1] = np1;
-        }
-        return;
-    }
-    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
-        // 16 cells per pass: four packed accumulators (4 x 16-bit per u64), four DPP sums, then lane j
-        // finishes cell j (one division per lane, one coalesced store)
-        const int cells = P.n_obs_cells;
-        for (int c0 = 0; c0 < cells; c0 += 16) {
-            uint64_t acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int w = lane + 64 * k;
-                if (w < P.n_words) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (c0 + j < cells)
-                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + j) * P.n_words + w])
-                                           << (16 * (j & 3));
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = wave_sum_u64(acc[g]);
-            const int cell = c0 + lane;
-            if (lane < 16 && cell < cells) {
-                uint64_t a4 = acc[0];
-#pragma unroll
-                for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
-                const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
-                const int num = P.cell_count[cell];
-                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
-            }
-        }
-        return;
-    }
-    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
-        __shared__ int s_cnt[4][128];
-        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, s_cnt[threadIdx.x >> 6], out);
-        if (lane == 0) {
-            if (mode == PRL_OBS_SECTION) {
-                out[C.obs_grad] = np0;
-                out[C.obs_grad + 1] = np1;
-            } else {
-                const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);
-                out[C.obs_grad] = 1.0 / (double)position;
-            }
-        }
-        return;
-    } else {
-    // section / discrete, 4-sector rule bpw:1034-1043
-    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
-    uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
-    // Pass 1, one word per lane and slot: a word whose box lies in one sector is counted whole.  A word
-    // that straddles only the vertical line x1 (its row is clear of x2) is resolved by its own lane
-    // below; only the rest -- the words of the row that x2 crosses -- is classified sample by sample.
-    bool vline[KW_MAX] = {false, false, false, false}, above[KW_MAX] = {false, false, false, false};
-    uint64_t valid[KW_MAX] = {0, 0, 0, 0}, smask[KW_MAX] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
-        bool straddle = false;
-        if (w < P.n_words) {
-            const f64x4 bb = reinterpret_cast<const f64x4 GAS *>(P.word_bbox)[w];
-            valid[k] = P.word_valid[w];
-            const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
-            if ((xg || xl) && (yg || yl)) {
-                const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
-                tot_l += (uint64_t)__popcll(valid[k]) << (16 * idx);
-                und_l += (uint64_t)__popcll(valid[k] & ~painted[k]) << (16 * idx);
-            } else if (valid[k] != 0) {
-                vline[k] = yg || yl;
-                above[k] = yg;
-                straddle = !vline[k];
-            }
-        }
-        smask[k] = __ballot(straddle);
-    }
-#ifndef PRL_ABLATE_STRADDLE
-    // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
-    // { xs > x1 } a suffix of the word: a 7-probe lower bound by the owning lane, all rows at once.
-    // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
-    {
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) any = any || vline[k];
-        if (__ballot(any)) {
-            int base[KW_MAX], pos[KW_MAX];
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                base[k] = vline[k] ? (lane + 64 * k) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
-                pos[k] = 0;
-            }
-#pragma unroll
-            for (int step = 32; step >= 0; step = step > 1 ? step >> 1 : step - 1) {   // 32 .. 1, then the closing probe
-                double probe[KW_MAX];
-#pragma unroll
-                for (int k = 0; k < KW; ++k) probe[k] = sx[base[k] + pos[k] + (step ? step - 1 : 0)];
-                __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip per step
-#pragma unroll
-                for (int k = 0; k < KW; ++k) pos[k] += probe[k] < x1 ? (step ? step : 1) : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int at = base[k] + (pos[k] < 64 ? pos[k] : 63);
-                int ub = (pos[k] < 64 && sx[at] == x1) ? (int)P.samp_ub[at] : pos[k];
-                if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
-                if (vline[k]) {
-                    const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
-                    const uint64_t ng = ub >= 64 ? ~0ull : ((1ull << ub) - 1);
-                    const uint64_t v = valid[k], u = valid[k] & ~painted[k];
-                    const uint64_t vg = __popcll(v & ~ng), vl = __popcll(v & lt), ve = __popcll(v) - vg - vl;
-                    const uint64_t ug = __popcll(u & ~ng), ul = __popcll(u & lt), ue = __popcll(u) - ug - ul;
-                    tot_l += above[k] ? (vg | (vl << 16) | (ve << 48)) : ((vl << 32) | ((vg + ve) << 48));
-                    und_l += above[k] ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
-                }
-            }
-        }
-    }
-#endif
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        uint64_t sm = smask[k];
-#ifdef PRL_ABLATE_STRADDLE
-        sm = 0;
-#endif
-        while (sm) {                                // wave-uniform loop over the words that straddle the tool
-            WCNT(6, 1);
-            const int L = __builtin_ctzll(sm);
-            sm &= sm - 1;
-            const int w2 = L + 64 * k;
-            const double xs = sx[(w2 << 6) + lane], ys = sy[(w2 << 6) + lane];
-            const uint64_t vs = P.word_valid[w2];
-            // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
-            // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
-            // 64 straddling words)
-            const uint64_t pw = bcast_u64(painted[k], L);
-            const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs) && !(xs == x1 && ys == x2);
-            const bool gy = ys > x2, lx = xs < x1;
-            const uint32_t sh = (xs > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys < x2) ? 16u : 24u));
-            const uint32_t one = cnt ? (1u << sh) : 0u;
-            tot_s += one;
-            und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
-        }
-    }
-    // widen the 8-bit straddle counters into the 16-bit fields
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
-        und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
-    }
-    tot_l = wave_sum_u64(tot_l);
-    und_l = wave_sum_u64(und_l);
-    if (lane == 0) {
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
-            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
-            out[q] = t == 0 ? 0.0 : (double)u / (double)t;
-        }
-        if (mode == PRL_OBS_SECTION) {
-            out[4] = np0;
-            out[5] = np1;
-        } else {
-            const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
-            out[4] = 1.0 / (double)position;
-        }
-    }
-    }
-}
-
-// ---------------------------------------------------------------- start-point RNG
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-__device__ __forceinline__ int draw_start(uint64_t seed, int env, uint64_t episode, int n_start) {
-    const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)env << 1) | 1) ^ (episode * 0xD1342543DE82EF95ull));
-    return (int)(((h >> 32) * (uint64_t)n_start) >> 32);
-}
-
-struct EnvState {                 // PRL_STATE_DOUBLES record
-    double pose[3], quat[4];
-    double last_angle, total_reward, total_return;
-    int terminate, terminate_counter, last_on_part, step_counter;
-    uint32_t episode;
-    int facet_hint;               // collision triangle the last ray of the previous step hit (-1: none); a cache
-    double last_ep_return, last_ep_reward;
-    int last_ep_len, last_ep_painted;
-};
-static_assert(sizeof(EnvState) == PRL_STATE_DOUBLES * 8, "state record layout");
-
-// Store the 128-byte record as one coalesced write: lane l < 16 writes double l.
-__device__ __forceinline__ void store_state(double *dst, const EnvState &S, int lane) {
-    const double *src = reinterpret_cast<const double *>(&S);
-    double v = 0;
-#pragma unroll
-    for (int k = 0; k < PRL_STATE_DOUBLES; ++k) v = lane == k ? src[k] : v;
-    if (lane < PRL_STATE_DOUBLES) dst[lane] = v;
-}
-
-__device__ __forceinline__ void reset_state(PartRef P, EnvState &S, int start) {   // rge:370-387, rob:366-372
-    S.pose[0] = P.start_pos[3 * start];
-    S.pose[1] = P.start_pos[3 * start + 1];
-    S.pose[2] = P.start_pos[3 * start + 2];
-    S.quat[0] = P.start_quat[4 * start];
-    S.quat[1] = P.start_quat[4 * start + 1];
-    S.quat[2] = P.start_quat[4 * start + 2];
-    S.quat[3] = P.start_quat[4 * start + 3];
-    S.last_angle = 0;
-    S.total_reward = 0;
-    S.total_return = 0;
-    S.terminate = 0;
-    S.terminate_counter = 0;
-    S.last_on_part = 1;
-    S.step_counter = 0;
-    S.episode += 1;
-    S.facet_hint = -1;
-}
-
-template <int KW>
-__device__ __forceinline__ void load_masks(const StepArgs &a, int env, int n_words, int lane, uint64_t painted[KW_MAX],
-                                           uint64_t last[KW_MAX]) {
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
-        const bool in = w < n_words;
-        painted[k] = in ? a.painted[(size_t)env * a.mask_stride + w] : 0;
-        last[k] = in ? a.last[(size_t)env * a.mask_stride + w] : 0;
-    }
-}
-
-template <int KW>
-__device__ __forceinline__ void store_masks(const StepArgs &a, int env, int n_words, int lane,
-                                            const uint64_t painted[KW_MAX], const uint64_t last[KW_MAX]) {
-#pragma unroll
-    for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
-        if (w < n_words) {
-            a.painted[(size_t)env * a.mask_stride + w] = painted[k];
-            a.last[(size_t)env * a.mask_stride + w] = last[k];
-        }
-    }
-}
-
-__host__ __device__ inline int obs_dim_of(int obs_mode, int obs_grad) {          // rge:166-173
-    switch (obs_mode) {
-    case PRL_OBS_SECTION: return obs_grad + 2;
-    case PRL_OBS_GRID: return obs_grad * obs_grad;
-    case PRL_OBS_SIMPLE: return 2;
-    default: return obs_grad + 1;
-    }
-}
 
 // ---------------------------------------------------------------- reset kernel (rge:370-387)
 template <int KW, bool GENSEC>

@@ -1,0 +1,291 @@
+// prl_device.hpp -- constants, table descriptor, diagnostic macros, wave-level helpers, reference arithmetic.
+// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
+// file for the overall design.  Compile with -ffp-contract=off.
+#pragma once
+
+namespace {
+
+
+constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples
+constexpr double PAINT_RADIUS = 0.051;          // bpw:42
+constexpr double STEP_SIZE = 0.051;             // bpw:43
+constexpr double HOOK_DISTANCE = 0.1;           // bpw:443
+constexpr int GRID_GRANULARITY = 100;           // bpw:447
+constexpr int PAINT_PER_ACTION = 5;             // rob:165
+constexpr int NOT_ON_PART_TERMINATE = 1000;     // rob:167
+constexpr double RAY_EPS_DET = 1e-12;
+constexpr double RAY_EPS_BARY = 1e-9;
+constexpr double PI = 3.141592653589793;
+
+// Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
+// space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
+// (address space 1) gives global_load with counted vmcnt waits.
+#define GAS __attribute__((address_space(1)))
+#define CAS __attribute__((address_space(4)))
+typedef const double GAS *gdouble_p;
+typedef const float GAS *gfloat_p;
+typedef const int GAS *gint_p;
+typedef const uint64_t GAS *gu64_p;
+typedef const uint8_t GAS *gu8_p;
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct PartDev {
+    int n_samples, n_samples_pad, n_words;
+    gdouble_p samp[3];
+    gdouble_p samp_a1, samp_a2;   // = samp[a1], samp[a2]: a dynamic index into samp[] would be a memory load of the pointer
+    gdouble_p word_bbox;
+    gu64_p word_valid;
+    gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
+    gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
+    double sg_o1, sg_o2, sg_inv;
+    int sg_nx, sg_ny;
+    gint_p sg_start;
+    int n_obs_cells;
+    gu64_p cell_mask;
+    gint_p cell_count;
+    int n_vertices;
+    gdouble_p vert[3];
+    gint_p vert_rank;
+    int adj_width;
+    gint_p vadj;
+    double vg_o1, vg_o2, vg_inv, vg_accept;
+    int vg_nx, vg_ny;
+    gint_p vg_start;
+    int n_triangles;
+    gdouble_p tri_rec;
+    int n_col, n_col_pad;
+    gdouble_p col[9];
+    gfloat_p col_bbox;
+    gint_p col_rank;
+    int col_convex, nbr_width;
+    gint_p col_nbr, col_orient;
+    gdouble_p col_rec;            // convex sets: [n_col_pad][12] v0 e1 e2 | edge margin | |e1 x e2|^2 | orient (derived in part_fill)
+    int n_col_chunks;
+    gfloat_p col_chunk_bbox;
+    gdouble_p grid_lo, grid_hi;
+    double r1min, r1max, r2min, r2max, lwr;
+    int a0, a1, a2;
+    int n_start;
+    gdouble_p start_pos, start_quat;
+    int n_beams;
+    gdouble_p beams;
+};
+
+// The part descriptor and the batch configuration are read-only for every kernel: typed as constant
+// address space so that their fields are fetched with scalar loads (s_load through the K$) instead
+// of wave-uniform vector loads the compiler has to assume the kernel's own stores may clobber.
+typedef const PartDev CAS &PartRef;
+typedef const PrlConfig CAS &CfgRef;
+
+struct StepArgs {
+    const PartDev *parts;
+    const PrlConfig *cfg;
+    const int *env_part;          // device, or nullptr
+    int n_envs, mask_stride;
+    uint64_t *painted, *last;
+    double *state;
+    const void *actions;
+    double *obs, *reward, *info, *final_obs;
+    uint8_t *done;
+    const int *start_idx;
+    const uint8_t *reset_mask;
+};
+
+#ifdef PRL_WAVE_TIMES      // per-wave trip counters of the data-dependent loops (diagnostic build only)
+__device__ uint32_t g_wcnt[1 << 16][8];
+#define WCNT(slot, v)                                                                        \
+    do {                                                                                     \
+        if ((threadIdx.x & 63) == 0) g_wcnt[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 0xffff][slot] += (v); \
+    } while (0)
+#else
+#define WCNT(slot, v)
+#endif
+
+// ---------------------------------------------------------------- diagnostic build only (-DPRL_PHASE_TIMING)
+// Per-phase s_memtime deltas summed over all waves into a buffer nothing else reads
+// (cdna_hip_programming.md "In-kernel stamps").  The product build contains no stamp.
+#ifdef PRL_PHASE_TIMING
+enum { PH_LOAD = 0, PH_RAY, PH_VERTEX, PH_BARY, PH_MATH, PH_BALL, PH_APPLY, PH_OBS, PH_STORE, PH_COUNT };
+__device__ unsigned long long g_phase_cycles[16];
+struct Prof {
+    unsigned long long acc[PH_COUNT];
+    unsigned long long prev;
+};
+#define PROF_ARG , Prof &prof
+#define PROF_PASS , prof
+#define STAMP(ph)                                                         \
+    do {                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        __builtin_amdgcn_s_waitcnt(0);                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+        prof.acc[ph] += now_ - prof.prev;                                 \
+        prof.prev = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define STAMP(ph) \
+    do {          \
+    } while (0)
+#endif
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double bcast_d(double v, int src) {
+    src = rfl(src);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
+    src = rfl(src);
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// Wave-wide min/max by DPP row shifts + row broadcasts (VALU speed) instead of ds_bpermute chains.
+// After the six steps lane 63 holds the reduction of all 64 lanes; it is broadcast with readlane.
+// dpp_ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143.  Lanes with no source
+// (bound_ctrl off) keep `old`, which is the lane's own value -- harmless for idempotent min/max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+#define WAVE_REDUCE_DPP(T, v, OP, DPPF)               \
+    do {                                              \
+        T x_;                                         \
+        x_ = DPPF<0x111, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x112, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x114, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x118, 0xf>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x142, 0xa>(v); v = OP(x_, v);      \
+        x_ = DPPF<0x143, 0xc>(v); v = OP(x_, v);      \
+    } while (0)
+
+#define OP_MIN(x, y) ((x) < (y) ? (x) : (y))
+#define OP_MAX(x, y) ((x) > (y) ? (x) : (y))
+
+__device__ __forceinline__ double wave_min_d(double v) {
+    WAVE_REDUCE_DPP(double, v, OP_MIN, dpp_d);
+    return bcast_d(v, 63);
+}
+
+__device__ __forceinline__ double wave_max_d(double v) {
+    WAVE_REDUCE_DPP(double, v, OP_MAX, dpp_d);
+    return bcast_d(v, 63);
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+    WAVE_REDUCE_DPP(int, v, OP_MIN, dpp_i);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Wave-wide sum the same way; a lane without a source contributes 0 (old = 0).  Used on packed
+// 16-bit counters too: partial sums never carry across fields as long as the totals fit.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    v += dpp0_u64<0x111, 0xf>(v);
+    v += dpp0_u64<0x112, 0xf>(v);
+    v += dpp0_u64<0x114, 0xf>(v);
+    v += dpp0_u64<0x118, 0xf>(v);
+    v += dpp0_u64<0x142, 0xa>(v);
+    v += dpp0_u64<0x143, 0xc>(v);
+    return bcast_u64(v, 63);
+}
+
+// A wave-uniform double computed by the vector ALU sits in a VGPR pair; moving it to scalar
+// registers frees vector registers for the per-lane work (masks, Moller-Trumbore temporaries).
+__device__ __forceinline__ double uni_d(double v) {
+    return __hiloint2double(rfl(__double2hiint(v)), rfl(__double2loint(v)));
+}
+
+__device__ __forceinline__ double sel3(double x, double y, double z, int axis) {
+    return axis == 0 ? x : (axis == 1 ? y : z);
+}
+
+// ---------------------------------------------------------------- reference arithmetic
+// numpy.dot on 3-vectors = OpenBLAS ddot = fused chain (oracle/paint_oracle.c dot3_np)
+__device__ __forceinline__ double dot3_np(double a0, double a1, double a2, double b0, double b1, double b2) {
+    return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
+}
+
+// this project's multiplyTransforms rotation (paintrl_amd/geometry.py quat_rotate)
+__device__ __forceinline__ void quat_rotate(const double q[4], double v0, double v1, double v2, double o[3]) {
+    double t0 = 2.0 * (q[1] * v2 - q[2] * v1);
+    double t1 = 2.0 * (q[2] * v0 - q[0] * v2);
+    double t2 = 2.0 * (q[0] * v1 - q[1] * v0);
+    o[0] = (v0 + q[3] * t0) + (q[1] * t2 - q[2] * t1);
+    o[1] = (v1 + q[3] * t1) + (q[2] * t0 - q[0] * t2);
+    o[2] = (v2 + q[3] * t2) + (q[0] * t1 - q[1] * t0);
+}
+
+__device__ __forceinline__ void transform_point(const double pos[3], const double q[4], double v0, double v1,
+                                                double v2, double o[3]) {
+    double r[3];
+    quat_rotate(q, v0, v1, v2, r);
+    o[0] = pos[0] + r[0];
+    o[1] = pos[1] + r[1];
+    o[2] = pos[2] + r[2];
+}
+
+// rob:93-100 get_pose_orn + bpw:32-37 normalize
+__device__ __forceinline__ void pose_orn_quat(const double orn[3], double q[4]) {
+    double x = 0.0 * orn[2] - 1.0 * orn[1];
+    double y = 1.0 * orn[0] - 0.0 * orn[2];
+    double z = 0.0 * orn[1] - 0.0 * orn[0];
+    double w = 1.0 + __builtin_fma(1.0, orn[2], __builtin_fma(0.0, orn[1], 0.0 * orn[0]));
+    double mag2 = (((0.0 + x * x) + y * y) + z * z) + w * w;
+    if (fabs(mag2 - 1.0) > 0.00001) {
+        double mag = sqrt(mag2);
+        x /= mag;
+        y /= mag;
+        z /= mag;
+        w /= mag;
+    }
+    q[0] = x;
+    q[1] = y;
+    q[2] = z;
+    q[3] = w;
+}
+
+// rob:266-271 _get_tcp_orn_norm
+__device__ __forceinline__ void tcp_orn_norm(const double pose[3], const double quat[4], double n[3]) {
+    double along[3];
+    transform_point(pose, quat, 0.0, 0.0, 1.0, along);
+    double v0 = along[0] - pose[0], v1 = along[1] - pose[1], v2 = along[2] - pose[2];
+    double norm = sqrt(dot3_np(v0, v1, v2, v0, v1, v2));
+    n[0] = v0 / norm;
+    n[1] = v1 / norm;
+    n[2] = v2 / norm;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {
+    double f = floor((x - origin) * inv);
+    f = f < -2.0 ? -2.0 : f;                       // NaN stays NaN -> comparison below sends it out of range
+    f = f > (double)(n + 1) ? (double)(n + 1) : f;
+    return (f == f) ? (int)f : -2;
+}
+
+}  // namespace

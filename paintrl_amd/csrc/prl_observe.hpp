@@ -1,0 +1,260 @@
+// prl_observe.hpp -- observations (rge:306-319, bpw:965-1139).
+// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
+// file for the overall design.  Compile with -ffp-contract=off.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- observation (rge:306-319)
+__device__ __forceinline__ int grid_index_2(PartRef P, double val) {
+    const double rel = (val - P.r2min) / (P.r2max - P.r2min);
+    const double g = rel * GRID_GRANULARITY;
+    int gi;
+    if (!(g > -2147483648.0 && g < 2147483648.0)) gi = g > 0 ? GRID_GRANULARITY - 1 : 0;
+    else gi = (int)g;
+    return gi < 0 ? 0 : (gi > GRID_GRANULARITY - 1 ? GRID_GRANULARITY - 1 : gi);
+}
+
+__device__ __forceinline__ double clip01(double v) { return v < 0 ? 0.0 : (v > 1 ? 1.0 : v); }
+
+__device__ __forceinline__ int handle_pos(double v) {        // rge:92-98
+    if (v == 0) return 0;
+    if (v == 1) return 21;
+    return (int)(v * 20) + 1;
+}
+
+// CPython float_floor_div, the `//` of bpw:1030 (exact floor of the true quotient)
+__device__ __forceinline__ double py_floor_div(double vx, double wx) {
+    const double mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0 && ((wx < 0) != (mod < 0))) div -= 1.0;
+    if (div != 0.0) {
+        double fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+        return fl;
+    }
+    return copysign(0.0, vx / wx);
+}
+
+// bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
+// is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
+template <int KW>
+__device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
+                                     int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
+    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
+    cnt[lane] = 0;
+    cnt[64 + lane] = 0;
+    const double two_pi = 2 * PI, basis = two_pi / g;
+    for (int w = 0; w < P.n_words; ++w) {
+        const uint64_t vw = P.word_valid[w];
+        uint64_t pw = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
+        if (!((vw >> lane) & 1)) continue;
+        const int s = (w << 6) + lane;
+        const double rx = sx[s] - x1, ry = sy[s] - x2;
+        if (rx == 0 && ry == 0) continue;
+        double ang = atan2(ry, rx);
+        if (ang < 0) ang = two_pi + ang;
+        int idx = (int)py_floor_div(ang, basis);
+        idx = idx > g - 1 ? g - 1 : (idx < 0 ? 0 : idx);
+        atomicAdd(&cnt[idx], 1);
+        if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
+    }
+    if (lane < g) {
+        const int t = cnt[lane], u = cnt[64 + lane];
+        out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
+    }
+}
+
+// GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
+// its registers or code.
+template <int KW, bool GENSEC>
+__device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
+                                 const uint64_t painted[KW_MAX], int lane, double *out) {
+    // bpw:965-978 get_normalized_pose
+    const double r = C.paint_radius;
+    const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
+    const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
+    const int gi = grid_index_2(P, x2);
+    const double lo = P.grid_lo[gi], hi = P.grid_hi[gi];
+    double in1;
+    if (hi - lo == 0) in1 = 0;
+    else in1 = (x1 - lo + r) / (hi - lo + 2 * r);
+    const double np0 = clip01(in1), np1 = clip01(in2);
+    const int mode = C.obs_mode;
+    if (mode == PRL_OBS_SIMPLE) {
+        if (lane == 0) {
+            out[0] = np0;
+            out[1] = np1;
+        }
+        return;
+    }
+    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
+        // 16 cells per pass: four packed accumulators (4 x 16-bit per u64), four DPP sums, then lane j
+        // finishes cell j (one division per lane, one coalesced store)
+        const int cells = P.n_obs_cells;
+        for (int c0 = 0; c0 < cells; c0 += 16) {
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int w = lane + 64 * k;
+                if (w < P.n_words) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (c0 + j < cells)
+                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + j) * P.n_words + w])
+                                           << (16 * (j & 3));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = wave_sum_u64(acc[g]);
+            const int cell = c0 + lane;
+            if (lane < 16 && cell < cells) {
+                uint64_t a4 = acc[0];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
+                const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
+                const int num = P.cell_count[cell];
+                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
+            }
+        }
+        return;
+    }
+    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
+        __shared__ int s_cnt[4][128];
+        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, s_cnt[threadIdx.x >> 6], out);
+        if (lane == 0) {
+            if (mode == PRL_OBS_SECTION) {
+                out[C.obs_grad] = np0;
+                out[C.obs_grad + 1] = np1;
+            } else {
+                const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);
+                out[C.obs_grad] = 1.0 / (double)position;
+            }
+        }
+        return;
+    } else {
+    // section / discrete, 4-sector rule bpw:1034-1043
+    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
+    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
+    uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
+    // Pass 1, one word per lane and slot: a word whose box lies in one sector is counted whole.  A word
+    // that straddles only the vertical line x1 (its row is clear of x2) is resolved by its own lane
+    // below; only the rest -- the words of the row that x2 crosses -- is classified sample by sample.
+    bool vline[KW_MAX] = {false, false, false, false}, above[KW_MAX] = {false, false, false, false};
+    uint64_t valid[KW_MAX] = {0, 0, 0, 0}, smask[KW_MAX] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        bool straddle = false;
+        if (w < P.n_words) {
+            const f64x4 bb = reinterpret_cast<const f64x4 GAS *>(P.word_bbox)[w];
+            valid[k] = P.word_valid[w];
+            const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
+            if ((xg || xl) && (yg || yl)) {
+                const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
+                tot_l += (uint64_t)__popcll(valid[k]) << (16 * idx);
+                und_l += (uint64_t)__popcll(valid[k] & ~painted[k]) << (16 * idx);
+            } else if (valid[k] != 0) {
+                vline[k] = yg || yl;
+                above[k] = yg;
+                straddle = !vline[k];
+            }
+        }
+        smask[k] = __ballot(straddle);
+    }
+#ifndef PRL_ABLATE_STRADDLE
+    // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
+    // { xs > x1 } a suffix of the word: a 7-probe lower bound by the owning lane, all rows at once.
+    // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
+    {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) any = any || vline[k];
+        if (__ballot(any)) {
+            int base[KW_MAX], pos[KW_MAX];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                base[k] = vline[k] ? (lane + 64 * k) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
+                pos[k] = 0;
+            }
+#pragma unroll
+            for (int step = 32; step >= 0; step = step > 1 ? step >> 1 : step - 1) {   // 32 .. 1, then the closing probe
+                double probe[KW_MAX];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) probe[k] = sx[base[k] + pos[k] + (step ? step - 1 : 0)];
+                __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip per step
+#pragma unroll
+                for (int k = 0; k < KW; ++k) pos[k] += probe[k] < x1 ? (step ? step : 1) : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int at = base[k] + (pos[k] < 64 ? pos[k] : 63);
+                int ub = (pos[k] < 64 && sx[at] == x1) ? (int)P.samp_ub[at] : pos[k];
+                if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
+                if (vline[k]) {
+                    const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
+                    const uint64_t ng = ub >= 64 ? ~0ull : ((1ull << ub) - 1);
+                    const uint64_t v = valid[k], u = valid[k] & ~painted[k];
+                    const uint64_t vg = __popcll(v & ~ng), vl = __popcll(v & lt), ve = __popcll(v) - vg - vl;
+                    const uint64_t ug = __popcll(u & ~ng), ul = __popcll(u & lt), ue = __popcll(u) - ug - ul;
+                    tot_l += above[k] ? (vg | (vl << 16) | (ve << 48)) : ((vl << 32) | ((vg + ve) << 48));
+                    und_l += above[k] ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
+                }
+            }
+        }
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        uint64_t sm = smask[k];
+#ifdef PRL_ABLATE_STRADDLE
+        sm = 0;
+#endif
+        while (sm) {                                // wave-uniform loop over the words that straddle the tool
+            WCNT(6, 1);
+            const int L = __builtin_ctzll(sm);
+            sm &= sm - 1;
+            const int w2 = L + 64 * k;
+            const double xs = sx[(w2 << 6) + lane], ys = sy[(w2 << 6) + lane];
+            const uint64_t vs = P.word_valid[w2];
+            // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
+            // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
+            // 64 straddling words)
+            const uint64_t pw = bcast_u64(painted[k], L);
+            const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs) && !(xs == x1 && ys == x2);
+            const bool gy = ys > x2, lx = xs < x1;
+            const uint32_t sh = (xs > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys < x2) ? 16u : 24u));
+            const uint32_t one = cnt ? (1u << sh) : 0u;
+            tot_s += one;
+            und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
+        }
+    }
+    // widen the 8-bit straddle counters into the 16-bit fields
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
+        und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
+    }
+    tot_l = wave_sum_u64(tot_l);
+    und_l = wave_sum_u64(und_l);
+    if (lane == 0) {
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
+            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
+            out[q] = t == 0 ? 0.0 : (double)u / (double)t;
+        }
+        if (mode == PRL_OBS_SECTION) {
+            out[4] = np0;
+            out[5] = np1;
+        } else {
+            const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
+            out[4] = 1.0 / (double)position;
+        }
+    }
+    }
+}
+
+}  // namespace

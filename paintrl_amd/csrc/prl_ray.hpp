@@ -1,0 +1,276 @@
+// prl_ray.hpp -- closest two-sided ray hit against the collision triangles (rayTestBatch semantics).
+// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
+// file for the overall design.  Compile with -ffp-contract=off.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- ray: closest two-sided hit (rayTestBatch)
+#define FACET_EDGE_MARGIN 1.0e-6     // metres from every edge of the entered facet (single-facet fast path)
+#define FACET_MIN_COS2 0.01          // squared cosine between segment and facet normal: no grazing entries
+// Cull before the float64 Moller-Trumbore test:
+//   * 3-D float boxes (rounded outward) per triangle and per 64-triangle chunk; lane c tests chunk c,
+//     only surviving chunks are visited (one triangle per lane, boxes + 9 doubles in one round trip);
+//   * two stages: first only the near part of the segment, t <= 0.125 (the tool hovers 0.1 above
+//     the part, so this is where the hit almost always is, and the short box excludes back and side
+//     facets); the whole segment only if nothing was hit.  The closest hit of the whole segment is
+//     the closest hit of the near part whenever the latter exists, so the result is unchanged.
+// Equal t resolves to the lowest reference-order index (col_rank), as in paintrl_amd/geometry.py.
+struct SegBox {
+    float lo[3], hi[3];      // axis1, axis2, axis0
+};
+
+__device__ __forceinline__ SegBox seg_box(const double o3[3], const double d3[3], double tmax) {
+    SegBox b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double e = o3[k] + tmax * d3[k];
+        b.lo[k] = nextafterf((float)fmin(o3[k], e), -INFINITY);
+        b.hi[k] = nextafterf((float)fmax(o3[k], e), INFINITY);
+    }
+    return b;
+}
+
+__device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, const f32x4 b) {
+    return (s.lo[0] <= a.y) && (s.hi[0] >= a.x) && (s.lo[1] <= a.w) && (s.hi[1] >= a.z) && (s.lo[2] <= b.y) &&
+           (s.hi[2] >= b.x);
+}
+
+// The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
+// running count + number of passing lanes below), then the float64 test runs ONCE over the list
+// with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
+// One float64 Moller-Trumbore test per lane (triangle i, or none if i < 0); keeps the lane's best
+// (t, reference rank) and remembers which triangle and which determinant produced it.
+__device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], double d0, double d1, double d2,
+                                       double tmax, double &best_t, int &best_r, int &best_i, double &best_det) {
+    if (i >= 0) {
+        const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
+        const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
+        const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
+        const int rk = P.col_rank[i];
+        const double p0 = d1 * e22 - d2 * e21;
+        const double p1 = d2 * e20 - d0 * e22;
+        const double p2 = d0 * e21 - d1 * e20;
+        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+        if (fabs(det) >= RAY_EPS_DET) {
+            const double inv = 1.0 / det;
+            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+            const double q0 = s1 * e12 - s2 * e11;
+            const double q1 = s2 * e10 - s0 * e12;
+            const double q2 = s0 * e11 - s1 * e10;
+            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= tmax &&
+                (t < best_t || (t == best_t && rk < best_r))) {
+                best_t = t;
+                best_r = rk;
+                best_i = i;
+                best_det = det;
+            }
+        }
+    }
+}
+
+// The same test on the facet record of a convex set (one 96-byte gather per lane instead of ten
+// strided loads); `interior` reports a hit that meets the single-facet criterion of ray_closest_wave.
+__device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
+                                       double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
+    interior = false;
+    if (i >= 0) {
+        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec + (size_t)i * 12);
+        const f64x2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+        const int rk = P.col_rank[i];
+        const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
+        const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
+        const double p0 = d1 * e22 - d2 * e21;
+        const double p1 = d2 * e20 - d0 * e22;
+        const double p2 = d0 * e21 - d1 * e20;
+        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+        if (fabs(det) >= RAY_EPS_DET) {
+            const double inv = 1.0 / det;
+            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+            const double q0 = s1 * e12 - s2 * e11;
+            const double q1 = s2 * e10 - s0 * e12;
+            const double q2 = s0 * e11 - s1 * e10;
+            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= 1.0 &&
+                (t < best_t || (t == best_t && rk < best_r))) {
+                best_t = t;
+                best_r = rk;
+                best_i = i;
+                best_det = det;
+                interior = u >= m && v >= m && (u + v) <= 1.0 - m && orient * det > 0 &&
+                           det * det >= FACET_MIN_COS2 * dd * nn;
+            }
+        }
+    }
+}
+
+// Lane holding the wave's best (t, rank); -1 if no lane has a hit.
+__device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
+    if (__ballot(best_t < INFINITY) == 0) return -1;
+    tmin = wave_min_d(best_t);
+    const uint64_t tie = __ballot(best_t == tmin);
+    if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
+    const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
+    return __builtin_ctzll(__ballot(best_t == tmin && best_r == rmin));
+}
+
+// `hint` (in/out): collision-set position of the facet hit by the previous ray of this env, or -1.
+//
+// Convex fast path (collision set = boundary of a convex polytope, i.e. hull mode): a segment that
+// starts outside enters the polytope at one point, so every facet with a valid hit at or before the
+// entry parameter contains that point and therefore shares a vertex with any one of them.  If the
+// vertex-neighbourhood of `hint` holds a valid hit whose facet is ENTERED (orient * det > 0), the
+// closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
+// hit there, an exit hit, a facet without a neighbour list) takes the general search below.
+__device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3], int lane, double &t_out,
+                                double hit[3], int &hint) {
+    __shared__ int s_cand[4][64];
+    int *cand = s_cand[threadIdx.x >> 6];
+    const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
+    double best_t = INFINITY, best_det = 0, tmin = INFINITY;
+    int best_r = 0x7fffffff, best_i = -1, win = -1;
+#ifdef PRL_FORCE_GENERAL_RAY                         // diagnostic build: never take the convex fast path
+    hint = -1;
+#endif
+    if (P.col_convex && hint >= 0) {
+        // (1) The previous facet alone, wave-uniform on scalar-loaded data.  If the segment ENTERS the hull
+        // through it at a point at least FACET_EDGE_MARGIN away from its edges, and not at a grazing
+        // angle, no other facet can report a hit at or before that point: a second hit there would lie
+        // in the other facet's 1e-9 tolerance fringe, i.e. within nanometres of an edge of the entered
+        // facet.  The result is then this facet's own Moller-Trumbore value, arithmetic as in mt_one.
+        {
+            const int h = rfl(hint);
+            const double CAS *r = reinterpret_cast<const double CAS *>((uint64_t)P.col_rec) + (size_t)h * 12;
+            const double e10 = r[3], e11 = r[4], e12 = r[5], e20 = r[6], e21 = r[7], e22 = r[8];
+            const double p0 = d1 * e22 - d2 * e21;
+            const double p1 = d2 * e20 - d0 * e22;
+            const double p2 = d0 * e21 - d1 * e20;
+            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+            bool inside = false;
+            double t = 0;
+            if (fabs(det) >= RAY_EPS_DET) {
+                const double inv = 1.0 / det;
+                const double s0 = o[0] - r[0], s1 = o[1] - r[1], s2 = o[2] - r[2];
+                const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+                const double q0 = s1 * e12 - s2 * e11;
+                const double q1 = s2 * e10 - s0 * e12;
+                const double q2 = s0 * e11 - s1 * e10;
+                const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+                t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+                const double m = r[9], dd = (d0 * d0 + d1 * d1) + d2 * d2;
+                inside = u >= m && v >= m && (u + v) <= 1.0 - m && t >= 0.0 && t <= 1.0 && r[11] * det > 0 &&
+                         det * det >= FACET_MIN_COS2 * dd * r[10];
+            }
+            if (rfl(inside)) {
+                WCNT(7, 1);
+                t_out = t;
+                hit[0] = o[0] + t * d0;
+                hit[1] = o[1] + t * d1;
+                hit[2] = o[2] + t * d2;
+                return reinterpret_cast<const int CAS *>((uint64_t)P.col_rank)[h];
+            }
+        }
+        // (2) The facets that share a vertex with it, one per lane.  A lane whose facet is entered at an
+        // interior point holds the closest hit of the whole set by the same argument (there is at most
+        // one such lane): no reduction, no second round.
+        WCNT(4, 1);
+        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
+        const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
+        bool interior;
+        mt_rec(P, i1, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+        const uint64_t im = __ballot(interior);
+        if (im) {
+            win = __builtin_ctzll(im);
+            tmin = bcast_d(best_t, win);
+        } else {
+            // (3) otherwise the closest hit there, if it enters the hull, decides after a look at its own
+            // neighbourhood
+            win = ray_winner_lane(best_t, best_r, tmin);
+            if (win >= 0) {
+                const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
+                const double fdet = bcast_d(best_det, win);
+                const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
+                const bool entering = (double)P.col_orient[f] * fdet > 0;
+                if (entering && __ballot(i2 >= 0) != 0) {
+                    if (f != hint) {
+                        WCNT(4, 16);
+                        mt_rec(P, i2, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+                        win = ray_winner_lane(best_t, best_r, tmin);
+                    }
+                } else {
+                    win = -1;
+                }
+            }
+        }
+        if (win < 0) {
+            best_t = INFINITY;
+            best_r = 0x7fffffff;
+            best_i = -1;
+        }
+    }
+    if (win < 0) {
+        WCNT(0, 1);
+        const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
+        const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
+        const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
+        const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
+        for (int stage = 0; stage < 2; ++stage) {
+#ifdef PRL_PHASE_COUNTERS
+            if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
+#endif
+            const double tmax = stage == 0 ? 0.125 : 1.0;
+            if (stage == 1) WCNT(1, 1);
+            const SegBox sb = seg_box(o3, d3, tmax);
+            int n_cand = 0;
+            for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
+                const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
+                uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
+                while (cm) {
+                    WCNT(2, 1);
+                    const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+                    cm &= cm - 1;
+                    const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
+                    const bool pass = box_overlap(sb, ba, bb);
+                    const uint64_t pm = __ballot(pass);
+                    if (pm == 0) continue;
+                    const int np = __popcll(pm);
+                    if (n_cand + np > 64) {                        // list full: test what is queued first
+                        __builtin_amdgcn_wave_barrier();
+                        mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
+                        __builtin_amdgcn_wave_barrier();
+                        n_cand = 0;
+                    }
+                    if (pass)
+                        cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
+                    n_cand += np;
+                }
+            }
+            if (n_cand) {
+                __builtin_amdgcn_wave_barrier();
+                mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (__ballot(best_t < INFINITY)) break;
+        }
+        win = ray_winner_lane(best_t, best_r, tmin);
+    }
+    if (win < 0) {
+        t_out = INFINITY;
+        hint = -1;
+        return -1;
+    }
+    hint = __builtin_amdgcn_readlane(best_i, rfl(win));
+    t_out = tmin;
+    hit[0] = o[0] + tmin * d0;
+    hit[1] = o[1] + tmin * d1;
+    hit[2] = o[2] + tmin * d2;
+    return __builtin_amdgcn_readlane(best_r, rfl(win));
+}
+
+}  // namespace

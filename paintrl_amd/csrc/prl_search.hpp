@@ -1,0 +1,275 @@
+// prl_search.hpp -- nearest same-side vertex, nearest sample, hook point (bpw:508-534, 565).
+// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
+// file for the overall design.  Compile with -ffp-contract=off.
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------- bpw:526 nearest same-side vertex
+// Grid rows cy-1..cy+1 of a uniform grid: each row's three cells are one contiguous index range.
+// Lanes 0..5 fetch the six range bounds in one load; `rows` returns them wave-uniform.
+struct Rows3 {
+    int begin[3], count[3];
+};
+
+__device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int icx, int icy, int lane) {
+    const int r = lane >> 1, cy = icy - 1 + r;
+    const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > nx - 1 ? nx - 1 : icx + 1;
+    const bool ok = lane < 6 && cy >= 0 && cy < ny && cx0 <= cx1;
+    const int v = ok ? start[cy * nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+    Rows3 out;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int b = __builtin_amdgcn_readlane(v, 2 * k), e = __builtin_amdgcn_readlane(v, 2 * k + 1);
+        out.begin[k] = b;
+        out.count[k] = e - b;
+    }
+    return out;
+}
+
+__device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const double pt[3], int lane,
+                                        double &best_d, int &best_rank, int &best_idx) {
+    for (int b = begin; b < end; b += 128) {                   // two batches per trip: eight loads in flight
+        const int v0 = b + lane, v1 = v0 + 64;
+        const bool k0 = v0 < end, k1 = v1 < end;
+        double x0 = 0, y0 = 0, z0 = 0, x1 = 0, y1 = 0, z1 = 0;
+        int r0 = 0, r1 = 0;
+        if (k0) {
+            x0 = P.vert[0][v0];
+            y0 = P.vert[1][v0];
+            z0 = P.vert[2][v0];
+            r0 = P.vert_rank[v0];
+        }
+        if (k1) {
+            x1 = P.vert[0][v1];
+            y1 = P.vert[1][v1];
+            z1 = P.vert[2][v1];
+            r1 = P.vert_rank[v1];
+        }
+        if (k0) {
+            const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd < best_d || (dd == best_d && r0 < best_rank)) {
+                best_d = dd;
+                best_rank = r0;
+                best_idx = v0;
+            }
+        }
+        if (k1) {
+            const double dx = x1 - pt[0], dy = y1 - pt[1], dz = z1 - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd < best_d || (dd == best_d && r1 < best_rank)) {
+                best_d = dd;
+                best_rank = r1;
+                best_idx = v1;
+            }
+        }
+    }
+}
+
+// Exact nearest neighbour by expanding rings: the (2k+1)^2 cell block around the query's cell is
+// scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
+// outside the block is at least k cells away in the principal plane, so the result is exact once the
+// best distance is within k * 0.99 * cell.  After ring 3 the whole table is scanned.
+__device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
+    double best_d = INFINITY, dmin = INFINITY;
+    int best_rank = 0x7fffffff, best_idx = -1;
+    bool exact = false;
+    for (int ring = 1; ring <= 3 && !exact; ++ring) {
+        const int nrows = 2 * ring + 1;
+        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
+        const int rcy = icy - ring + (lane >> 1);
+        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
+        const int bound = okr ? P.vg_start[rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        // per-row begin and exclusive prefix of counts, wave-uniform (<= 7 rows)
+        int rbeg[7], rpre[8];
+        rpre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+            rbeg[r] = b0;
+            rpre[r + 1] = rpre[r] + ((r < nrows) ? e0 - b0 : 0);
+        }
+        const int total = rpre[7];
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            WCNT(3, 1);
+            const int c = c0 + lane;
+            if (c < total) {
+                int v = rbeg[0] + c;
+#pragma unroll
+                for (int r = 1; r < 7; ++r)
+                    if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
+                const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                const int rk = P.vert_rank[v];
+                if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                    best_d = dd;
+                    best_rank = rk;
+                    best_idx = v;
+                }
+            }
+        }
+        dmin = wave_min_d(best_d);
+        const double lim = ring * P.vg_accept;          // ring * 0.99 * cell
+        exact = dmin <= lim * lim;
+    }
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: exercise the whole-table scans
+    exact = false;
+#endif
+    if (!exact) {
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
+        dmin = wave_min_d(best_d);
+    }
+    const uint64_t tie = __ballot(best_d == dmin);
+    if (tie == 0) return -1;                                        // NaN query point
+    if ((tie & (tie - 1)) == 0) return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(tie)));
+    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
+    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
+    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
+}
+
+// ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1): nearest sample
+// Same exact expanding-ring search as for vertices, over the sample grid; equal distances resolve
+// to the lowest reference-order index.  Returns the device position of the sample, or -1.
+__device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(h2, P.sg_o2, P.sg_inv, P.sg_ny);
+    double best_d = INFINITY, dmin = INFINITY;
+    int best_rank = 0x7fffffff, best_idx = -1;
+    bool exact = false;
+    for (int ring = 1; ring <= 3 && !exact; ++ring) {
+        const int nrows = 2 * ring + 1;
+        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.sg_nx - 1 ? P.sg_nx - 1 : icx + ring;
+        const int rcy = icy - ring + (lane >> 1);
+        const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
+        const int bound = okr ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+            if (r >= nrows) continue;
+            for (int s0 = b0; s0 < e0; s0 += 64) {
+                const int sidx = s0 + lane;
+                if (sidx < e0) {
+                    const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const int rk = P.samp_rank[sidx];
+                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        best_d = dd;
+                        best_rank = rk;
+                        best_idx = sidx;
+                    }
+                }
+            }
+        }
+        dmin = wave_min_d(best_d);
+        const double lim = ring * (0.99 / P.sg_inv);        // ring * 0.99 * sample cell
+        exact = dmin <= lim * lim;
+    }
+#ifdef PRL_FORCE_FULL_SCANS
+    exact = false;
+#endif
+    if (!exact) {                                   // far from every sample: scan the whole table
+        best_d = INFINITY;
+        best_rank = 0x7fffffff;
+        best_idx = -1;
+        for (int s0 = 0; s0 < P.n_samples_pad; s0 += 64) {
+            const int sidx = s0 + lane;
+            const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            const int rk = P.samp_rank[sidx];
+            if (rk != 0x7fffffff && (dd < best_d || (dd == best_d && rk < best_rank))) {
+                best_d = dd;
+                best_rank = rk;
+                best_idx = sidx;
+            }
+        }
+        dmin = wave_min_d(best_d);
+    }
+    const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
+    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin && best_idx >= 0);
+    if (win == 0) return -1;
+    return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
+}
+
+// ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
+__device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
+#ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
+    const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
+#else
+#ifdef PRL_DOUBLE_VERTEX
+    {
+        const int v2 = nearest_vertex_wave(P, pt, lane);
+        asm volatile("" ::"s"(v2));
+    }
+#endif
+    const int vidx = nearest_vertex_wave(P, pt, lane);
+#endif
+    STAMP(PH_VERTEX);
+    if (vidx < 0) return false;
+    const int ti = lane < P.adj_width ? P.vadj[vidx * P.adj_width + lane] : -1;   // file order, -1 = pad
+    if (__ballot(ti >= 0) == 0) return false;
+    bool inside = false, ok = false;
+    double m = -INFINITY, n0 = 0, n1 = 0, n2 = 0;
+    if (ti >= 0) {
+        gdouble_p r = P.tri_rec + (size_t)ti * 16;
+        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(r);
+        const f64x2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
+        // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
+        const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
+        const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
+        const double d21 = dot3_np(x0, x1, x2, q3.x, q3.y, q4.x);
+        const double inv = q6.x;
+        double v = (q5.y * d20 - q5.x * d21) * inv;
+        double w = (q4.y * d21 - q5.x * d20) * inv;
+        double u = 1.0 - v - w;
+        if (inv == 0) {
+            u = -1;
+            v = -1;
+            w = -1;
+        }
+        inside = 0 <= u && u <= 1 && 0 <= v && v <= 1 && 0 <= w && w <= 1;
+        m = v < u ? v : u;
+        m = w < m ? w : m;
+        ok = m >= -1.0;
+        n0 = q6.y;
+        n1 = q7.x;
+        n2 = q7.y;
+    }
+    int j;
+    const uint64_t in_mask = __ballot(inside);
+    if (in_mask) {
+        j = __builtin_ctzll(in_mask);                               // first triangle containing the point
+    } else {
+        const uint64_t ok_mask = __ballot(ok);
+        if (ok_mask == 0) {
+            j = 0;                                                   // nothing beat -1: the first candidate stays
+        } else {
+            const double mx = wave_max_d(ok ? m : -INFINITY);
+            j = 63 - __builtin_clzll(__ballot(ok && m == mx));       // last one reaching the maximum
+        }
+    }
+    n0 = bcast_d(n0, j);
+    n1 = bcast_d(n1, j);
+    n2 = bcast_d(n2, j);
+    pose[0] = pt[0] + n0 * HOOK_DISTANCE;
+    pose[1] = pt[1] + n1 * HOOK_DISTANCE;
+    pose[2] = pt[2] + n2 * HOOK_DISTANCE;
+    orn[0] = -n0;
+    orn[1] = -n1;
+    orn[2] = -n2;
+    STAMP(PH_BARY);
+    return true;
+}
+
+}  // namespace
