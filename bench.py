@@ -95,8 +95,9 @@ def main():
     ap.add_argument('--actions', default='random', choices=['random', 'sweep'],
                     help="'sweep': every env follows an on-part serpentine with a random phase (SURVEY 8d item 2), so "
                          'episodes run long instead of ending after ~17 random steps')
-    ap.add_argument('--policy', default='random', choices=['random', 'mlp'],
-                    help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4)")
+    ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch'],
+                    help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4), one fused "
+                         "kernel per step (prl_policy_act); 'mlp-torch': the same net in torch eager")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -145,10 +146,20 @@ def main():
     stream_sync = torch.cuda.synchronize
 
     policy = None
-    if args.policy == 'mlp':
+    if args.policy != 'random':
         from paintrl_amd.rollout import MLPPolicy
         torch.manual_seed(1234)
-        policy = MLPPolicy(env.obs_dim, 4).to(device)
+        torch_policy = MLPPolicy(env.obs_dim, 4).to(device)
+        if args.policy == 'mlp':
+            from paintrl_amd.policy import FusedPolicy
+            fused = FusedPolicy(torch_policy)
+
+            class _Fused(object):                   # same call shape as MLPPolicy.act, float64 observations in
+                def act(self, obs32, generator=None):
+                    return fused.act(env.obs, generator=generator)
+            policy = _Fused()
+        else:
+            policy = torch_policy
 
     graph = None
     if policy is not None and args.graph:
@@ -213,7 +224,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
-                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, 'policy-MLP (6-256-128-4, fp32)' if args.policy == 'mlp' else ('on-part serpentine' if args.actions == 'sweep' else 'random')),
+                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, ('policy-MLP (6-256-128-4, fp32, %s)' % ('fused HIP kernel' if args.policy == 'mlp' else 'torch eager')) if args.policy != 'random' else ('on-part serpentine' if args.actions == 'sweep' else 'random')),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},

@@ -189,6 +189,25 @@ int prl_ray_batch(PrlPart *part, int n, const double *from, const double *to, in
 int prl_batch_timing_enable(PrlBatch *batch, int every);
 int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);
 
+/* ---- rollout policy: the caller of the step in BASELINE.json configs 3-4 ----------
+ * The policy of paint_ppo.py:170-195 (model fcnet_hiddens [256, 128], RLlib's default tanh, a linear
+ * logits head and a linear value head) as ONE launch on the env's stream, so that a rollout worker keeps
+ * the host out of the per-step loop: obs f64[N][in_dim] (what prl_batch_step wrote) -> action i32[N]
+ * (what the next prl_batch_step reads), log-probability, value estimate, optionally the logits.
+ * Weights are f32, row-major [in][out] (the transpose of torch.nn.Linear.weight); w3/b3 hold the
+ * n_actions logit columns followed by the value column.  Arithmetic is f32 (a k-ordered fmaf chain per
+ * output, tanhf, expf/logf); the action is the inverse-CDF draw for uniform[env] in [0, 1).
+ * Limits: hidden sizes multiples of 32, n_actions <= 31, 64 KB of LDS per 32 envs. */
+typedef struct {
+    int32_t in_dim, h1, h2, n_actions;
+    const float *w1, *b1;        /* [in_dim][h1], [h1] */
+    const float *w2, *b2;        /* [h1][h2], [h2] */
+    const float *w3, *b3;        /* [h2][n_actions + 1], [n_actions + 1] */
+} PrlPolicyWeights;              /* host struct holding device pointers */
+int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, const float *uniform, int32_t *action,
+                   float *logp /* or NULL */, float *value /* or NULL */, float *logits /* or NULL, [N][n_actions] */,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

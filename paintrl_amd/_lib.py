@@ -16,6 +16,12 @@ _up = C.POINTER(C.c_uint64)
 _fp = C.POINTER(C.c_float)
 
 
+class PrlPolicyWeights(C.Structure):
+    _fields_ = [('in_dim', C.c_int32), ('h1', C.c_int32), ('h2', C.c_int32), ('n_actions', C.c_int32),
+                ('w1', C.c_void_p), ('b1', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p),
+                ('w3', C.c_void_p), ('b3', C.c_void_p)]
+
+
 class PrlPartTables(C.Structure):
     _fields_ = [
         ('n_samples', C.c_int32), ('n_samples_pad', C.c_int32),
@@ -70,6 +76,7 @@ SYMBOLS = {
     'prl_batch_step': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'prl_batch_set_pose': (C.c_int, [_vp, C.c_int, _dp, _dp]),
     'prl_batch_observe': (C.c_int, [_vp, _vp, _vp]),
+    'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_state': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_returns': (C.c_int, [_vp, _vp, _vp]),

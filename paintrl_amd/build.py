@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, 'csrc')                      # paintrl_hip.hip + the prl_*.hpp it includes
 SOURCE = os.path.join(CSRC, 'paintrl_hip.hip')
+POLICY_SOURCE = os.path.join(CSRC, 'policy_mlp.hip')    # rollout policy (prl_policy_act), same library
 HEADER = os.path.join(_REPO, 'include', 'paintrl.h')
 # PAINTRL_LIB points the binding at another build of the same source (diagnostic builds of tools/)
 LIBRARY = os.environ.get('PAINTRL_LIB') or os.path.join(_HERE, 'libpaintrl_hip.so')
@@ -29,14 +30,14 @@ def is_stale():
         return True
     built = os.path.getmtime(LIBRARY)
     import glob
-    sources = [SOURCE, HEADER] + glob.glob(os.path.join(CSRC, '*.hpp'))
+    sources = [SOURCE, POLICY_SOURCE, HEADER] + glob.glob(os.path.join(CSRC, '*.hpp'))
     return any(os.path.getmtime(p) > built for p in sources)
 
 
 def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIBRARY
-    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, '-o', LIBRARY]
+    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, POLICY_SOURCE, '-o', LIBRARY]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -694,6 +694,9 @@ StepArgs base_args(PrlBatch *b) {
 }  // namespace
 
 // ================================================================= C ABI
+// error slot shared with the other translation units of the library (policy_mlp.hip); not exported
+extern "C" __attribute__((visibility("hidden"))) int prl_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 int prl_abi_version(void) { return PRL_ABI_VERSION; }

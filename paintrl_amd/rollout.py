@@ -44,10 +44,16 @@ class RolloutWorker(object):
     """Collects fragments of ``fragment`` steps from a BatchedPaintEnv (auto_reset=True) into
     preallocated [T, N, ...] device tensors with RLlib SampleBatch field names."""
 
-    def __init__(self, env, policy, fragment=FRAGMENT, seed=0):
+    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True):
         if not env.cfg.auto_reset:
             raise ValueError('RolloutWorker needs BatchedPaintEnv(auto_reset=True)')
         self.env, self.policy, self.T = env, policy, int(fragment)
+        # sampling goes through the fused kernel (prl_policy_act); the torch module stays the learner's
+        # copy -- call sync_policy() after an optimizer step.  fused=False keeps torch eager sampling.
+        self.fused = None
+        if fused:
+            from .policy import FusedPolicy
+            self.fused = FusedPolicy(policy)
         dev, n, od = env.device, env.n_envs, env.obs_dim
         f32 = dict(dtype=torch.float32, device=dev)
         self.buf = {
@@ -59,15 +65,25 @@ class RolloutWorker(object):
         }
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
-        self.obs = env.reset().to(torch.float32)
+        self.obs64 = env.reset()
+        self.obs = self.obs64.to(torch.float32)
         self.steps_done = 0
+
+    def sync_policy(self):
+        if self.fused is not None:
+            self.fused.sync()
+
+    def _act(self):
+        if self.fused is not None:
+            return self.fused.act(self.obs64, generator=self.gen)
+        return self.policy.act(self.obs, self.gen)
 
     @torch.no_grad()
     def collect(self):
         """One fragment.  Returns (batch dict, last value estimates, gathered episode returns)."""
         b, env = self.buf, self.env
         for t in range(self.T):
-            actions, logp, value = self.policy.act(self.obs, self.gen)
+            actions, logp, value = self._act()
             obs64, reward, done, info = env.step(actions)
             b['obs'][t] = self.obs
             b['actions'][t] = actions
@@ -78,9 +94,10 @@ class RolloutWorker(object):
             b['infos_reward'][t] = info[:, 0]
             b['infos_penalty'][t] = info[:, 1]
             b['new_obs'][t] = torch.where(done.unsqueeze(-1), env.final_obs, obs64).to(torch.float32)
+            self.obs64 = obs64
             self.obs = obs64.to(torch.float32)
         self.steps_done += self.T
-        _, _, last_value = self.policy.act(self.obs, self.gen)
+        _, _, last_value = self._act()
         returns = pdist.gather_returns(env.episode_returns())       # once per fragment, RCCL when world > 1
         return b, last_value, returns
 
