@@ -156,7 +156,7 @@ def main():
 
             class _Fused(object):                   # same call shape as MLPPolicy.act, float64 observations in
                 def act(self, obs32, generator=None):
-                    return fused.act(env.obs, generator=generator)
+                    return fused.act(env.obs)        # in-kernel sampling stream (graph-safe, no torch.rand launch)
             policy = _Fused()
         else:
             policy = torch_policy

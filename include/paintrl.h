@@ -196,15 +196,19 @@ int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);
  * (what the next prl_batch_step reads), log-probability, value estimate, optionally the logits.
  * Weights are f32, row-major [in][out] (the transpose of torch.nn.Linear.weight); w3/b3 hold the
  * n_actions logit columns followed by the value column.  Arithmetic is f32 (a k-ordered fmaf chain per
- * output, tanhf, expf/logf); the action is the inverse-CDF draw for uniform[env] in [0, 1).
- * Limits: hidden sizes multiples of 32, n_actions <= 31, 64 KB of LDS per 32 envs. */
+ * output, a fast tanh, expf/logf); the action is the inverse-CDF draw for uniform[env] in [0, 1), or,
+ * with uniform == NULL, for a counter-based random number keyed by (rng_seed, env, rng_count[env]++):
+ * rng_count is a zero-initialised u32[N] device array the caller keeps alive (race-free, and safe to
+ * replay from a captured HIP graph).  Limits: hidden sizes multiples of 32, n_actions <= 31, 64 KB of
+ * LDS per 32 envs. */
 typedef struct {
     int32_t in_dim, h1, h2, n_actions;
     const float *w1, *b1;        /* [in_dim][h1], [h1] */
     const float *w2, *b2;        /* [h1][h2], [h2] */
     const float *w3, *b3;        /* [h2][n_actions + 1], [n_actions + 1] */
 } PrlPolicyWeights;              /* host struct holding device pointers */
-int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, const float *uniform, int32_t *action,
+int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, const float *uniform /* or NULL */,
+                   uint32_t *rng_count /* or NULL if uniform is given */, uint64_t rng_seed, int32_t *action,
                    float *logp /* or NULL */, float *value /* or NULL */, float *logits /* or NULL, [N][n_actions] */,
                    void *stream);
 

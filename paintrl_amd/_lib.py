@@ -76,7 +76,7 @@ SYMBOLS = {
     'prl_batch_step': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'prl_batch_set_pose': (C.c_int, [_vp, C.c_int, _dp, _dp]),
     'prl_batch_observe': (C.c_int, [_vp, _vp, _vp]),
-    'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_state': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_returns': (C.c_int, [_vp, _vp, _vp]),

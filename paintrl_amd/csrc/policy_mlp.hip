@@ -32,10 +32,19 @@ struct PolicyArgs {
     PrlPolicyWeights w;
     int n, o_off;                 // o_off: float offset of the head tiles in LDS (they reuse the X/H1 area when it is large enough)
     const double *obs;
-    const float *uniform;
+    const float *uniform;         // one number per env, or nullptr: draw from the per-env counter stream
+    uint32_t *rng_count;
+    uint64_t rng_seed;
     int32_t *action;
     float *logp, *value, *logits;
 };
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {          // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 
 __device__ __forceinline__ int acc_row(int g, int lane) { return (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5); }
 
@@ -124,7 +133,14 @@ __global__ __launch_bounds__(256) void policy_act_kernel(PolicyArgs a) {
         for (int j = 1; j < A; ++j) m = fmaxf(m, o[j]);
         float sum = 0.0f;
         for (int j = 0; j < A; ++j) sum += expf(o[j] - m);
-        const float lse = m + logf(sum), u = a.uniform[env];
+        float u;
+        if (a.uniform) {
+            u = a.uniform[env];
+        } else {                                    // counter-based: (seed, env, draws so far) -> 24 random bits
+            const uint32_t c = a.rng_count[env]++;
+            u = (float)(mix64(a.rng_seed ^ mix64(((uint64_t)env << 32) | c)) >> 40) * (1.0f / 16777216.0f);
+        }
+        const float lse = m + logf(sum);
         int act = A - 1;
         float cdf = 0.0f;
         for (int j = 0; j < A - 1; ++j) {
@@ -144,9 +160,10 @@ __global__ __launch_bounds__(256) void policy_act_kernel(PolicyArgs a) {
 
 }  // namespace
 
-extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *obs, const float *uniform, int32_t *action,
-                              float *logp, float *value, float *logits, void *stream) {
-    if (!w || !obs || !uniform || !action || n <= 0) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: null argument or n <= 0");
+extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *obs, const float *uniform, uint32_t *rng_count,
+                              uint64_t rng_seed, int32_t *action, float *logp, float *value, float *logits, void *stream) {
+    if (!w || !obs || !action || n <= 0) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: null argument or n <= 0");
+    if (!uniform && !rng_count) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: need uniform numbers or a counter array");
     if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: null weights");
     if (w->in_dim < 1 || w->h1 < 32 || w->h1 % 32 || w->h2 < 32 || w->h2 % 32 || w->n_actions < 1 || w->n_actions > 31)
         return prl_set_error_(PRL_E_UNSUPPORTED, "prl_policy_act: hidden sizes must be multiples of 32, 1..31 actions");
@@ -155,6 +172,8 @@ extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *ob
     a.n = n;
     a.obs = obs;
     a.uniform = uniform;
+    a.rng_count = rng_count;
+    a.rng_seed = rng_seed;
     a.action = action;
     a.logp = logp;
     a.value = value;

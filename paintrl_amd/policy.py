@@ -17,10 +17,12 @@ def _torch():
 
 
 class FusedPolicy(object):
-    def __init__(self, policy):
+    def __init__(self, policy, seed=0):
         self.policy = policy
         self.lib = _lib.load()
         self._w = None
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._rng_count = None                      # u32 per env, advanced by the kernel (in-kernel sampling stream)
         self.sync()
 
     @property
@@ -51,14 +53,18 @@ class FusedPolicy(object):
 
     def act(self, obs, uniform=None, generator=None, want_logits=False):
         """obs: float64 (N, in_dim) device tensor -> (int32 actions, float32 log-probabilities, float32 values
-        [, float32 logits]).  ``uniform``: float32 (N,) in [0, 1), drawn from ``generator`` if absent."""
+        [, float32 logits]).  ``uniform``: float32 (N,) in [0, 1); if absent it is drawn from ``generator``,
+        and if that is absent too the kernel draws from its own counter-based stream (seed, env, draw number)
+        -- no extra launch, and replayable from a captured HIP graph."""
         torch = _torch()
         if obs.dtype != torch.float64 or not obs.is_cuda or obs.dim() != 2 or obs.shape[1] != self._w.in_dim:
             raise ValueError('obs must be a float64 (N, %d) device tensor' % self._w.in_dim)
         obs = obs.contiguous()
         n = obs.shape[0]
-        if uniform is None:
+        if uniform is None and generator is not None:
             uniform = torch.rand(n, dtype=torch.float32, device=obs.device, generator=generator)
+        if uniform is None and (self._rng_count is None or self._rng_count.shape[0] != n):
+            self._rng_count = torch.zeros(n, dtype=torch.int32, device=obs.device)
         action = torch.empty(n, dtype=torch.int32, device=obs.device)
         logp = torch.empty(n, dtype=torch.float32, device=obs.device)
         value = torch.empty(n, dtype=torch.float32, device=obs.device)
@@ -66,7 +72,9 @@ class FusedPolicy(object):
         with torch.cuda.device(obs.device):
             stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
             _lib.check(self.lib.prl_policy_act(C.byref(self._w), n, C.c_void_p(obs.data_ptr()),
-                                               C.c_void_p(uniform.data_ptr()), C.c_void_p(action.data_ptr()),
+                                               C.c_void_p(uniform.data_ptr()) if uniform is not None else None,
+                                               C.c_void_p(self._rng_count.data_ptr()) if uniform is None else None,
+                                               C.c_uint64(self.seed), C.c_void_p(action.data_ptr()),
                                                C.c_void_p(logp.data_ptr()), C.c_void_p(value.data_ptr()),
                                                C.c_void_p(logits.data_ptr()) if want_logits else None, stream),
                        'prl_policy_act')

@@ -53,7 +53,7 @@ class RolloutWorker(object):
         self.fused = None
         if fused:
             from .policy import FusedPolicy
-            self.fused = FusedPolicy(policy)
+            self.fused = FusedPolicy(policy, seed=seed)
         dev, n, od = env.device, env.n_envs, env.obs_dim
         f32 = dict(dtype=torch.float32, device=dev)
         self.buf = {
@@ -75,7 +75,7 @@ class RolloutWorker(object):
 
     def _act(self):
         if self.fused is not None:
-            return self.fused.act(self.obs64, generator=self.gen)
+            return self.fused.act(self.obs64)              # in-kernel sampling stream keyed by the worker's seed
         return self.policy.act(self.obs, self.gen)
 
     @torch.no_grad()

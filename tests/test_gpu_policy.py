@@ -83,10 +83,33 @@ def test_fused_policy_follows_weight_updates_and_rejects_bad_shapes():
     C.memmove(C.byref(w), C.byref(fused._w), C.sizeof(w))
     w.h1 = 100                                          # not a multiple of 32
     out = torch.empty(64, dtype=torch.int32, device='cuda')
-    rc = lib.prl_policy_act(C.byref(w), 64, C.c_void_p(obs.data_ptr()), C.c_void_p(u.data_ptr()),
+    rc = lib.prl_policy_act(C.byref(w), 64, C.c_void_p(obs.data_ptr()), C.c_void_p(u.data_ptr()), None, 0,
                             C.c_void_p(out.data_ptr()), None, None, None, None)
     assert rc == -3 and b'multiples of 32' in lib.prl_last_error()
-    assert lib.prl_policy_act(None, 64, None, None, None, None, None, None, None) == -1
+    assert lib.prl_policy_act(None, 64, None, None, None, 0, None, None, None, None, None) == -1
+    rc = lib.prl_policy_act(C.byref(fused._w), 64, C.c_void_p(obs.data_ptr()), None, None, 0,
+                            C.c_void_p(out.data_ptr()), None, None, None, None)
+    assert rc == -1 and b'counter array' in lib.prl_last_error()
+
+
+def test_in_kernel_sampling_stream():
+    """Without uniforms or a generator the kernel draws from (seed, env, draw number): reproducible per seed,
+    different across seeds, envs and draws, and distributed like the policy."""
+    import torch
+    from paintrl_amd.policy import FusedPolicy
+    p = _policy(scale=3.0)
+    obs = torch.rand((1, 6), dtype=torch.float64, device='cuda').repeat(20000, 1)
+    a, b, c = FusedPolicy(p, seed=5), FusedPolicy(p, seed=5), FusedPolicy(p, seed=6)
+    a1, _, _, logits = a.act(obs, want_logits=True)
+    a2, _, _ = a.act(obs)
+    b1, _, _ = b.act(obs)
+    c1, _, _ = c.act(obs)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2) and not torch.equal(a1, c1)
+    prob = torch.softmax(logits[0].double(), -1).cpu().numpy()
+    for draw in (a1, a2, c1):
+        freq = np.bincount(draw.cpu().numpy(), minlength=4) / 20000.0
+        assert np.abs(freq - prob).max() < 0.02
+    assert int(a._rng_count.min()) == 2 and int(a._rng_count.max()) == 2
 
 
 def test_rollout_worker_samples_with_the_fused_kernel():
