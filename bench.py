@@ -98,6 +98,9 @@ def main():
     ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4), one fused "
                          "kernel per step (prl_policy_act); 'mlp-torch': the same net in torch eager")
+    ap.add_argument('--streams', type=int, default=1,
+                    help='issue a batched step as S launches of envs/S envs on S streams (independent env groups: a '
+                         "group's slowest wave then only delays that group); default 1 = one launch per step")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -131,8 +134,18 @@ def main():
                               obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
                               seed=pdist.rank_seed(5678, rank), max_possible_point=[9148, 14350])
     else:
-        env = BatchedPaintEnv(dt, args.envs, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
-                              overlap_penalty=overlap, seed=pdist.rank_seed(5678, rank), max_possible_point=9148)
+        if args.streams > 1 and (args.policy != 'random' or args.envs % args.streams):
+            raise SystemExit('--streams needs --policy random and a divisible --envs')
+        n_sub = args.envs // args.streams
+        subs = [BatchedPaintEnv(dt, n_sub, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
+                                overlap_penalty=overlap, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=9148)
+                for g in range(args.streams)]
+        env = subs[0]
+    if args.mixed:
+        if args.streams > 1:
+            raise SystemExit('--streams is not combined with --mixed')
+        subs = [env]
+    sub_streams = [torch.cuda.Stream(device=device) for _ in subs] if len(subs) > 1 else [None]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     total = args.steps + args.warmup
@@ -142,8 +155,12 @@ def main():
         phase = torch.randint(0, pattern.numel(), (args.envs,), generator=gen, device=device)
         steps_idx = torch.arange(total, device=device).unsqueeze(1)
         actions = pattern[(steps_idx + phase.unsqueeze(0)) % pattern.numel()].contiguous()
-    env.reset()
+    for e in subs:
+        e.reset()
     stream_sync = torch.cuda.synchronize
+    n_sub = args.envs // len(subs)
+    sub_actions = [actions] if len(subs) == 1 else [actions[:, g * n_sub:(g + 1) * n_sub].contiguous()
+                                                     for g in range(len(subs))]
 
     policy = None
     if args.policy != 'random':
@@ -181,40 +198,49 @@ def main():
             if graph is not None:
                 graph.replay()
                 continue
-            if policy is None:
+            if policy is None and len(subs) > 1:
+                for g, e in enumerate(subs):
+                    with torch.cuda.stream(sub_streams[g]):
+                        e.step_raw(sub_actions[g][k])
+            elif policy is None:
                 env.step_raw(actions[k])
             else:
                 act, _, _ = policy.act(env.obs.to(torch.float32), gen)
                 env.step_raw(act)
             if world > 1 and (k + 1) % FRAGMENT == 0:
-                pdist.gather_returns(env.episode_returns())
+                if len(subs) > 1:
+                    stream_sync()
+                pdist.gather_returns(torch.cat([e.episode_returns() for e in subs]))
 
     run(0, args.warmup)
     stream_sync()
     pdist.barrier()
     stream_sync()
-    env.timing(TIMING_EVERY)
+    for e in subs:
+        e.timing(TIMING_EVERY)
     t0 = time.perf_counter()
     run(args.warmup, total)
     stream_sync()
     pdist.barrier()
     stream_sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = env.timing_read()
-    env.timing(0)
+    kernel_ms, launches = 0.0, 0
+    for e in subs:
+        ms_, n_ = e.timing_read()
+        kernel_ms, launches = kernel_ms + ms_, launches + n_
+        e.timing(0)
     elapsed = pdist.max_over_ranks(elapsed, device)
 
-    st = env.state()
-    episodes = int(st['episode'].sum()) - args.envs
+    episodes = sum(int(e.state()['episode'].sum()) for e in subs) - args.envs
     if rank == 0:
-        per_env, static, per_launch = algorithmic_bytes(dt, args.envs, env.obs_dim)
+        per_env, static, per_launch = algorithmic_bytes(dt, args.envs // len(subs), env.obs_dim)   # per LAUNCH
         # inside a captured HIP graph (--graph) the per-launch events are not recorded: no kernel time then
         avg_kernel_s = kernel_ms / launches / 1e3 if launches and kernel_ms > 0 else None
         achieved = per_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         # the committed PMC measurement is for the default workload only
-        if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random':
+        if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' and len(subs) == 1:
             with open(tpath) as f:
                 traffic = json.load(f).get('bytes_per_launch_%s' % args.obs_mode)
         value = world * args.steps / elapsed
@@ -227,7 +253,8 @@ def main():
                                    '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, ('policy-MLP (6-256-128-4, fp32, %s)' % ('fused HIP kernel' if args.policy == 'mlp' else 'torch eager')) if args.policy != 'random' else ('on-part serpentine' if args.actions == 'sweep' else 'random')),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
-                       'episodes_finished_rank0': episodes, 'parallelism': 'env-shard x%d' % world},
+                       'episodes_finished_rank0': episodes, 'launches_per_step': len(subs),
+                       'parallelism': 'env-shard x%d' % world + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs)) if len(subs) > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
                          'algorithmic_bytes_per_env_step': per_env, 'static_table_bytes': static,
@@ -237,7 +264,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs)
         print(json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)))
-    env.close()
+    for e in subs:
+        e.close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
