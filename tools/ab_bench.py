@@ -6,7 +6,6 @@
 Builds each source into a scratch library, then alternates timed runs (same GPU, same process,
 HIP-event kernel time) so that device-to-device and DVFS differences cancel.
 """
-import ctypes as C
 import os
 import subprocess
 import sys
