@@ -278,3 +278,34 @@ def test_observation_at_exact_sample_coordinates(obs_mode):
     o2, r2, d2, _ = orc.step(a)
     assert np.array_equal(o1.cpu().numpy(), o2) and np.array_equal(r1.cpu().numpy(), r2)
     env.close()
+
+
+@pytest.mark.parametrize('tex,kw_slots,obs_mode', [(120, 1, 'section'), (160, 2, 'section'), (120, 1, 'grid'), (160, 2, 'discrete')])
+def test_small_textures_use_the_one_and_two_slot_kernels(tex, kw_slots, obs_mode):
+    """The step kernel is instantiated per number of 64-word mask slots per lane (1..4); the standard door and
+    sheet use 3 and 4.  A 120x120 / 160x160 texture of the same door gives 47 / 76 words: the 1- and 2-slot
+    instantiations, checked against the oracle like the others (obs, reward, done, painted set, pose)."""
+    from paintrl_amd import part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(tex, tex), name='door_test')
+    dt = DeviceTables(tables)
+    assert (dt.n_words + 63) // 64 == kw_slots
+    n = 128
+    env = BatchedPaintEnv(dt, n, obs_mode=obs_mode, overlap_penalty=True)
+    orc = oracle.Oracle(tables, n, obs_mode=obs_mode, overlap_penalty=True)
+    start = np.arange(n) % 4
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    rng = np.random.RandomState(tex)
+    for k in range(30):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr), 'step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd) and np.array_equal(i.cpu().numpy(), ii), 'step %d' % k
+    bits = dt.mask_to_canonical(env.painted_words().cpu().numpy().view(np.uint64))
+    st = env.state()
+    for e in range(n):
+        assert np.array_equal(bits[e], orc.painted_bits(e))
+        assert np.array_equal(st['pose'][e], orc.state(e)['pose'])
+    env.close()
