@@ -22,7 +22,7 @@ from paintrl_amd.device_tables import DeviceTables  # noqa: E402
 
 def build(src, flags):
     out = os.path.join(tempfile.mkdtemp(prefix='prl_ab_'), 'libpaintrl_hip.so')
-    subprocess.check_call([hb.hipcc()] + hb.FLAGS + flags + ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, src, '-o', out])
+    subprocess.check_call([hb.hipcc()] + hb.FLAGS + flags + ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, src, hb.POLICY_SOURCE, '-o', out])
     return out
 
 

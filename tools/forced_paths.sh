@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 for flags in "-DPRL_FORCE_PER_SHOT_PAINT" "-DPRL_FORCE_FULL_SCANS -DPRL_FORCE_GENERAL_RAY"; do
   out=$(mktemp -d)/libpaintrl_hip.so
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Iinclude -Ipaintrl_amd/csrc $flags \
-        paintrl_amd/csrc/paintrl_hip.hip -o "$out"
+        paintrl_amd/csrc/paintrl_hip.hip paintrl_amd/csrc/policy_mlp.hip -o "$out"
   echo "== $flags"
   PAINTRL_LIB="$out" python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py -x -q \
         -k "not missing_library" 2>&1 | tail -1

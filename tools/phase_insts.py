@@ -11,7 +11,7 @@ sys.path.insert(0, REPO)
 from paintrl_amd import build as hb  # noqa: E402
 
 out = os.path.join(tempfile.mkdtemp(prefix='prl_pi_'), 'libpaintrl_hip.so')
-subprocess.check_call([hb.hipcc()] + hb.FLAGS + sys.argv[1:] + ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, '-o', out])
+subprocess.check_call([hb.hipcc()] + hb.FLAGS + sys.argv[1:] + ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, hb.POLICY_SOURCE, '-o', out])
 hb.LIBRARY = out
 import torch  # noqa: E402
 from paintrl_amd import part_tables, synth_parts  # noqa: E402

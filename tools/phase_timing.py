@@ -21,7 +21,7 @@ def main():
     flags = [] if '--no-stamps' in extra else ['-DPRL_PHASE_TIMING']
     extra = [e for e in extra if e != '--no-stamps']
     subprocess.check_call([hb.hipcc()] + hb.FLAGS + flags + extra +
-                          ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, '-o', out])
+                          ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, hb.POLICY_SOURCE, '-o', out])
     hb.LIBRARY = out                     # make paintrl_amd._lib load the diagnostic build
     import torch
     from paintrl_amd import _lib, part_tables, synth_parts

@@ -12,7 +12,7 @@ from paintrl_amd import build as hb  # noqa: E402
 
 out = os.path.join(tempfile.mkdtemp(prefix='prl_wt_'), 'libpaintrl_hip.so')
 subprocess.check_call([hb.hipcc()] + hb.FLAGS + ['-DPRL_WAVE_TIMES'] + sys.argv[1:] +
-                      ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, '-o', out])
+                      ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, hb.POLICY_SOURCE, '-o', out])
 hb.LIBRARY = out
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
