@@ -112,8 +112,8 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
             WCNT(5, 1);
             const int s = (w << 6) + lane;
             const double x = P.samp[0][s], y = P.samp[1][s], z = P.samp[2][s];
-            const bool in = (s >= rb[0] && s < re[0]) || (s >= rb[1] && s < re[1]) || (s >= rb[2] && s < re[2]) ||
-                            (s >= rb[3] && s < re[3]);
+            // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only
+            const bool in = s >= rb[r] && s < re[r];
             uint64_t b[PAINT_PER_ACTION];
             uint64_t any = 0;
 #pragma unroll
