@@ -3,14 +3,14 @@
 // The caller of the env step in BASELINE.json configs 3-4 is an RLlib rollout worker whose policy is
 // the fully connected net of paint_ppo.py:170-195 (fcnet_hiddens [256, 128], RLlib's default tanh,
 // a linear logits head and a linear value head).  In torch that is ~10 tiny launches per env step;
-// here it is ONE kernel on the env's stream: 32 envs per 256-thread workgroup, the three GEMMs on the
+// here it is ONE kernel on the env's stream: 32 envs per workgroup of four or eight waves, the three GEMMs on the
 // f32-in / f32-accumulate matrix instruction v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered fmaf chain,
 // cdna_hip_programming.md "FP32-input MFMA"), activations staged through LDS, then softmax and an
 // inverse-CDF draw from a caller-supplied uniform number per env.
 //
 //   X  [32][in]  = (float) obs                       LDS, K padded to even with zeros
-//   H1 [32][h1]  = tanh(X  W1 + b1)   h1/32 tiles, spread over the 4 waves        LDS
-//   H2 [32][h2]  = tanh(H1 W2 + b2)   h2/32 tiles                                 LDS
+//   H1 [32][h1]  = tanh(X  W1 + b1)   h1/32 tiles, spread over the waves          LDS
+//   H2 [32][h2]  = tanh(H1 W2 + b2)   h2/32 tiles (K halved over two waves each)  LDS
 //   O  [32][32]  = H2 W3 + b3         columns 0..A-1 logits, column A the value   LDS (K split over the waves)
 //
 // Operand maps of the 32x32x2 instruction: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31];
@@ -48,11 +48,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {          // splitmix64 f
 
 __device__ __forceinline__ int acc_row(int g, int lane) { return (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5); }
 
-// One 32x32 output tile: C = A(32 x K, LDS, row stride lda) * B(K x ldb, global, columns col0..col0+31).
-// Columns >= n_cols and rows k >= k_real of B read as zero.  K must be even.
-// The K range [k_begin, k_end) is walked 32 MFMA steps (64 k) at a time with all 32 weight loads of a
-// block issued before its first MFMA: the kernel is bound by the latency of these L2 reads, not by
-// the matrix pipe.
+// One 32x32 output tile: C = A(32 x K, LDS, row stride lda) * B(K x ldb, global, columns col0..col0+31) over
+// the K range [k_begin, k_end) (even bounds).  Columns >= n_cols and rows k >= k_real of B read as zero.
+// The range is walked BLK MFMA steps (2 BLK values of k) at a time: all weight loads and all LDS operand
+// reads of a block are issued before its first MFMA -- the kernel is bound by the latency of these reads,
+// not by the matrix pipe -- and the MFMAs themselves are unconditional: out-of-range steps get zero
+// operands instead of a branch (a per-lane condition around an MFMA costs an EXEC save / restore and a
+// pipeline drain per instruction).
+template <int BLK>
 __device__ __forceinline__ f32x16 tile_gemm(const float *A, int lda, const float *B, int ldb, int col0, int n_cols,
                                             int k_begin, int k_end, int k_real, int lane) {
     f32x16 acc;
@@ -60,18 +63,20 @@ __device__ __forceinline__ f32x16 tile_gemm(const float *A, int lda, const float
     for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
     const int r = lane & 31, h = lane >> 5, col = col0 + r;
     const bool col_ok = col < n_cols;
-    for (int k0 = k_begin + h; k0 < k_end; k0 += 64) {
-        float b[32];
+    for (int kb = k_begin; kb < k_end; kb += 2 * BLK) {      // wave-uniform trip count
+        float bv[BLK], av[BLK];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int k = k0 + 2 * j;
-            b[j] = (col_ok && k < k_end && k < k_real) ? B[(size_t)k * ldb + col] : 0.0f;
+        for (int j = 0; j < BLK; ++j) {
+            const int k = kb + h + 2 * j;
+            bv[j] = (col_ok && k < k_end && k < k_real) ? B[(size_t)k * ldb + col] : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int k = k0 + 2 * j;
-            if (k < k_end) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * lda + k], b[j], acc, 0, 0, 0);
+        for (int j = 0; j < BLK; ++j) {
+            const int k = kb + h + 2 * j;
+            av[j] = k < k_end ? A[r * lda + k] : 0.0f;
         }
+#pragma unroll
+        for (int j = 0; j < BLK; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
     }
     return acc;
 }
@@ -83,44 +88,68 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
 
-__global__ __launch_bounds__(256) void policy_act_kernel(PolicyArgs a) {
+__global__ __launch_bounds__(512) void policy_act_kernel(PolicyArgs a) {
     extern __shared__ float lds[];
     const PrlPolicyWeights &W = a.w;
     const int in_pad = (W.in_dim + 1) & ~1, xs = in_pad + 1, s1 = W.h1 + 1, s2 = W.h2 + 1, n_out = W.n_actions + 1;
     float *X = lds, *H1 = X + 32 * xs, *H2 = H1 + 32 * s1, *O = lds + a.o_off;      // O: 4 x [32][33] partial head tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, nw = blockDim.x >> 6;
     const int env0 = blockIdx.x * 32;
 
-    for (int i = tid; i < 32 * in_pad; i += 256) {
+    for (int i = tid; i < 32 * in_pad; i += blockDim.x) {
         const int row = i / in_pad, k = i - row * in_pad, env = env0 + row;
         X[row * xs + k] = (env < a.n && k < W.in_dim) ? (float)a.obs[(size_t)env * W.in_dim + k] : 0.0f;
     }
     __syncthreads();
-    for (int t = wave; t < W.h1 / 32; t += 4) {
-        const f32x16 acc = tile_gemm(X, xs, W.w1, W.h1, t * 32, W.h1, 0, in_pad, W.in_dim, lane);
+    for (int t = wave; t < W.h1 / 32; t += nw) {
+        const f32x16 acc = tile_gemm<4>(X, xs, W.w1, W.h1, t * 32, W.h1, 0, in_pad, W.in_dim, lane);
         const float bias = W.b1[t * 32 + r];
 #pragma unroll
         for (int g = 0; g < 16; ++g) H1[acc_row(g, lane) * s1 + t * 32 + r] = fast_tanh(acc[g] + bias);
     }
     __syncthreads();
-    for (int t = wave; t < W.h2 / 32; t += 4) {
-        const f32x16 acc = tile_gemm(H1, s1, W.w2, W.h2, t * 32, W.h2, 0, W.h1, W.h1, lane);
-        const float bias = W.b2[t * 32 + r];
+    const int t2 = W.h2 / 32;
+    if (nw == 2 * t2 && W.h1 % 4 == 0) {
+        // eight waves, four tiles: waves t and t + t2 each take half of K for tile t.  The upper half parks its
+        // partial sums in the H2 slot itself; after a barrier the lower half adds them, applies bias and tanh and
+        // overwrites the slot (every element is read and written by the same lane).
+        const int t = wave % t2, part = wave / t2, kh = W.h1 / 2;
+        const f32x16 acc = tile_gemm<32>(H1, s1, W.w2, W.h2, t * 32, W.h2, part * kh, (part + 1) * kh, W.h1, lane);
+        if (part == 1) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) H2[acc_row(g, lane) * s2 + t * 32 + r] = fast_tanh(acc[g] + bias);
+            for (int g = 0; g < 16; ++g) H2[acc_row(g, lane) * s2 + t * 32 + r] = acc[g];
+        }
+        __syncthreads();
+        if (part == 0) {
+            const float bias = W.b2[t * 32 + r];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                float *h = H2 + acc_row(g, lane) * s2 + t * 32 + r;
+                *h = fast_tanh((acc[g] + *h) + bias);
+            }
+        }
+    } else {
+        for (int t = wave; t < t2; t += nw) {
+            const f32x16 acc = tile_gemm<32>(H1, s1, W.w2, W.h2, t * 32, W.h2, 0, W.h1, W.h1, lane);
+            const float bias = W.b2[t * 32 + r];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) H2[acc_row(g, lane) * s2 + t * 32 + r] = fast_tanh(acc[g] + bias);
+        }
     }
     __syncthreads();
     {   // the narrow head layer: each wave takes a quarter of K, the four partial tiles are summed below
         const int kq = ((W.h2 / 4) + 1) & ~1;                         // even slice length
         const int kb = wave * kq, ke = kb + kq < W.h2 ? kb + kq : W.h2;
-        f32x16 acc;
-        if (kb < ke) acc = tile_gemm(H2, s2, W.w3, n_out, 0, n_out, kb, ke, W.h2, lane);
-        else
+        if (wave < 4) {                             // four partial tiles, whatever the workgroup size
+            f32x16 acc;
+            if (kb < ke) acc = tile_gemm<16>(H2, s2, W.w3, n_out, 0, n_out, kb, ke, W.h2, lane);
+            else
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
-        float *Ow = O + wave * (32 * 33);
+                for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+            float *Ow = O + wave * (32 * 33);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) Ow[acc_row(g, lane) * 33 + r] = acc[g];
+            for (int g = 0; g < 16; ++g) Ow[acc_row(g, lane) * 33 + r] = acc[g];
+        }
     }
     __syncthreads();
     if (tid < 32 && env0 + tid < a.n) {             // one env per thread: softmax, inverse-CDF draw
@@ -184,7 +213,9 @@ extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *ob
     a.o_off = front >= head ? 0 : (int)(front + h2_floats);
     const size_t lds = sizeof(float) * (front + h2_floats + (front >= head ? 0 : head));
     if (lds > 64 * 1024) return prl_set_error_(PRL_E_UNSUPPORTED, "prl_policy_act: layer sizes need more than 64 KB of LDS per 32 envs");
-    hipLaunchKernelGGL(policy_act_kernel, dim3((n + 31) / 32), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    // eight waves when that gives layer 1 one tile per wave and layer 2 two waves per tile (the paint_ppo shape)
+    const int threads = (w->h2 / 32) * 2 * 64 == 512 ? 512 : 256;
+    hipLaunchKernelGGL(policy_act_kernel, dim3((n + 31) / 32), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return prl_set_error_(PRL_E_HIP, hipGetErrorString(e));
     return PRL_OK;
