@@ -199,8 +199,8 @@ int prl_batch_timing_read(PrlBatch *batch, double *total_ms, int64_t *launches);
  * output, a fast tanh, expf/logf); the action is the inverse-CDF draw for uniform[env] in [0, 1), or,
  * with uniform == NULL, for a counter-based random number keyed by (rng_seed, env, rng_count[env]++):
  * rng_count is a zero-initialised u32[N] device array the caller keeps alive (race-free, and safe to
- * replay from a captured HIP graph).  Limits: hidden sizes multiples of 32, n_actions <= 31, 64 KB of
- * LDS per 32 envs. */
+ * replay from a captured HIP graph).  Limits: hidden sizes multiples of 16, n_actions <= 15, 64 KB of
+ * LDS per 16 envs. */
 typedef struct {
     int32_t in_dim, h1, h2, n_actions;
     const float *w1, *b1;        /* [in_dim][h1], [h1] */

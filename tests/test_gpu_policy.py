@@ -2,7 +2,7 @@
 
 This is a floating-point kernel, so the reference is the same network in torch (float32 on the device,
 and float64 as ground truth).  Tolerance: 2e-5 absolute on logits / values / log-probabilities -- the
-kernel's dot products are k-ordered f32 fma chains (v_mfma_f32_32x32x2_f32), torch's use another
+kernel's dot products are k-ordered f32 fma chains (v_mfma_f32_16x16x4_f32), torch's use another
 order, and tanhf / expf differ in the last ulp."""
 import ctypes as C
 
@@ -25,7 +25,8 @@ def _policy(in_dim=6, n_actions=4, hiddens=(256, 128), seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize('n,in_dim,n_actions,hiddens,scale', [(1000, 6, 4, (256, 128), 1.0), (4096, 6, 4, (256, 128), 4.0),
-                                                              (33, 16, 8, (64, 32), 2.0), (5, 5, 3, (32, 32), 1.0)])
+                                                              (33, 16, 8, (64, 32), 2.0), (5, 5, 3, (32, 32), 1.0),
+                                                              (100, 7, 15, (48, 16), 1.5)])
 def test_fused_policy_matches_torch(n, in_dim, n_actions, hiddens, scale):
     import torch
     from paintrl_amd.policy import FusedPolicy
@@ -81,11 +82,11 @@ def test_fused_policy_follows_weight_updates_and_rejects_bad_shapes():
     lib = _lib.load()
     w = _lib.PrlPolicyWeights()
     C.memmove(C.byref(w), C.byref(fused._w), C.sizeof(w))
-    w.h1 = 100                                          # not a multiple of 32
+    w.h1 = 100                                          # not a multiple of 16
     out = torch.empty(64, dtype=torch.int32, device='cuda')
     rc = lib.prl_policy_act(C.byref(w), 64, C.c_void_p(obs.data_ptr()), C.c_void_p(u.data_ptr()), None, 0,
                             C.c_void_p(out.data_ptr()), None, None, None, None)
-    assert rc == -3 and b'multiples of 32' in lib.prl_last_error()
+    assert rc == -3 and b'multiples of 16' in lib.prl_last_error()
     assert lib.prl_policy_act(None, 64, None, None, None, 0, None, None, None, None, None) == -1
     rc = lib.prl_policy_act(C.byref(fused._w), 64, C.c_void_p(obs.data_ptr()), None, None, 0,
                             C.c_void_p(out.data_ptr()), None, None, None, None)
