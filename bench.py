@@ -178,6 +178,10 @@ def main():
         else:
             policy = torch_policy
 
+    def obs_for_policy():
+        # the torch module wants float32; the fused kernel reads the env's float64 observations itself
+        return env.obs.to(torch.float32) if args.policy == 'mlp-torch' else None
+
     graph = None
     if policy is not None and args.graph:
         # policy forward + sampling + env step captured once; the launch-bound inner loop becomes a replay
@@ -185,12 +189,12 @@ def main():
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(3):                      # warm the allocator and the kernels on the side stream
-                act, _, _ = policy.act(env.obs.to(torch.float32))
+                act, _, _ = policy.act(obs_for_policy())
                 env.step_raw(act)
         torch.cuda.current_stream(device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            act, _, _ = policy.act(env.obs.to(torch.float32))
+            act, _, _ = policy.act(obs_for_policy())
             env.step_raw(act)
 
     def run(k0, k1):
@@ -205,7 +209,7 @@ def main():
             elif policy is None:
                 env.step_raw(actions[k])
             else:
-                act, _, _ = policy.act(env.obs.to(torch.float32), gen)
+                act, _, _ = policy.act(obs_for_policy(), gen)
                 env.step_raw(act)
             if world > 1 and (k + 1) % FRAGMENT == 0:
                 if len(subs) > 1:
