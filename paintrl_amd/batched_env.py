@@ -124,6 +124,15 @@ class BatchedPaintEnv(object):
                                            self._ptr(self.reward), self._ptr(self.done_u8), self._ptr(self.info),
                                            self._ptr(self.final_obs), None, self._stream()), 'prl_batch_step')
 
+    def step_into(self, actions_i32, obs, reward, done_u8, info, final_obs):
+        """Like ``step_raw`` but the kernel writes into caller-owned tensors (float64 (N, obs_dim), float64 (N,),
+        uint8 (N,), float64 (N, 2), float64 (N, obs_dim)): a rollout worker passes rows of its trajectory
+        buffers, so that a step costs two launches and no copies."""
+        _lib.check(self.lib.prl_batch_step(self._batch, C.c_void_p(actions_i32.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                           C.c_void_p(reward.data_ptr()), C.c_void_p(done_u8.data_ptr()),
+                                           C.c_void_p(info.data_ptr()), C.c_void_p(final_obs.data_ptr()), None,
+                                           self._stream()), 'prl_batch_step')
+
     # RLlib VectorEnv-style names
     def vector_reset(self):
         return self.reset()

@@ -79,3 +79,18 @@ class FusedPolicy(object):
                                                C.c_void_p(logits.data_ptr()) if want_logits else None, stream),
                        'prl_policy_act')
         return (action, logp, value, logits) if want_logits else (action, logp, value)
+
+    def act_into(self, obs, action, logp, value):
+        """``act`` with the kernel's own sampling stream, writing into caller-owned tensors (int32 (N,), float32
+        (N,), float32 (N,)) -- rows of a trajectory buffer.  No checks, no allocations: the rollout hot loop."""
+        torch = _torch()
+        n = obs.shape[0]
+        if self._rng_count is None or self._rng_count.shape[0] != n:
+            self._rng_count = torch.zeros(n, dtype=torch.int32, device=obs.device)
+        rc = self.lib.prl_policy_act(C.byref(self._w), n, C.c_void_p(obs.data_ptr()), None,
+                                     C.c_void_p(self._rng_count.data_ptr()), C.c_uint64(self.seed),
+                                     C.c_void_p(action.data_ptr()), C.c_void_p(logp.data_ptr()),
+                                     C.c_void_p(value.data_ptr()), None,
+                                     C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc:
+            _lib.check(rc, 'prl_policy_act')

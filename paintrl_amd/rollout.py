@@ -42,7 +42,13 @@ class MLPPolicy(nn.Module):
 
 class RolloutWorker(object):
     """Collects fragments of ``fragment`` steps from a BatchedPaintEnv (auto_reset=True) into
-    preallocated [T, N, ...] device tensors with RLlib SampleBatch field names."""
+    preallocated [T, N, ...] device tensors with RLlib SampleBatch field names.
+
+    With the fused policy (default) a step is two launches and nothing else: ``prl_policy_act`` reads the
+    observations of step t from the buffer row the env wrote them to and writes actions / log-probabilities /
+    value estimates into their buffer rows; ``prl_batch_step`` reads those actions and writes the next
+    observations, rewards, done flags, info and terminal observations into theirs.  The float32 views RLlib
+    expects are made once per fragment."""
 
     def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True):
         if not env.cfg.auto_reset:
@@ -54,52 +60,64 @@ class RolloutWorker(object):
         if fused:
             from .policy import FusedPolicy
             self.fused = FusedPolicy(policy, seed=seed)
-        dev, n, od = env.device, env.n_envs, env.obs_dim
-        f32 = dict(dtype=torch.float32, device=dev)
-        self.buf = {
-            'obs': torch.zeros((self.T, n, od), **f32), 'new_obs': torch.zeros((self.T, n, od), **f32),
-            'actions': torch.zeros((self.T, n), dtype=torch.int32, device=dev),
-            'rewards': torch.zeros((self.T, n), **f32), 'dones': torch.zeros((self.T, n), dtype=torch.bool, device=dev),
-            'action_logp': torch.zeros((self.T, n), **f32), 'vf_preds': torch.zeros((self.T, n), **f32),
-            'infos_reward': torch.zeros((self.T, n), **f32), 'infos_penalty': torch.zeros((self.T, n), **f32),
+        dev, n, od, T = env.device, env.n_envs, env.obs_dim, self.T
+        f32, f64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.float64, device=dev)
+        # what the kernels write (float64 like the reference's observations and rewards) ...
+        self.raw = {
+            'obs': torch.zeros((T + 1, n, od), **f64),         # row t: observation before step t; row T: after the last
+            'final_obs': torch.zeros((T, n, od), **f64), 'rewards': torch.zeros((T, n), **f64),
+            'dones': torch.zeros((T, n), dtype=torch.uint8, device=dev), 'infos': torch.zeros((T, n, 2), **f64),
         }
+        # ... and the SampleBatch the learner reads
+        self.buf = {
+            'obs': torch.zeros((T, n, od), **f32), 'new_obs': torch.zeros((T, n, od), **f32),
+            'actions': torch.zeros((T, n), dtype=torch.int32, device=dev),
+            'rewards': torch.zeros((T, n), **f32), 'dones': torch.zeros((T, n), dtype=torch.bool, device=dev),
+            'action_logp': torch.zeros((T, n), **f32), 'vf_preds': torch.zeros((T, n), **f32),
+            'infos_reward': torch.zeros((T, n), **f32), 'infos_penalty': torch.zeros((T, n), **f32),
+        }
+        self._last_value = torch.zeros(n, **f32)
+        self._scratch_action = torch.zeros(n, dtype=torch.int32, device=dev)
+        self._scratch_logp = torch.zeros(n, **f32)
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
-        self.obs64 = env.reset()
-        self.obs = self.obs64.to(torch.float32)
+        self.raw['obs'][0].copy_(env.reset())
         self.steps_done = 0
 
     def sync_policy(self):
         if self.fused is not None:
             self.fused.sync()
 
-    def _act(self):
-        if self.fused is not None:
-            return self.fused.act(self.obs64)              # in-kernel sampling stream keyed by the worker's seed
-        return self.policy.act(self.obs, self.gen)
-
     @torch.no_grad()
     def collect(self):
         """One fragment.  Returns (batch dict, last value estimates, gathered episode returns)."""
-        b, env = self.buf, self.env
-        for t in range(self.T):
-            actions, logp, value = self._act()
-            obs64, reward, done, info = env.step(actions)
-            b['obs'][t] = self.obs
-            b['actions'][t] = actions
-            b['action_logp'][t] = logp
-            b['vf_preds'][t] = value
-            b['rewards'][t] = reward
-            b['dones'][t] = done
-            b['infos_reward'][t] = info[:, 0]
-            b['infos_penalty'][t] = info[:, 1]
-            b['new_obs'][t] = torch.where(done.unsqueeze(-1), env.final_obs, obs64).to(torch.float32)
-            self.obs64 = obs64
-            self.obs = obs64.to(torch.float32)
-        self.steps_done += self.T
-        _, _, last_value = self._act()
+        b, raw, env, T = self.buf, self.raw, self.env, self.T
+        if self.fused is not None:
+            for t in range(T):
+                self.fused.act_into(raw['obs'][t], b['actions'][t], b['action_logp'][t], b['vf_preds'][t])
+                env.step_into(b['actions'][t], raw['obs'][t + 1], raw['rewards'][t], raw['dones'][t], raw['infos'][t],
+                              raw['final_obs'][t])
+            self.fused.act_into(raw['obs'][T], self._scratch_action, self._scratch_logp, self._last_value)
+            # the extra draw advanced the sampling stream by one; harmless (it is never replayed)
+        else:
+            for t in range(T):
+                actions, logp, value = self.policy.act(raw['obs'][t].to(torch.float32), self.gen)
+                b['actions'][t], b['action_logp'][t], b['vf_preds'][t] = actions, logp, value
+                env.step_into(b['actions'][t], raw['obs'][t + 1], raw['rewards'][t], raw['dones'][t], raw['infos'][t],
+                              raw['final_obs'][t])
+            _, _, last = self.policy.act(raw['obs'][T].to(torch.float32), self.gen)
+            self._last_value.copy_(last)
+        # float32 SampleBatch views, once per fragment
+        b['obs'].copy_(raw['obs'][:T])
+        b['dones'].copy_(raw['dones'].bool())
+        b['new_obs'].copy_(torch.where(b['dones'].unsqueeze(-1), raw['final_obs'], raw['obs'][1:]))
+        b['rewards'].copy_(raw['rewards'])
+        b['infos_reward'].copy_(raw['infos'][..., 0])
+        b['infos_penalty'].copy_(raw['infos'][..., 1])
+        raw['obs'][0].copy_(raw['obs'][T])                          # the next fragment starts where this one ended
+        self.steps_done += T
         returns = pdist.gather_returns(env.episode_returns())       # once per fragment, RCCL when world > 1
-        return b, last_value, returns
+        return b, self._last_value.clone(), returns
 
 
 def gae(batch, last_value, gamma=0.99, lam=0.95):
