@@ -39,3 +39,49 @@ def test_rollout_fragment_and_ppo_step():
     loss = ppo_update(policy, opt, batch, last_value, epochs=1, minibatches=2)
     assert np.isfinite(loss) and any(not torch.equal(a, b) for a, b in zip(before, policy.parameters()))
     env.close()
+
+
+def test_rollout_buffers_replay_through_the_oracle():
+    """The kernels write straight into rows of the worker's trajectory buffers; replaying the recorded actions
+    through the CPU oracle must give the recorded observations, rewards, done flags and info, row by row, until
+    an env's first episode end (after it the env restarts from a start point drawn by the library's RNG)."""
+    import torch
+    import oracle
+    from conftest import synthetic_tables
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    tables = synthetic_tables('door_test')
+    n, T = 96, 25
+    env = BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=11)
+    torch.manual_seed(3)
+    policy = MLPPolicy(env.obs_dim, 4).to(env.device)
+    worker = RolloutWorker(env, policy, fragment=T, seed=5)
+    start_obs = worker.raw['obs'][0].cpu().numpy().copy()
+    batch, _, _ = worker.collect()
+    torch.cuda.synchronize()
+    b = {k: v.cpu().numpy() for k, v in batch.items()}
+    raw = {k: v.cpu().numpy() for k, v in worker.raw.items()}
+    raw['obs'] = np.concatenate([start_obs[None], raw['obs'][1:]])     # row 0 already holds the next fragment's start
+    # which start point did the library draw for each env?  (reset observations identify it)
+    orc = oracle.Oracle(tables, n)
+    n_start = orc.n_start
+    cand = [orc.reset(np.full(n, s, dtype=np.int32))[0] for s in range(n_start)]
+    start = np.array([next(s for s in range(n_start) if np.array_equal(cand[s], start_obs[e])) for e in range(n)])
+    assert np.array_equal(orc.reset(start), start_obs)
+    alive = np.ones(n, dtype=bool)
+    checked = 0
+    for t in range(T):
+        assert np.array_equal(b['obs'][t][alive], raw['obs'][t][alive].astype(np.float32))
+        o, r, d, info = orc.step(b['actions'][t])
+        assert np.array_equal(raw['rewards'][t][alive], r[alive]) and np.array_equal(raw['infos'][t][alive], info[alive])
+        assert np.array_equal(raw['dones'][t][alive].astype(bool), d[alive])
+        cont = alive & ~d
+        assert np.array_equal(raw['obs'][t + 1][cont], o[cont])               # next observation of running envs
+        assert np.array_equal(raw['final_obs'][t][alive & d], o[alive & d])     # terminal observation of finished ones
+        assert np.array_equal(b['new_obs'][t][alive], o[alive].astype(np.float32))
+        assert np.allclose(b['rewards'][t][alive], r[alive], atol=1e-6)
+        checked += int(alive.sum())
+        alive = cont
+    assert checked > n * 8
+    env.close()
