@@ -234,10 +234,12 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             // the reference returns early and leaves the last-shot set untouched.
             uint64_t cur[KW_MAX] = {0, 0, 0, 0};
             int beam_hits = 0;
+            // consecutive beams of the cone hit neighbouring facets: a beam starts from the facet the previous
+            // one hit (the first from the tool ray's facet); a wrong hint only costs the general search
+            int beam_hint = facet_hint;
             for (int bm = 0; bm < P.n_beams; ++bm) {
                 double dst[3], bt, bh[3];
                 transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
-                int beam_hint = -1;
                 if (ray_closest_wave(P, pos, dst, lane, bt, bh, beam_hint) < 0) continue;
                 ++beam_hits;
                 const int sidx = nearest_sample_wave(P, bh, lane);
