@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Benchmark of the batched paint-coverage step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
@@ -11,9 +10,13 @@ from a device generator seeded 1234, auto-reset inside the step kernel with the
 library's counter-based start-point RNG (seed 5678).  One "step" = one batched
 PaintGymEnv.step() of all 4096 envs of a GPU = one launch of step_kernel.
 
-For N > 1 the driver starts one process per GPU with torch.distributed.run; envs
-are sharded (weak scaling, 4096 per GPU, no data-path collective) and every 100
-steps the ranks all_gather their episode returns over RCCL.
+N > 1: one process per GPU.  Under `python -m torch.distributed.run` the ranks come
+from the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); started plainly
+as `python bench.py --gpus N` the parent -- which never touches the GPU -- starts
+the N ranks itself as child processes and exits with their status (the analogue of
+the reference's ray.init + num_workers, paint_ppo.py:153,171).  Envs are sharded
+(weak scaling, 4096 per GPU, no data-path collective) and every 100 steps the ranks
+all_gather their episode returns over RCCL on a side stream.
 
 Prints ONE JSON line on rank 0 (see README / the task contract), including
 "roofline" for step_kernel and "cpu_baseline" (the C oracle on the host cores).
@@ -21,6 +24,8 @@ Prints ONE JSON line on rank 0 (see README / the task contract), including
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,12 +34,25 @@ sys.path.insert(0, REPO)
 
 ENVS_PER_GPU = 4096
 FRAGMENT = 100                  # rollout fragment length (paint_ppo.py:190 sample_batch_size)
-TIMING_EVERY = 8                # HIP events around every 8th step launch (kernel time for the roofline)
+TIME_ALL_BELOW = 256            # runs of at most this many steps time EVERY launch with HIP events ...
+TIMING_EVERY = 8                # ... longer ones every 8th (the events cost ~1 us of stream time each)
+PREWARM_SECONDS = 0.4           # untimed stepping of a scratch batch first: the timed region then runs at
+                                # the clocks a long job holds, also at the driver's --warmup 5 --steps 20
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+CLOCK_GHZ = 2.4                 # MI355X_MICROARCH.md: max shader clock
+N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 
 
 def algorithmic_bytes(dt, n_envs, obs_dim):
-    """Minimal HBM bytes of one step launch (DESIGN.md "Roofline accounting")."""
+    """(survey_per_env, survey_per_launch, layout_per_env, layout_static, layout_per_launch).
+
+    `survey_*` is SURVEY.md §8(d)'s figure (what `roofline.achieved` uses): the reference's state as 1 bit per
+    sample in 32-bit words of the UNPADDED sample count, 52 bytes of scalars, f32 outputs, 0.4 MB of tables.
+    `layout_*` is what this implementation's own layout must move at minimum: word-aligned 64-bit mask rows, the
+    128-byte record, f64 outputs, and every static table once."""
+    mask32 = ((dt.n_samples + 31) // 32) * 4
+    survey_env = 4 * mask32 + 2 * 52 + 4 + obs_dim * 4 + 4 + 1 + 8
+    survey_launch = survey_env * n_envs + 400000
     words = dt.n_words
     per_env = (2 * 2 * words * 8          # painted + last-shot masks, read and write
                + 2 * 16 * 8               # 128-byte scalar state record, read and write
@@ -47,7 +65,7 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
               + dt.start_pos.nbytes + dt.start_quat.nbytes
               + dt.n_samples_pad                                                # equal-run ends (u8), derived on upload
               + (dt.n_collision_pad * 96 if dt.col_convex else 0))              # hull facet records, derived on upload
-    return per_env, static, per_env * n_envs + static
+    return survey_env, survey_launch, per_env, static, per_env * n_envs + static
 
 
 def usable_cores():
@@ -62,26 +80,107 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(tables, steps_sample=60, n_envs=ENVS_PER_GPU):
-    """The C oracle (a scalar float64 port of the reference step()) on all host cores."""
+def _oracle_rate(tables, n_envs, steps_sample, threads, obs_mode='section', overlap=False):
     import numpy as np
     import oracle
-    cores = usable_cores()
-    orc = oracle.Oracle(tables, n_envs, threads=cores)
+    orc = oracle.Oracle(tables, n_envs, threads=threads, obs_mode=obs_mode, overlap_penalty=overlap)
     rng = np.random.RandomState(1234)
-    start = rng.randint(0, 4, size=n_envs)
-    orc.reset(start)
+    orc.reset(rng.randint(0, 4, size=n_envs))
     acts = rng.randint(0, 4, size=(steps_sample, n_envs))
     t0 = time.perf_counter()
     for k in range(steps_sample):
         _, _, done, _ = orc.step(acts[k])
         if done.any():
             orc.reset(rng.randint(0, 4, size=n_envs), mask=done)
-    dt = time.perf_counter() - t0
-    return {'value': steps_sample / dt, 'unit': 'batched steps/s (4096 envs each)', 'cores': cores,
-            'kind': 'port', 'env_steps_per_s': steps_sample * n_envs / dt,
-            'sample': '%d batched steps of %d envs (same door, same action distribution, reset on done), '
-                      'oracle/paint_oracle.c with OpenMP over envs, %.1f s wall' % (steps_sample, n_envs, dt)}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(tables, steps_sample=300, n_envs=ENVS_PER_GPU, obs_mode='section', overlap=False):
+    """The C oracle (a scalar float64 port of the reference step()) on the host cores: all of them (the headline
+    value) and one (SURVEY §8d asks for both); the reference's own Python step() cannot travel to this box, its
+    figure is the one recorded next to the golden fixtures when they were generated from the imported reference."""
+    cores = usable_cores()
+    dt_all = _oracle_rate(tables, n_envs, steps_sample, cores, obs_mode, overlap)
+    one_steps = max(2, steps_sample // 12)
+    dt_one = _oracle_rate(tables, n_envs, one_steps, 1, obs_mode, overlap)
+    out = {'value': steps_sample / dt_all, 'unit': 'batched steps/s (%d envs each)' % n_envs, 'cores': cores,
+           'kind': 'port', 'env_steps_per_s': steps_sample * n_envs / dt_all,
+           'sample': '%d batched steps of %d envs (same door, same action distribution, reset on done), '
+                     'oracle/paint_oracle.c with OpenMP over envs, %.1f s wall' % (steps_sample, n_envs, dt_all),
+           'single_thread': {'value': one_steps / dt_one, 'env_steps_per_s': one_steps * n_envs / dt_one, 'cores': 1,
+                             'sample': '%d batched steps of %d envs, one thread, %.1f s wall' % (one_steps, n_envs, dt_one)}}
+    try:
+        with open(os.path.join(REPO, 'tests', 'golden', 'MANIFEST.json')) as f:
+            tm = json.load(f)['timings']
+        ms = tm['door_grid_ms_per_step' if obs_mode == 'grid' else 'door_section_ms_per_step']
+        out['reference_python'] = {
+            'ms_per_env_step': ms, 'env_steps_per_s_per_core': 1e3 / ms,
+            'provenance': 'the reference PaintGymEnv.step() itself (CPython, one core of the build container, '
+                          'synthetic door, ray time of the stand-in pybullet included), timed by '
+                          'tests/golden/make_golden.py while it recorded the golden episodes; tests/golden/MANIFEST.json'}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
+
+
+def valu_issue_bound(kernel_us, obs_mode):
+    """Second roofline: the step kernel against its own vector-issue bound, from the committed SQ counters.
+
+    A wave64 VALU instruction occupies a SIMD-32 for 2 cycles (f32 / int) or 4 (f64, half rate); with W waves
+    per SIMD the SIMD cannot finish before W x (per-wave issue cycles).  frac = that time / measured kernel time."""
+    path = os.path.join(REPO, 'profiles', 'r02_sq_counters.json')
+    if not os.path.isfile(path) or not kernel_us:
+        return None
+    with open(path) as f:
+        c = json.load(f).get(obs_mode)
+    if not c:
+        return None
+    waves_per_simd = c['waves'] / float(N_SIMD)
+    cycles = waves_per_simd * (2.0 * (c['valu_per_wave'] - c['valu_f64_per_wave']) + 4.0 * c['valu_f64_per_wave'])
+    bound_us = cycles / (CLOCK_GHZ * 1e3)
+    return {'bound': 'valu_issue', 'valu_per_wave': c['valu_per_wave'], 'valu_f64_per_wave': c['valu_f64_per_wave'],
+            'salu_per_wave': c.get('salu_per_wave'), 'waves': c['waves'], 'cycles_per_instr': {'f32_int': 2, 'f64': 4},
+            'clock_ghz': CLOCK_GHZ, 'issue_bound_us': bound_us, 'frac': bound_us / kernel_us,
+            'source': 'profiles/r02_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_INSTS_VALU_*_F64, '
+                      'SQ_INSTS_SALU on the same command)'}
+
+
+# ---------------------------------------------------------------------------- self-launch (N > 1)
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script as child processes and wait for them.  The parent has not imported torch
+    and never touches the GPU; no process is replaced (no exec after a HIP call).  Rank 0 inherits stdout, so
+    the one JSON line comes out of this process's stdout as usual."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+            if rc:                                  # a rank failed: its peers would wait in a collective forever
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
 
 
 def main():
@@ -95,15 +194,23 @@ def main():
     ap.add_argument('--actions', default='random', choices=['random', 'sweep'],
                     help="'sweep': every env follows an on-part serpentine with a random phase (SURVEY 8d item 2), so "
                          'episodes run long instead of ending after ~17 random steps')
-    ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch'],
+    ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch', 'fragment'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4), one fused "
-                         "kernel per step (prl_policy_act); 'mlp-torch': the same net in torch eager")
+                         "kernel per step (prl_policy_act); 'mlp-torch': the same net in torch eager; 'fragment': "
+                         'policy + env step for a whole 100-step rollout fragment in ONE persistent launch '
+                         '(prl_rollout_fragment)')
     ap.add_argument('--streams', type=int, default=1,
                     help='issue a batched step as S launches of envs/S envs on S streams (independent env groups: a '
                          "group's slowest wave then only delays that group); default 1 = one launch per step")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
+    ap.add_argument('--paint-method', default='fast', choices=['fast', 'normal'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prewarm', action='store_true')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above imported torch or touched HIP.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -114,7 +221,7 @@ def main():
 
     rank, local_rank, world = pdist.init_process_group()
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if os.environ.get('PAINTRL_SINGLE_DEVICE'):          # testing aid: all ranks share GPU 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -125,26 +232,26 @@ def main():
     start_mode = 'all' if args.actions == 'sweep' else 'anchor'      # the sweep starts anywhere on the part
     dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, start_mode))
     overlap = args.obs_mode == 'grid'
+    common = dict(device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
+                  paint_method=args.paint_method)
     if args.mixed:
+        if args.streams > 1:
+            raise SystemExit('--streams is not combined with --mixed')
         sheet = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('square'), tex_size=(240, 240),
                                               name='square')
         dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, 'all'))
         dts = DeviceTables(sheet, obs_grad=4, start_points=part_tables.start_points(sheet, 'all'))
-        env = BatchedPaintEnv([dt, dts], args.envs, env_part_id=np.arange(args.envs) % 2, device=device,
-                              obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
-                              seed=pdist.rank_seed(5678, rank), max_possible_point=[9148, 14350])
+        env = BatchedPaintEnv([dt, dts], args.envs, env_part_id=np.arange(args.envs) % 2,
+                              seed=pdist.rank_seed(5678, rank), max_possible_point=[9148, 14350], **common)
+        subs = [env]
     else:
         if args.streams > 1 and (args.policy != 'random' or args.envs % args.streams):
             raise SystemExit('--streams needs --policy random and a divisible --envs')
         n_sub = args.envs // args.streams
-        subs = [BatchedPaintEnv(dt, n_sub, device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True,
-                                overlap_penalty=overlap, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=9148)
-                for g in range(args.streams)]
+        subs = [BatchedPaintEnv(dt, n_sub, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=9148,
+                                **common) for g in range(args.streams)]
         env = subs[0]
-    if args.mixed:
-        if args.streams > 1:
-            raise SystemExit('--streams is not combined with --mixed')
-        subs = [env]
+    main_stream = torch.cuda.current_stream(device)
     sub_streams = [torch.cuda.Stream(device=device) for _ in subs] if len(subs) > 1 else [None]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
@@ -155,15 +262,40 @@ def main():
         phase = torch.randint(0, pattern.numel(), (args.envs,), generator=gen, device=device)
         steps_idx = torch.arange(total, device=device).unsqueeze(1)
         actions = pattern[(steps_idx + phase.unsqueeze(0)) % pattern.numel()].contiguous()
+
+    prewarm_steps = 0
+    if not args.no_prewarm and PREWARM_SECONDS > 0:
+        # a scratch batch of the same shape, stepped untimed: brings the clocks up and the code / tables into cache
+        scratch = BatchedPaintEnv(dt, min(args.envs, ENVS_PER_GPU), seed=1, max_possible_point=9148, **common) \
+            if not args.mixed else None
+        if scratch is not None:
+            scratch.reset()
+            a0 = actions[0][:scratch.n_envs].contiguous()
+            t_end = time.perf_counter() + PREWARM_SECONDS
+            while time.perf_counter() < t_end:
+                for _ in range(50):
+                    scratch.step_raw(a0)
+                prewarm_steps += 50
+                torch.cuda.synchronize(device)
+            scratch.close()
+
     for e in subs:
         e.reset()
-    stream_sync = torch.cuda.synchronize
+    stream_sync = lambda: torch.cuda.synchronize(device)        # noqa: E731
     n_sub = args.envs // len(subs)
     sub_actions = [actions] if len(subs) == 1 else [actions[:, g * n_sub:(g + 1) * n_sub].contiguous()
                                                      for g in range(len(subs))]
+    for s in sub_streams:                                  # resets and the action slices ran on the main stream
+        if s is not None:
+            s.wait_stream(main_stream)
 
     policy = None
-    if args.policy != 'random':
+    fragment_runner = None
+    if args.policy == 'fragment':
+        from paintrl_amd.rollout import MLPPolicy, FragmentRunner
+        torch.manual_seed(1234)
+        fragment_runner = FragmentRunner(env, MLPPolicy(env.obs_dim, 4).to(device), fragment=FRAGMENT, seed=1234 + rank)
+    elif args.policy != 'random':
         from paintrl_amd.rollout import MLPPolicy
         torch.manual_seed(1234)
         torch_policy = MLPPolicy(env.obs_dim, 4).to(device)
@@ -197,37 +329,53 @@ def main():
             act, _, _ = policy.act(obs_for_policy())
             env.step_raw(act)
 
+    gatherer = pdist.ReturnsGatherer(device) if world > 1 else None
+
+    def gather_fragment():
+        # the all_gather of the fragment's episode returns runs on a side stream, overlapped with the next steps
+        if len(subs) > 1:
+            for s in sub_streams:
+                main_stream.wait_stream(s)
+        gatherer.submit(torch.cat([e.episode_returns() for e in subs]) if len(subs) > 1 else env.episode_returns())
+
     def run(k0, k1):
-        for k in range(k0, k1):
-            if graph is not None:
-                graph.replay()
-                continue
-            if policy is None and len(subs) > 1:
-                for g, e in enumerate(subs):
-                    with torch.cuda.stream(sub_streams[g]):
-                        e.step_raw(sub_actions[g][k])
-            elif policy is None:
-                env.step_raw(actions[k])
+        k = k0
+        while k < k1:
+            if fragment_runner is not None:
+                n = min(FRAGMENT - (k % FRAGMENT), k1 - k)
+                fragment_runner.run(n)              # n policy + env steps in one persistent launch
+                k += n
             else:
-                act, _, _ = policy.act(obs_for_policy(), gen)
-                env.step_raw(act)
-            if world > 1 and (k + 1) % FRAGMENT == 0:
-                if len(subs) > 1:
-                    stream_sync()
-                pdist.gather_returns(torch.cat([e.episode_returns() for e in subs]))
+                if graph is not None:
+                    graph.replay()
+                elif policy is None and len(subs) > 1:
+                    for g, e in enumerate(subs):
+                        with torch.cuda.stream(sub_streams[g]):
+                            e.step_raw(sub_actions[g][k])
+                elif policy is None:
+                    env.step_raw(actions[k])
+                else:
+                    act, _, _ = policy.act(obs_for_policy(), gen)
+                    env.step_raw(act)
+                k += 1
+            if gatherer is not None and k % FRAGMENT == 0:
+                gather_fragment()
 
     run(0, args.warmup)
     stream_sync()
     pdist.barrier()
     stream_sync()
+    timing_every = 1 if args.steps <= TIME_ALL_BELOW else TIMING_EVERY
     for e in subs:
-        e.timing(TIMING_EVERY)
+        e.timing(timing_every)
     t0 = time.perf_counter()
     run(args.warmup, total)
     stream_sync()
     pdist.barrier()
     stream_sync()
     elapsed = time.perf_counter() - t0
+    if gatherer is not None:
+        gatherer.wait()
     kernel_ms, launches = 0.0, 0
     for e in subs:
         ms_, n_ = e.timing_read()
@@ -237,37 +385,67 @@ def main():
 
     episodes = sum(int(e.state()['episode'].sum()) for e in subs) - args.envs
     if rank == 0:
-        per_env, static, per_launch = algorithmic_bytes(dt, args.envs // len(subs), env.obs_dim)   # per LAUNCH
-        # inside a captured HIP graph (--graph) the per-launch events are not recorded: no kernel time then
+        n_launch_envs = args.envs // len(subs)
+        survey_env, survey_launch, per_env, static, per_launch = algorithmic_bytes(dt, n_launch_envs, env.obs_dim)
+        ms_per_step = 1e3 * elapsed / args.steps
+        # inside a captured HIP graph (--graph) or the fragment kernel the per-launch events are not recorded
         avg_kernel_s = kernel_ms / launches / 1e3 if launches and kernel_ms > 0 else None
-        achieved = per_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
+        if avg_kernel_s is not None and len(subs) == 1 and fragment_runner is None:
+            # the kernel runs inside the step: an event pair that reads longer than the step it brackets is
+            # event overhead (short runs), not kernel time
+            assert avg_kernel_s * 1e3 <= ms_per_step * 1.001 or timing_every > 1, \
+                'kernel %.1f us > step %.1f us' % (avg_kernel_s * 1e6, ms_per_step * 1e3)
+            avg_kernel_s = min(avg_kernel_s, ms_per_step / 1e3)
+        achieved = survey_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-        # the committed PMC measurement is for the default workload only
-        if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' and len(subs) == 1:
+        # the committed PMC measurement is for the default workload (section / grid) only
+        if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' \
+                and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast':
             with open(tpath) as f:
                 traffic = json.load(f).get('bytes_per_launch_%s' % args.obs_mode)
         value = world * args.steps / elapsed
+        if args.policy == 'random':
+            act_desc = 'on-part serpentine' if args.actions == 'sweep' else 'random'
+        else:
+            act_desc = 'policy-MLP (6-256-128-4, fp32, %s)' % {
+                'mlp': 'fused HIP kernel', 'mlp-torch': 'torch eager',
+                'fragment': 'persistent rollout-fragment kernel, %d steps per launch' % FRAGMENT}[args.policy]
+        import torch.distributed as dist
+        dist_world = dist.get_world_size() if dist.is_initialized() else 1
         out = {
             'metric': 'batched env steps/sec (door panel, N=4096)', 'value': value,
             'unit': 'batched steps/s (%d envs each)' % args.envs, 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel, OBS_MODE=%r, %d envs per GPU, '
-                                   '%s discrete-4 actions, in-kernel auto-reset' % (args.obs_mode, args.envs, ('policy-MLP (6-256-128-4, fp32, %s)' % ('fused HIP kernel' if args.policy == 'mlp' else 'torch eager')) if args.policy != 'random' else ('on-part serpentine' if args.actions == 'sweep' else 'random')),
+            'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel%s, OBS_MODE=%r%s, %d envs per GPU, '
+                                   '%s discrete-4 actions, in-kernel auto-reset'
+                                   % (' + sheet (mixed, START_POINT_MODE all)' if args.mixed else '', args.obs_mode,
+                                      ' + OVERLAP_PENALTY' if overlap else '', args.envs, act_desc)
+                                   + (", PAINT_METHOD='normal'" if args.paint_method == 'normal' else ''),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'launches_per_step': len(subs),
-                       'parallelism': 'env-shard x%d' % world + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs)) if len(subs) > 1 else '')},
+                       'prewarm_steps_untimed_scratch_batch': prewarm_steps,
+                       'parallelism': 'env-shard x%d (torch.distributed world size %d, backend %s)'
+                                      % (world, dist_world, dist.get_backend() if dist.is_initialized() else 'none')
+                                      + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs))
+                                         if len(subs) > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
-                         'algorithmic_bytes_per_env_step': per_env, 'static_table_bytes': static,
-                         'bytes_per_launch': per_launch, 'avg_kernel_us': avg_kernel_s * 1e6 if avg_kernel_s else None,
-                         'launches_timed': int(launches)},
+                         'algorithmic_bytes_per_env_step': survey_env, 'bytes_per_launch': survey_launch,
+                         'layout_bytes_per_env_step': per_env, 'layout_static_table_bytes': static,
+                         'layout_bytes_per_launch': per_launch,
+                         'avg_kernel_us': avg_kernel_s * 1e6 if avg_kernel_s else None,
+                         'launches_timed': int(launches), 'timed_every': timing_every,
+                         'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
+                         if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random'
+                             and args.paint_method == 'fast' and len(subs) == 1) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs)
+            out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs, obs_mode=args.obs_mode, overlap=overlap)
         print(json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)))
+        sys.stdout.flush()
     for e in subs:
         e.close()
     if world > 1:

@@ -52,10 +52,34 @@ def lib_path():
 
 
 def build(force=False):
-    src = os.path.join(_HERE, 'paint_oracle.c')
-    if force or not os.path.isfile(lib_path()) or os.path.getmtime(lib_path()) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-C', _HERE, '-B', 'libpaint_oracle.so'], stdout=subprocess.DEVNULL)
-    return lib_path()
+    """Compile paint_oracle.c if the library is missing or older than the source.
+
+    Safe to call from several processes at once (multi-rank tests do): the build runs under an exclusive
+    file lock, writes to a temporary name and is moved into place with os.replace, so no process ever
+    maps a half-written library."""
+    import fcntl
+    src, out = os.path.join(_HERE, 'paint_oracle.c'), lib_path()
+
+    def stale():
+        return not os.path.isfile(out) or os.path.getmtime(out) < os.path.getmtime(src)
+
+    if not force and not stale():
+        return out
+    with open(os.path.join(_HERE, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():                     # another process may have built it while we waited
+                tmp = '%s.tmp.%d' % (out, os.getpid())
+                try:
+                    subprocess.check_call(['make', '-C', _HERE, '-B', 'libpaint_oracle.so',
+                                           'OUT=' + os.path.basename(tmp)], stdout=subprocess.DEVNULL)
+                    os.replace(tmp, out)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return out
 
 
 _lib = None

@@ -8,7 +8,7 @@ of include/paintrl.h.  Rollout driver: rollout (RolloutWorker, PPO step), policy
 from .config import EXTRA_CONFIG, PaintToolProfile, Part_Dict, make_config  # noqa: F401
 from .param_test_env import ParamTestEnv  # noqa: F401
 
-__all__ = ['PaintGymEnv', 'BatchedPaintEnv', 'FusedPolicy', 'ParamTestEnv', 'Part_Dict', 'EXTRA_CONFIG',
+__all__ = ['PaintGymEnv', 'Robot', 'BatchedPaintEnv', 'FusedPolicy', 'ParamTestEnv', 'Part_Dict', 'EXTRA_CONFIG',
            'PaintToolProfile', 'make_config']
 
 
@@ -16,6 +16,9 @@ def __getattr__(name):            # torch-dependent classes are imported lazily
     if name == 'PaintGymEnv':
         from .robot_gym_env import PaintGymEnv
         return PaintGymEnv
+    if name == 'Robot':
+        from .robot_gym_env import Robot
+        return Robot
     if name == 'BatchedPaintEnv':
         from .batched_env import BatchedPaintEnv
         return BatchedPaintEnv

@@ -195,6 +195,11 @@ class BatchedPaintEnv(object):
                 'last_episode_return': r[:, 13].copy(), 'last_episode_reward': r[:, 14].copy(),
                 'last_episode_len': ints[:, 30].copy(), 'last_episode_painted': ints[:, 31].copy()}
 
+    def state_into(self, out):
+        """Copy the raw per-env state records into a caller-owned float64 (N, 16) device tensor (stream-ordered)."""
+        _lib.check(self.lib.prl_batch_get_state(self._batch, C.c_void_p(out.data_ptr()), self._stream()),
+                   'prl_batch_get_state')
+
     def episode_returns(self):
         """float64 tensor (N,): return of each env's last finished episode (the RCCL gather payload)."""
         torch = _torch()

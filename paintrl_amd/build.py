@@ -44,5 +44,28 @@ def build_library(force=False, verbose=False):
     return LIBRARY
 
 
+# Diagnostic variants used by tests/test_gpu_forced_paths.py: the same sources with every fast path
+# replaced by its general counterpart.  The product library never defines these macros.
+VARIANTS = {
+    'force_per_shot_paint': ['-DPRL_FORCE_PER_SHOT_PAINT'],
+    'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY'],
+}
+
+
+def variant_path(name):
+    return os.path.join(_HERE, '_variants', 'libpaintrl_hip_%s.so' % name)
+
+
+def build_variant(name, verbose=False, extra=()):
+    out = variant_path(name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + list(VARIANTS.get(name, [])) + list(extra) + \
+        ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, POLICY_SOURCE, '-o', out]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == '__main__':
     print(build_library(force=True, verbose=True))

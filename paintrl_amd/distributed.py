@@ -63,6 +63,37 @@ def gather_returns(local_returns):
     return out
 
 
+class ReturnsGatherer(object):
+    """The per-fragment all_gather of episode returns, issued on a SIDE stream so that it overlaps the next
+    fragment's step launches; ``wait()`` hands back the last gathered tensor.
+
+    submit(local) orders the side stream after the producer of ``local`` (the caller's current stream), runs the
+    collective there and returns immediately; the main stream never waits for RCCL."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.result = None
+        self.count = 0
+
+    def submit(self, local_returns):
+        self.count += 1
+        if not self.cuda:
+            self.result = gather_returns(local_returns)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            local_returns.record_stream(self.side)
+            self.result = gather_returns(local_returns)
+
+    def wait(self):
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        return self.result
+
+
 def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (used for the timed region of bench.py)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -7,8 +7,10 @@ Same constructor, class attributes, spaces, classmethods, ``step`` 4-tuple and
 throughput use ``BatchedPaintEnv`` directly (thousands of envs per launch).
 
 Differences from the reference, by design:
-  * ``with_robot=True`` (KUKA inverse kinematics through Bullet) is out of scope;
-    the flag is accepted and ignored (training uses with_robot=False, paint_ppo.py:87);
+  * ``with_robot=True`` (KUKA inverse kinematics through Bullet, SURVEY §2 row 2: out of scope)
+    raises NotImplementedError -- pass with_robot=False as paint_ppo.py:87 does;
+  * ``Robot.PAINT_METHOD`` ('fast' | 'normal', rob:171-172) is this module's ``Robot`` class
+    attribute, read when an env is constructed;
   * ``renders`` only controls printing of the replay buffer; there is no GUI;
   * rays hit an explicit collision triangle set (``collision_mode``), see DESIGN.md.
 """
@@ -34,25 +36,34 @@ def load_part_tables(path, collision_mode='hull', obs_grad=4, paint_radius=None)
     return _urdf_cache[key]
 
 
-class _RobotView(object):
-    """The few ``env.robot`` members scripts touch (rge:436, spiral.py:38)."""
+class Robot(object):
+    """Class-level switches of rob:163-172 plus the few ``env.robot`` members scripts touch
+    (rge:436, spiral.py:38).  The kinematics themselves run inside the step kernel."""
+
+    PAINT_PER_ACTION = 5                 # compile-time constant of the kernel
+    NOT_ON_PART_TERMINATE_STEPS = 1000
+    PAINT_METHOD = 'fast'                # 'fast' (ball query, bpw:568-570) | 'normal' (cone beams, rob:280-285)
 
     def __init__(self, env):
         self._env = env
+        self.angle_diff = 0.0            # rob:203
 
     def reset(self, pose):
         """Robot.reset([pose, orn_normal]) (rob:366-372), as spiral.py:38 uses it."""
         self._env._batch.set_pose(0, pose[0], pose[1])
+        self._env._refresh_state()
 
-    def get_angle_diff(self):
-        raise NotImplementedError('angle_diff is consumed inside the step kernel (TURNING_PENALTY)')
+    def get_angle_diff(self):            # rob:374-375: |new turning angle - previous| of the last action
+        return self.angle_diff
 
-    def termination_request(self):
-        return bool(self._env._batch.state()['terminate'][0])
+    def termination_request(self):       # rob:377-378
+        return bool(self._env._state['terminate'])
 
-    def get_observation(self):
-        st = self._env._batch.state()
-        return st['pose'][0], st['quat'][0]
+    def get_observation(self):           # rob:380-381 (the tool pose; orientation as the quaternion it is kept as)
+        return self._env._state['pose'].copy(), self._env._state['quat'].copy()
+
+
+_RobotView = Robot                       # name of round 1
 
 
 class PaintGymEnv(spaces.Env):
@@ -97,6 +108,13 @@ class PaintGymEnv(spaces.Env):
         cfg = dict(_DEFAULT_EXTRA)
         cfg.update(extra_config)
         self._setup_extra_config(cfg)
+        if with_robot:
+            raise NotImplementedError(
+                'with_robot=True needs Bullet inverse kinematics and the KUKA URDF of pybullet_data (rob:193-195, '
+                '220-233): out of scope for the batched simulator.  Construct with with_robot=False, as '
+                'paint_ppo.py:87 does.')
+        if Robot.PAINT_METHOD not in _config.PAINT_METHODS:
+            raise ValueError("Robot.PAINT_METHOD must be 'fast' or 'normal', not %r" % (Robot.PAINT_METHOD,))
         self._with_robot = False
         self._renders = renders
         self._rollout = rollout
@@ -112,11 +130,23 @@ class PaintGymEnv(spaces.Env):
             obs_mode=self.OBS_MODE, obs_grad=self.OBS_GRAD, action_mode=self.ACTION_MODE,
             action_dim=self.ACTION_SHAPE if self.ACTION_MODE == 'continuous' else 1, n_discrete=n_disc,
             termination_mode=self.TERMINATION_MODE, turning_penalty=self.TURNING_PENALTY,
-            overlap_penalty=self.OVERLAP_PENALTY, paint_method='fast', max_episode_len=self.EPISODE_MAX_LENGTH,
+            overlap_penalty=self.OVERLAP_PENALTY, paint_method=Robot.PAINT_METHOD, max_episode_len=self.EPISODE_MAX_LENGTH,
             expected_episode_len=self.Expected_Episode_Length, switch_threshold=self.SWITCH_THRESHOLD,
             max_possible_point=self._max_possible_point, paint_radius=PaintToolProfile.PAINT_RADIUS,
             step_size=PaintToolProfile.STEP_SIZE)
-        self.robot = _RobotView(self)
+        self.robot = Robot(self)
+        # one device buffer for everything a step returns, so that step() costs ONE device-to-host copy:
+        # obs[od] | reward | info[2] | state record[16] | done (u8 in the last 8 bytes)
+        import torch
+        od = self._batch.obs_dim
+        self._pack = torch.zeros(od + 3 + 16 + 1, dtype=torch.float64, device=self._batch.device)
+        self._pack_obs = self._pack[:od].view(1, od)
+        self._pack_reward, self._pack_info = self._pack[od:od + 1], self._pack[od + 1:od + 3].view(1, 2)
+        self._pack_state = self._pack[od + 3:od + 19].view(1, 16)
+        self._pack_done = self._pack[od + 19:od + 20].view(torch.uint8)[:1]
+        self._scratch_final = torch.zeros((1, od), dtype=torch.float64, device=self._batch.device)
+        self._act_i32 = torch.zeros(1, dtype=torch.int32, device=self._batch.device)
+        self._state = None
         self.reset()
 
     def _setup_extra_config(self, config):                                    # rge:240-252
@@ -137,21 +167,38 @@ class PaintGymEnv(spaces.Env):
     def _obs_out(self, row):
         return np.array(row.cpu().numpy(), dtype=np.float64)
 
+    def _decode_state(self, rec):
+        ints = rec.view(np.int32)
+        return {'pose': rec[0:3].copy(), 'quat': rec[3:7].copy(), 'last_turning_angle': float(rec[7]),
+                'total_reward': float(rec[8]), 'total_return': float(rec[9]), 'terminate': int(ints[20]),
+                'terminate_counter': int(ints[21]), 'last_on_part': int(ints[22]), 'step_counter': int(ints[23])}
+
+    def _refresh_state(self):
+        self._batch.state_into(self._pack_state)
+        self._state = self._decode_state(self._pack[self._batch.obs_dim + 3:self._batch.obs_dim + 19].cpu().numpy())
+
     def step(self, action):                                                    # rge:349-368
+        b, od = self._batch, self._batch.obs_dim
         if self.ACTION_MODE == 'continuous':
-            act = np.asarray(action, dtype=np.float64).reshape(1, -1)
+            import torch
+            act = torch.as_tensor(np.asarray(action, dtype=np.float64).reshape(1, -1), device=b.device)
         else:
-            act = [int(action)]
-        obs, reward, done, info = self._batch.step(act)
+            self._act_i32.fill_(int(action))
+            act = self._act_i32
+        b.step_into(act, self._pack_obs, self._pack_reward, self._pack_done, self._pack_info, self._scratch_final)
+        b.state_into(self._pack_state)
+        host = self._pack.cpu().numpy()                  # the step's only device-to-host copy (and sync)
+        prev_angle = self._state['last_turning_angle']
+        self._state = self._decode_state(host[od + 3:od + 19])
+        self.robot.angle_diff = abs(self._state['last_turning_angle'] - prev_angle)      # rob:357
         self._step_counter += 1
-        done = bool(done[0])
-        info_row = info[0].cpu().numpy()
+        done = bool(host[od + 19:od + 20].view(np.uint8)[0])
         if self._renders and self._rollout:
             self.replay_buffer.append(action)
             if done:
                 print(self.replay_buffer)
-        return self._obs_out(obs[0]), float(reward[0]), done, {'reward': float(info_row[0]),
-                                                               'penalty': float(info_row[1])}
+        return np.array(host[:od], dtype=np.float64), float(host[od]), done, {'reward': float(host[od + 1]),
+                                                                               'penalty': float(host[od + 2])}
 
     def reset(self):                                                           # rge:370-387
         if self._rollout:
@@ -161,7 +208,10 @@ class PaintGymEnv(spaces.Env):
             random.randint(0, 7)              # the reference draws an (unused) pre-paint mode first, rge:378
             index = random.randint(0, len(self._start_points) - 1)
         self._step_counter = 0
-        return self._obs_out(self._batch.reset(start_idx=[index])[0])
+        obs = self._obs_out(self._batch.reset(start_idx=[index])[0])
+        self._refresh_state()
+        self.robot.angle_diff = 0.0
+        return obs
 
     def get_texture_image(self):
         """(H, W, 3) uint8 texture: painted texels red, unpainted front texels grey (bpw:585-592, 737-738)."""

@@ -1,0 +1,32 @@
+"""Every fast path of the step kernel against its general counterpart.
+
+__graft_entry__.build() also compiles two diagnostic variants of the library in which the fast paths are
+disabled (per-shot painting instead of the five-shot union pass; whole-table scans instead of ring searches
+and the general two-stage ray instead of the convex-neighbourhood path).  The parity suites are run against
+each variant in a fresh child process (PAINTRL_LIB selects the library before anything is loaded); the product
+build never defines these macros.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('variant', ['force_per_shot_paint', 'force_general_search'])
+def test_parity_suites_on_forced_general_paths(variant):
+    from paintrl_amd import build
+    lib = build.variant_path(variant)
+    if not os.path.isfile(lib):
+        build.build_variant(variant)
+    env = dict(os.environ, PAINTRL_LIB=lib)
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(REPO, 'tests', 'test_gpu_parity.py'),
+                          os.path.join(REPO, 'tests', 'test_gpu_edge_cases.py'), '-x', '-q', '-m', 'gpu', '-p',
+                          'no:cacheprovider'], env=env, cwd=REPO, capture_output=True, text=True, timeout=1500)
+    tail = out.stdout[-1500:] + out.stderr[-500:]
+    assert out.returncode == 0, tail
+    assert ' passed' in out.stdout and 'failed' not in out.stdout, tail
