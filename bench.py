@@ -34,8 +34,8 @@ sys.path.insert(0, REPO)
 
 ENVS_PER_GPU = 4096
 FRAGMENT = 100                  # rollout fragment length (paint_ppo.py:190 sample_batch_size)
-TIME_ALL_BELOW = 256            # runs of at most this many steps time EVERY launch with HIP events ...
-TIMING_EVERY = 8                # ... longer ones every 8th (the events cost ~1 us of stream time each)
+TIMING_EVERY = 8                # runs of > SAMPLE_ABOVE steps also bracket every 8th launch with its own HIP event
+SAMPLE_ABOVE = 256              # pair (a pair costs ~3.5 us of stream time, so short runs are left unperturbed)
 PREWARM_SECONDS = 0.4           # untimed stepping of a scratch batch first: the timed region then runs at
                                 # the clocks a long job holds, also at the driver's --warmup 5 --steps 20
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -365,11 +365,19 @@ def main():
     stream_sync()
     pdist.barrier()
     stream_sync()
-    timing_every = 1 if args.steps <= TIME_ALL_BELOW else TIMING_EVERY
+    # kernel time for the roofline: ONE HIP event pair on the launch stream around the whole timed region (the
+    # launches are back to back, the host runs ahead), divided by the launches -- an upper bound on the kernel's
+    # duration (it includes the ~1 us dispatch gaps) that cannot exceed ms_per_step and does not perturb the run;
+    # long runs additionally sample single launches with their own event pairs
+    timing_every = TIMING_EVERY if args.steps > SAMPLE_ABOVE else 0
     for e in subs:
         e.timing(timing_every)
+    region_ok = len(subs) == 1 and graph is None
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(main_stream)
     run(args.warmup, total)
+    ev1.record(main_stream)
     stream_sync()
     pdist.barrier()
     stream_sync()
@@ -388,14 +396,14 @@ def main():
         n_launch_envs = args.envs // len(subs)
         survey_env, survey_launch, per_env, static, per_launch = algorithmic_bytes(dt, n_launch_envs, env.obs_dim)
         ms_per_step = 1e3 * elapsed / args.steps
-        # inside a captured HIP graph (--graph) or the fragment kernel the per-launch events are not recorded
-        avg_kernel_s = kernel_ms / launches / 1e3 if launches and kernel_ms > 0 else None
-        if avg_kernel_s is not None and len(subs) == 1 and fragment_runner is None:
-            # the kernel runs inside the step: an event pair that reads longer than the step it brackets is
-            # event overhead (short runs), not kernel time
-            assert avg_kernel_s * 1e3 <= ms_per_step * 1.001 or timing_every > 1, \
+        sampled_us = 1e3 * kernel_ms / launches if launches and kernel_ms > 0 else None
+        avg_kernel_s = None
+        if region_ok and args.policy == 'random':
+            avg_kernel_s = ev0.elapsed_time(ev1) / 1e3 / args.steps       # one step = one step_kernel launch
+            assert avg_kernel_s * 1e3 <= ms_per_step * 1.001, \
                 'kernel %.1f us > step %.1f us' % (avg_kernel_s * 1e6, ms_per_step * 1e3)
-            avg_kernel_s = min(avg_kernel_s, ms_per_step / 1e3)
+        elif sampled_us:
+            avg_kernel_s = sampled_us / 1e6
         achieved = survey_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
         traffic = None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
@@ -437,7 +445,11 @@ def main():
                          'layout_bytes_per_env_step': per_env, 'layout_static_table_bytes': static,
                          'layout_bytes_per_launch': per_launch,
                          'avg_kernel_us': avg_kernel_s * 1e6 if avg_kernel_s else None,
-                         'launches_timed': int(launches), 'timed_every': timing_every,
+                         'launches_timed': args.steps if (region_ok and args.policy == 'random') else int(launches),
+                         'kernel_time_from': 'one HIP event pair on the launch stream around the timed region / launches '
+                                             '(upper bound: includes dispatch gaps)' if (region_ok and args.policy == 'random')
+                                             else 'HIP event pairs around sampled launches',
+                         'avg_kernel_us_sampled': sampled_us, 'sampled_launches': int(launches),
                          'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
                          if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random'
                              and args.paint_method == 'fast' and len(subs) == 1) else None},

@@ -38,6 +38,7 @@
 
 #include "paintrl.h"
 
+#include "prl_diag.hpp"
 #include "prl_device.hpp"
 #include "prl_ray.hpp"
 #include "prl_search.hpp"
@@ -87,25 +88,13 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-#ifdef PRL_WAVE_TIMES
-    const unsigned long long wave_t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wave_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
-#ifdef PRL_REPEAT          // diagnostic build: PRL_REPEAT whole steps per launch (cold-start vs steady-state cost)
-  for (int prl_rep = 0; prl_rep < PRL_REPEAT; ++prl_rep) {
-    __threadfence();
-#endif
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-#ifdef PRL_PHASE_TIMING
-    Prof prof;
-    for (int k = 0; k < PH_COUNT; ++k) prof.acc[k] = 0;
-    prof.prev = __builtin_amdgcn_s_memtime();
-#endif
+    PROF_BEGIN();
     load_masks<KW>(a, env, P.n_words, lane, painted, last);
     STAMP(PH_LOAD);
 
@@ -168,40 +157,17 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
         double t, hit[3], pos[3], orn[3], quat[4];
         STAMP(PH_MATH);
-#ifdef PRL_ABLATE_RAY                       // diagnostic stand-in: hit 0.1 along the normal, no table reads
-        bool on = true;
-        t = 0.1;
-        hit[0] = pt[0] + 0.1 * cur_norm[0];
-        hit[1] = pt[1] + 0.1 * cur_norm[1];
-        hit[2] = pt[2] + 0.1 * cur_norm[2];
-#else
-#ifdef PRL_DOUBLE_RAY                       // diagnostic build: the phase runs twice, the first result is discarded
-        {
-            double t2, h2[3] = {0, 0, 0};
-            int hint2 = facet_hint;
-            const int r2 = ray_closest_wave(P, pt, end, lane, t2, h2, hint2);
-            asm volatile("" ::"v"(t2), "v"(h2[0]), "v"(h2[1]), "v"(h2[2]), "s"(r2), "s"(hint2));
-        }
-#endif
         bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint) >= 0;
-#endif
         STAMP(PH_RAY);
-#ifdef PRL_DOUBLE_HOOK
-        if (on) {
-            double p2[3] = {0, 0, 0}, o2[3] = {0, 0, 0};
-            const bool b2 = hook_point_wave(P, hit, lane, p2, o2 PROF_PASS);
-            asm volatile("" ::"v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(o2[0]), "v"(o2[1]), "v"(o2[2]), "s"((int)b2));
-        }
-#endif
-        if (on) on = hook_point_wave(P, hit, lane, pos, orn PROF_PASS);
+        double center[3];                                  // rob:277-278 shot centre
+        if (on) on = hook_point_wave(P, hit, lane, pos, orn, quat, center PROF_PASS);
         if (!on) {
             orn[0] = cur_norm[0];
             orn[1] = cur_norm[1];
             orn[2] = cur_norm[2];
-        }
-        pose_orn_quat(orn, quat);
-        if (!on) {
+            pose_orn_quat(orn, quat);
             transform_point(cur_pose, quat, d2, d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
+            transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, center);
             if (S.last_on_part) {                                    // rob:292-300
                 S.last_on_part = 0;
             } else {
@@ -221,9 +187,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];       // stays in vector registers: scalar registers are the scarce kind
-        // rob:277-278 shot centre; painting is deferred until all five centres are known
-        double center[3];
-        transform_point(pos, quat, 0.0, 0.0, 0.1, center);
+        // painting is deferred until all five centres are known
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (lane == 0) cen[3 * shot + k] = center[k];
@@ -256,6 +220,10 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
             }
         }
     }
+    // lane 0 wrote the shot centres to LDS, every lane reads them below: order the two within the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
     if constexpr (NORMAL) {
@@ -267,20 +235,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         pixel_counter = (int)(sums & 0xffffffffu);
     } else {
         uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
-#ifdef PRL_ABLATE_BALL
-        if (true) {
-#else
-#ifdef PRL_DOUBLE_BALL
-        {
-            uint64_t p2[KW_MAX], l2[KW_MAX] = {0, 0, 0, 0};
-            int s2 = 0, c2 = 0;
-            for (int k = 0; k < KW_MAX; ++k) p2[k] = painted[k];
-            const bool b2 = paint_shots_union<KW>(P, C.paint_radius, cen, lane, p2, last, l2, s2, c2);
-            asm volatile("" ::"v"(p2[0]), "v"(l2[0]), "v"(p2[1]), "v"(l2[1]), "v"(p2[2]), "v"(l2[2]), "s"(s2), "s"(c2), "s"((int)b2));
-        }
-#endif
         if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
-#endif
 #pragma unroll
             for (int k = 0; k < KW; ++k) last[k] = new_last[k];
         } else {                                   // general path: one ball query per shot
@@ -334,13 +289,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     const bool do_reset = dn && C.auto_reset;
     double *obs_row = a.obs + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
-#ifndef PRL_ABLATE_OBS
-#ifdef PRL_DOUBLE_OBS
     if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
-    __builtin_amdgcn_s_waitcnt(0);
-#endif
-    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
-#endif
     if (lane == 0) {
         a.reward[env] = actual;
         a.done[env] = (uint8_t)dn;
@@ -371,32 +320,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     STAMP(PH_STORE);
-#ifdef PRL_WAVE_TIMES      // diagnostic build: wave lifetime and on-part shot count into final_obs[env][0..1]
-    if (lane == 0 && a.final_obs) {
-        a.final_obs[(size_t)env * od] = (double)(__builtin_amdgcn_s_memtime() - wave_t0);
-        uint32_t *wc = g_wcnt[env & 0xffff];       // misses:3 dn:1 | general rays:4 | stage 1:4 | chunk tests:6 |
-        const uint64_t packed =                    // vertex batches:8 | extra rings:4 | paint words:8 | straddle words:8
-            (uint64_t)(S.terminate_counter - counter_before) | ((uint64_t)dn << 3) | ((uint64_t)(wc[0] & 15) << 4) |
-            ((uint64_t)(wc[1] & 15) << 8) | ((uint64_t)(wc[2] & 63) << 12) | ((uint64_t)(wc[3] & 255) << 18) |
-            ((uint64_t)(wc[4] & 15) << 26) | ((uint64_t)(wc[5] & 255) << 30) | ((uint64_t)(wc[6] & 255) << 38) |
-            ((uint64_t)(wc[7] & 15) << 46) | ((uint64_t)((wc[4] >> 4) & 15) << 50);
-        for (int k = 0; k < 8; ++k) wc[k] = 0;
-        a.final_obs[(size_t)env * od + 1] = (double)packed;
-        a.final_obs[(size_t)env * od + 2] = (double)dn;
-        a.final_obs[(size_t)env * od + 3] = (double)wave_r0;                              // 100 MHz wall clock
-        a.final_obs[(size_t)env * od + 4] = (double)__builtin_amdgcn_s_memrealtime();
-        a.final_obs[(size_t)env * od + 5] =                                               // HW_ID + 2^32 * XCC_ID
-            (double)(((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
-                     __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
-    }
-#endif
-#ifdef PRL_PHASE_TIMING
-    if (lane == 0)
-        for (int k = 0; k < PH_COUNT; ++k) atomicAdd(&g_phase_cycles[k], prof.acc[k]);
-#endif
-#ifdef PRL_REPEAT
-  }
-#endif
+    PROF_END();
 }
 
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
@@ -553,7 +477,24 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (!monotone_starts(t->vgrid_start, (size_t)d.vg_nx * d.vg_ny + 1, d.n_vertices) ||
         t->vgrid_start[(size_t)d.vg_nx * d.vg_ny] != d.n_vertices)
         return fail(PRL_E_INVALID, "vertex grid starts must be non-decreasing and end at n_vertices");
-    UP(tri_rec, t->tri_records, (size_t)d.n_triangles * 16);
+    {   // device triangle records: the host's 16 doubles + the quaternion and shot-centre offset a hit on the
+        // triangle produces (prl_device.hpp TRI_REC), so that the step kernel reads them instead of running a
+        // square root, four divisions and a rotation per sub-shot
+        if (!t->tri_records || d.n_triangles <= 0) return fail(PRL_E_INVALID, "no triangle records");
+        std::vector<double> rec((size_t)d.n_triangles * TRI_REC, 0.0);
+        for (int i = 0; i < d.n_triangles; ++i) {
+            const double *src = t->tri_records + (size_t)i * 16;
+            double *r = rec.data() + (size_t)i * TRI_REC;
+            for (int k = 0; k < 16; ++k) r[k] = src[k];
+            const double orn[3] = {-src[13], -src[14], -src[15]};
+            double q[4], off[3];
+            pose_orn_quat(orn, q);
+            quat_rotate(q, 0.0, 0.0, SHOT_CENTRE_OFFSET, off);
+            for (int k = 0; k < 4; ++k) r[16 + k] = q[k];
+            for (int k = 0; k < 3; ++k) r[20 + k] = off[k];
+        }
+        UP(tri_rec, rec.data(), rec.size());
+    }
     d.n_col = t->n_collision;
     d.n_col_pad = t->n_collision_pad;
     if (d.n_col <= 0 || d.n_col_pad % 64 || d.n_col_pad < d.n_col) return fail(PRL_E_INVALID, "bad collision counts");

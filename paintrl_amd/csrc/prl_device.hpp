@@ -1,4 +1,4 @@
-// prl_device.hpp -- constants, table descriptor, diagnostic macros, wave-level helpers, reference arithmetic.
+// prl_device.hpp -- constants, table descriptor, wave-level helpers, reference arithmetic.
 // Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
 // file for the overall design.  Compile with -ffp-contract=off.
 #pragma once
@@ -16,6 +16,11 @@ constexpr int NOT_ON_PART_TERMINATE = 1000;     // rob:167
 constexpr double RAY_EPS_DET = 1e-12;
 constexpr double RAY_EPS_BARY = 1e-9;
 constexpr double PI = 3.141592653589793;
+constexpr double SHOT_CENTRE_OFFSET = 0.1;      // rob:277-278: the shot centre lies 0.1 ahead of the tool
+// Device triangle record: a[3] v0[3] v1[3] d00 d01 d11 inv normal[3] | quat[4] centre_off[3] pad.  The tail is what
+// a hit on this triangle makes of its normal, computed once on upload with the device's own arithmetic:
+// quat = get_pose_orn(-normal) (rob:93-100), centre_off = R(quat) (0, 0, 0.1) (rob:277-278).
+constexpr int TRI_REC = 24;
 
 // Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
 // space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
@@ -54,7 +59,7 @@ struct PartDev {
     int vg_nx, vg_ny;
     gint_p vg_start;
     int n_triangles;
-    gdouble_p tri_rec;
+    gdouble_p tri_rec;            // [n_triangles][TRI_REC]: the 16 doubles of the host table + derived tail (part_fill)
     int n_col, n_col_pad;
     gdouble_p col[9];
     gfloat_p col_bbox;
@@ -93,45 +98,17 @@ struct StepArgs {
     const uint8_t *reset_mask;
 };
 
-#ifdef PRL_WAVE_TIMES      // per-wave trip counters of the data-dependent loops (diagnostic build only)
-__device__ uint32_t g_wcnt[1 << 16][8];
-#define WCNT(slot, v)                                                                        \
-    do {                                                                                     \
-        if ((threadIdx.x & 63) == 0) g_wcnt[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 0xffff][slot] += (v); \
-    } while (0)
-#else
-#define WCNT(slot, v)
-#endif
-
-// ---------------------------------------------------------------- diagnostic build only (-DPRL_PHASE_TIMING)
-// Per-phase s_memtime deltas summed over all waves into a buffer nothing else reads
-// (cdna_hip_programming.md "In-kernel stamps").  The product build contains no stamp.
-#ifdef PRL_PHASE_TIMING
-enum { PH_LOAD = 0, PH_RAY, PH_VERTEX, PH_BARY, PH_MATH, PH_BALL, PH_APPLY, PH_OBS, PH_STORE, PH_COUNT };
-__device__ unsigned long long g_phase_cycles[16];
-struct Prof {
-    unsigned long long acc[PH_COUNT];
-    unsigned long long prev;
-};
-#define PROF_ARG , Prof &prof
-#define PROF_PASS , prof
-#define STAMP(ph)                                                         \
-    do {                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                \
-        __builtin_amdgcn_s_waitcnt(0);                                    \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
-        prof.acc[ph] += now_ - prof.prev;                                 \
-        prof.prev = now_;                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                \
-    } while (0)
-#else
-#define PROF_ARG
-#define PROF_PASS
-#define STAMP(ph) \
-    do {          \
-    } while (0)
-#endif
+// ---------------------------------------------------------------- table loads
+// Table indices are non-negative ints.  Indexing a global pointer with a SIGNED 32-bit value makes the
+// compiler sign-extend it and build a 64-bit address per lane (v_ashrrev + v_lshl_add_u64, then a load
+// with a VGPR-pair address); a 32-bit unsigned BYTE offset lets it keep the table base in scalar registers
+// and use the "saddr + 32-bit voffset" form of global_load (one v_lshlrev per load).  Every table is far
+// smaller than 4 GB, so the byte offset cannot wrap.
+template <typename T>
+__device__ __forceinline__ T ldg(const T GAS *p, int i) {
+    const uint32_t off = (uint32_t)i * (uint32_t)sizeof(T);
+    return *reinterpret_cast<const T GAS *>(reinterpret_cast<const char GAS *>(p) + off);
+}
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -227,12 +204,12 @@ __device__ __forceinline__ double sel3(double x, double y, double z, int axis) {
 
 // ---------------------------------------------------------------- reference arithmetic
 // numpy.dot on 3-vectors = OpenBLAS ddot = fused chain (oracle/paint_oracle.c dot3_np)
-__device__ __forceinline__ double dot3_np(double a0, double a1, double a2, double b0, double b1, double b2) {
+__host__ __device__ __forceinline__ double dot3_np(double a0, double a1, double a2, double b0, double b1, double b2) {
     return __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0));
 }
 
 // this project's multiplyTransforms rotation (paintrl_amd/geometry.py quat_rotate)
-__device__ __forceinline__ void quat_rotate(const double q[4], double v0, double v1, double v2, double o[3]) {
+__host__ __device__ __forceinline__ void quat_rotate(const double q[4], double v0, double v1, double v2, double o[3]) {
     double t0 = 2.0 * (q[1] * v2 - q[2] * v1);
     double t1 = 2.0 * (q[2] * v0 - q[0] * v2);
     double t2 = 2.0 * (q[0] * v1 - q[1] * v0);
@@ -241,7 +218,7 @@ __device__ __forceinline__ void quat_rotate(const double q[4], double v0, double
     o[2] = (v2 + q[3] * t2) + (q[0] * t1 - q[1] * t0);
 }
 
-__device__ __forceinline__ void transform_point(const double pos[3], const double q[4], double v0, double v1,
+__host__ __device__ __forceinline__ void transform_point(const double pos[3], const double q[4], double v0, double v1,
                                                 double v2, double o[3]) {
     double r[3];
     quat_rotate(q, v0, v1, v2, r);
@@ -251,7 +228,7 @@ __device__ __forceinline__ void transform_point(const double pos[3], const doubl
 }
 
 // rob:93-100 get_pose_orn + bpw:32-37 normalize
-__device__ __forceinline__ void pose_orn_quat(const double orn[3], double q[4]) {
+__host__ __device__ __forceinline__ void pose_orn_quat(const double orn[3], double q[4]) {
     double x = 0.0 * orn[2] - 1.0 * orn[1];
     double y = 1.0 * orn[0] - 0.0 * orn[2];
     double z = 0.0 * orn[1] - 0.0 * orn[0];

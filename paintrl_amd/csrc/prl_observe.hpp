@@ -44,6 +44,8 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     cnt[lane] = 0;
     cnt[64 + lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // zeroes before the atomics of other lanes
+    __builtin_amdgcn_wave_barrier();
     const double two_pi = 2 * PI, basis = two_pi / g;
     for (int w = 0; w < P.n_words; ++w) {
         const uint64_t vw = P.word_valid[w];
@@ -53,7 +55,7 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
             if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
         if (!((vw >> lane) & 1)) continue;
         const int s = (w << 6) + lane;
-        const double rx = sx[s] - x1, ry = sy[s] - x2;
+        const double rx = ldg(sx, s) - x1, ry = ldg(sy, s) - x2;
         if (rx == 0 && ry == 0) continue;
         double ang = atan2(ry, rx);
         if (ang < 0) ang = two_pi + ang;
@@ -62,6 +64,9 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
         atomicAdd(&cnt[idx], 1);
         if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // all atomics before the read-out
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < g) {
         const int t = cnt[lane], u = cnt[64 + lane];
         out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
@@ -104,7 +109,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
 #pragma unroll
                     for (int j = 0; j < 16; ++j)
                         if (c0 + j < cells)
-                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & P.cell_mask[(size_t)(c0 + j) * P.n_words + w])
+                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & ldg(P.cell_mask, (c0 + j) * P.n_words + w))
                                            << (16 * (j & 3));
                 }
             }
@@ -116,7 +121,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
 #pragma unroll
                 for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
                 const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
-                const int num = P.cell_count[cell];
+                const int num = ldg(P.cell_count, cell);
                 out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
             }
         }
@@ -150,8 +155,8 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         const int w = lane + 64 * k;
         bool straddle = false;
         if (w < P.n_words) {
-            const f64x4 bb = reinterpret_cast<const f64x4 GAS *>(P.word_bbox)[w];
-            valid[k] = P.word_valid[w];
+            const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), w);
+            valid[k] = ldg(P.word_valid, w);
             const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
             if ((xg || xl) && (yg || yl)) {
                 const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
@@ -165,7 +170,6 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         }
         smask[k] = __ballot(straddle);
     }
-#ifndef PRL_ABLATE_STRADDLE
     // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
     // { xs > x1 } a suffix of the word: a 7-probe lower bound by the owning lane, all rows at once.
     // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
@@ -184,7 +188,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
             for (int step = 32; step >= 0; step = step > 1 ? step >> 1 : step - 1) {   // 32 .. 1, then the closing probe
                 double probe[KW_MAX];
 #pragma unroll
-                for (int k = 0; k < KW; ++k) probe[k] = sx[base[k] + pos[k] + (step ? step - 1 : 0)];
+                for (int k = 0; k < KW; ++k) probe[k] = ldg(sx, base[k] + pos[k] + (step ? step - 1 : 0));
                 __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip per step
 #pragma unroll
                 for (int k = 0; k < KW; ++k) pos[k] += probe[k] < x1 ? (step ? step : 1) : 0;
@@ -192,7 +196,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const int at = base[k] + (pos[k] < 64 ? pos[k] : 63);
-                int ub = (pos[k] < 64 && sx[at] == x1) ? (int)P.samp_ub[at] : pos[k];
+                int ub = (pos[k] < 64 && ldg(sx, at) == x1) ? (int)ldg(P.samp_ub, at) : pos[k];
                 if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
                 if (vline[k]) {
                     const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
@@ -206,19 +210,15 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
             }
         }
     }
-#endif
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         uint64_t sm = smask[k];
-#ifdef PRL_ABLATE_STRADDLE
-        sm = 0;
-#endif
         while (sm) {                                // wave-uniform loop over the words that straddle the tool
             WCNT(6, 1);
             const int L = __builtin_ctzll(sm);
             sm &= sm - 1;
             const int w2 = L + 64 * k;
-            const double xs = sx[(w2 << 6) + lane], ys = sy[(w2 << 6) + lane];
+            const double xs = ldg(sx, (w2 << 6) + lane), ys = ldg(sy, (w2 << 6) + lane);
             const uint64_t vs = P.word_valid[w2];
             // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
             // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most

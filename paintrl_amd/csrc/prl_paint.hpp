@@ -29,12 +29,12 @@ __device__ void ball_query_wave(PartRef P, double radius, const double c[3], int
         for (int w = begin >> 6; w <= wlast; w += 2) {            // two words per trip: six loads in flight
             const int s0 = (w << 6) + lane, s1 = s0 + 64;
             const bool two = w + 1 <= wlast;
-            const double x0 = P.samp[0][s0], y0 = P.samp[1][s0], z0 = P.samp[2][s0];
+            const double x0 = ldg(P.samp[0], s0), y0 = ldg(P.samp[1], s0), z0 = ldg(P.samp[2], s0);
             double x1 = 0, y1 = 0, z1 = 0;
             if (two) {
-                x1 = P.samp[0][s1];
-                y1 = P.samp[1][s1];
-                z1 = P.samp[2][s1];
+                x1 = ldg(P.samp[0], s1);
+                y1 = ldg(P.samp[1], s1);
+                z1 = ldg(P.samp[2], s1);
             }
             {
                 const double dx = x0 - c[0], dy = y0 - c[1], dz = z0 - c[2];
@@ -96,7 +96,7 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
     const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
     const int rcy = cy_lo - 1 + (lane >> 1);
     const bool ok = lane < 8 && rcy <= cy_hi + 1 && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
-    const int bound = ok ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+    const int bound = ok ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
     int rb[4], re[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -111,7 +111,7 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
         for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
             WCNT(5, 1);
             const int s = (w << 6) + lane;
-            const double x = P.samp[0][s], y = P.samp[1][s], z = P.samp[2][s];
+            const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
             // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only
             const bool in = s >= rb[r] && s < re[r];
             uint64_t b[PAINT_PER_ACTION];

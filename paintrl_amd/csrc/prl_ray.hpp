@@ -44,10 +44,10 @@ __device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, cons
 __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], double d0, double d1, double d2,
                                        double tmax, double &best_t, int &best_r, int &best_i, double &best_det) {
     if (i >= 0) {
-        const double v00 = P.col[0][i], v01 = P.col[1][i], v02 = P.col[2][i];
-        const double e10 = P.col[3][i], e11 = P.col[4][i], e12 = P.col[5][i];
-        const double e20 = P.col[6][i], e21 = P.col[7][i], e22 = P.col[8][i];
-        const int rk = P.col_rank[i];
+        const double v00 = ldg(P.col[0], i), v01 = ldg(P.col[1], i), v02 = ldg(P.col[2], i);
+        const double e10 = ldg(P.col[3], i), e11 = ldg(P.col[4], i), e12 = ldg(P.col[5], i);
+        const double e20 = ldg(P.col[6], i), e21 = ldg(P.col[7], i), e22 = ldg(P.col[8], i);
+        const int rk = ldg(P.col_rank, i);
         const double p0 = d1 * e22 - d2 * e21;
         const double p1 = d2 * e20 - d0 * e22;
         const double p2 = d0 * e21 - d1 * e20;
@@ -78,9 +78,11 @@ __device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], doub
                                        double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
     interior = false;
     if (i >= 0) {
-        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec + (size_t)i * 12);
-        const f64x2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
-        const int rk = P.col_rank[i];
+        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
+        const int i6 = i * 6;
+        const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4),
+                    r5 = ldg(r, i6 + 5);
+        const int rk = ldg(P.col_rank, i);
         const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
         const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
         const double p0 = d1 * e22 - d2 * e21;
@@ -180,7 +182,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         // one such lane): no reduction, no second round.
         WCNT(4, 1);
         const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
-        const int i1 = lane < P.nbr_width ? P.col_nbr[hint * P.nbr_width + lane] : -1;
+        const int i1 = lane < P.nbr_width ? ldg(P.col_nbr, hint * P.nbr_width + lane) : -1;
         bool interior;
         mt_rec(P, i1, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
         const uint64_t im = __ballot(interior);
@@ -194,7 +196,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
             if (win >= 0) {
                 const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
                 const double fdet = bcast_d(best_det, win);
-                const int i2 = lane < P.nbr_width ? P.col_nbr[f * P.nbr_width + lane] : -1;
+                const int i2 = lane < P.nbr_width ? ldg(P.col_nbr, f * P.nbr_width + lane) : -1;
                 const bool entering = (double)P.col_orient[f] * fdet > 0;
                 if (entering && __ballot(i2 >= 0) != 0) {
                     if (f != hint) {
@@ -220,21 +222,18 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
         const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
         for (int stage = 0; stage < 2; ++stage) {
-#ifdef PRL_PHASE_COUNTERS
-            if (lane == 0) atomicAdd(&g_phase_cycles[10 + stage], 1ull);
-#endif
             const double tmax = stage == 0 ? 0.125 : 1.0;
             if (stage == 1) WCNT(1, 1);
             const SegBox sb = seg_box(o3, d3, tmax);
             int n_cand = 0;
             for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
-                const f32x4 ca = chunk_boxes[2 * (cbase + lane)], cb = chunk_boxes[2 * (cbase + lane) + 1];
+                const f32x4 ca = ldg(chunk_boxes, 2 * (cbase + lane)), cb = ldg(chunk_boxes, 2 * (cbase + lane) + 1);
                 uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
                 while (cm) {
                     WCNT(2, 1);
                     const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
                     cm &= cm - 1;
-                    const f32x4 ba = boxes[2 * i], bb = boxes[2 * i + 1];
+                    const f32x4 ba = ldg(boxes, 2 * i), bb = ldg(boxes, 2 * i + 1);
                     const bool pass = box_overlap(sb, ba, bb);
                     const uint64_t pm = __ballot(pass);
                     if (pm == 0) continue;

@@ -16,7 +16,7 @@ __device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int ic
     const int r = lane >> 1, cy = icy - 1 + r;
     const int cx0 = icx - 1 < 0 ? 0 : icx - 1, cx1 = icx + 1 > nx - 1 ? nx - 1 : icx + 1;
     const bool ok = lane < 6 && cy >= 0 && cy < ny && cx0 <= cx1;
-    const int v = ok ? start[cy * nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+    const int v = ok ? ldg(start, cy * nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
     Rows3 out;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -35,16 +35,16 @@ __device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const dou
         double x0 = 0, y0 = 0, z0 = 0, x1 = 0, y1 = 0, z1 = 0;
         int r0 = 0, r1 = 0;
         if (k0) {
-            x0 = P.vert[0][v0];
-            y0 = P.vert[1][v0];
-            z0 = P.vert[2][v0];
-            r0 = P.vert_rank[v0];
+            x0 = ldg(P.vert[0], v0);
+            y0 = ldg(P.vert[1], v0);
+            z0 = ldg(P.vert[2], v0);
+            r0 = ldg(P.vert_rank, v0);
         }
         if (k1) {
-            x1 = P.vert[0][v1];
-            y1 = P.vert[1][v1];
-            z1 = P.vert[2][v1];
-            r1 = P.vert_rank[v1];
+            x1 = ldg(P.vert[0], v1);
+            y1 = ldg(P.vert[1], v1);
+            z1 = ldg(P.vert[2], v1);
+            r1 = ldg(P.vert_rank, v1);
         }
         if (k0) {
             const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
@@ -82,7 +82,7 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
         const int rcy = icy - ring + (lane >> 1);
         const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
-        const int bound = okr ? P.vg_start[rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        const int bound = okr ? ldg(P.vg_start, rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
         // per-row begin and exclusive prefix of counts, wave-uniform (<= 7 rows)
         int rbeg[7], rpre[8];
         rpre[0] = 0;
@@ -104,9 +104,9 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
 #pragma unroll
                 for (int r = 1; r < 7; ++r)
                     if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
-                const double dx = P.vert[0][v] - pt[0], dy = P.vert[1][v] - pt[1], dz = P.vert[2][v] - pt[2];
+                const double dx = ldg(P.vert[0], v) - pt[0], dy = ldg(P.vert[1], v) - pt[1], dz = ldg(P.vert[2], v) - pt[2];
                 const double dd = (dx * dx + dy * dy) + dz * dz;
-                const int rk = P.vert_rank[v];
+                const int rk = ldg(P.vert_rank, v);
                 if (dd < best_d || (dd == best_d && rk < best_rank)) {
                     best_d = dd;
                     best_rank = rk;
@@ -150,7 +150,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
         const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.sg_nx - 1 ? P.sg_nx - 1 : icx + ring;
         const int rcy = icy - ring + (lane >> 1);
         const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
-        const int bound = okr ? P.sg_start[rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)] : 0;
+        const int bound = okr ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
@@ -161,9 +161,9 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
             for (int s0 = b0; s0 < e0; s0 += 64) {
                 const int sidx = s0 + lane;
                 if (sidx < e0) {
-                    const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+                    const double dx = ldg(P.samp[0], sidx) - pt[0], dy = ldg(P.samp[1], sidx) - pt[1], dz = ldg(P.samp[2], sidx) - pt[2];
                     const double dd = (dx * dx + dy * dy) + dz * dz;
-                    const int rk = P.samp_rank[sidx];
+                    const int rk = ldg(P.samp_rank, sidx);
                     if (dd < best_d || (dd == best_d && rk < best_rank)) {
                         best_d = dd;
                         best_rank = rk;
@@ -185,9 +185,9 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
         best_idx = -1;
         for (int s0 = 0; s0 < P.n_samples_pad; s0 += 64) {
             const int sidx = s0 + lane;
-            const double dx = P.samp[0][sidx] - pt[0], dy = P.samp[1][sidx] - pt[1], dz = P.samp[2][sidx] - pt[2];
+            const double dx = ldg(P.samp[0], sidx) - pt[0], dy = ldg(P.samp[1], sidx) - pt[1], dz = ldg(P.samp[2], sidx) - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            const int rk = P.samp_rank[sidx];
+            const int rk = ldg(P.samp_rank, sidx);
             if (rk != 0x7fffffff && (dd < best_d || (dd == best_d && rk < best_rank))) {
                 best_d = dd;
                 best_rank = rk;
@@ -203,28 +203,22 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
 }
 
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
-__device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3] PROF_ARG) {
-#ifdef PRL_ABLATE_VERTEX                    // diagnostic stand-in: some vertex near the right cell, no scan
-    const int vidx = P.vg_start[0] + ((int)(fabs(pt[1] * 977.0 + pt[2] * 1543.0)) % P.n_vertices);
-#else
-#ifdef PRL_DOUBLE_VERTEX
-    {
-        const int v2 = nearest_vertex_wave(P, pt, lane);
-        asm volatile("" ::"s"(v2));
-    }
-#endif
+// Also returns what the chosen triangle's normal implies for the tool: the quaternion of rob:93-100 and the shot
+// centre of rob:277-278 (pose + R(quat)(0, 0, 0.1)), read from the triangle record's precomputed tail.
+__device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3], double quat[4],
+                                double center[3] PROF_ARG) {
     const int vidx = nearest_vertex_wave(P, pt, lane);
-#endif
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;
-    const int ti = lane < P.adj_width ? P.vadj[vidx * P.adj_width + lane] : -1;   // file order, -1 = pad
+    const int ti = lane < P.adj_width ? ldg(P.vadj, vidx * P.adj_width + lane) : -1;   // file order, -1 = pad
     if (__ballot(ti >= 0) == 0) return false;
     bool inside = false, ok = false;
-    double m = -INFINITY, n0 = 0, n1 = 0, n2 = 0;
+    double m = -INFINITY, n0, n1, n2;
     if (ti >= 0) {
-        gdouble_p r = P.tri_rec + (size_t)ti * 16;
-        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(r);
-        const f64x2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4], q5 = r2[5], q6 = r2[6], q7 = r2[7];
+        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(P.tri_rec);
+        const int t8 = ti * (TRI_REC / 2);
+        const f64x2 q0 = ldg(r2, t8), q1 = ldg(r2, t8 + 1), q2 = ldg(r2, t8 + 2), q3 = ldg(r2, t8 + 3), q4 = ldg(r2, t8 + 4),
+                    q5 = ldg(r2, t8 + 5), q6 = ldg(r2, t8 + 6);
         // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
         const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
         const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
@@ -242,9 +236,6 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
         m = v < u ? v : u;
         m = w < m ? w : m;
         ok = m >= -1.0;
-        n0 = q6.y;
-        n1 = q7.x;
-        n2 = q7.y;
     }
     int j;
     const uint64_t in_mask = __ballot(inside);
@@ -259,15 +250,26 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
             j = 63 - __builtin_clzll(__ballot(ok && m == mx));       // last one reaching the maximum
         }
     }
-    n0 = bcast_d(n0, j);
-    n1 = bcast_d(n1, j);
-    n2 = bcast_d(n2, j);
+    // the chosen triangle's normal, quaternion and centre offset: one wave-uniform read of its record's tail
+    const int tj = __builtin_amdgcn_readlane(ti, rfl(j));
+    const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)tj * (TRI_REC / 2);
+    const f64x2 t6 = rj[6], t7 = rj[7], t8 = rj[8], t9 = rj[9], t10 = rj[10], t11 = rj[11];
+    n0 = t6.y;
+    n1 = t7.x;
+    n2 = t7.y;
     pose[0] = pt[0] + n0 * HOOK_DISTANCE;
     pose[1] = pt[1] + n1 * HOOK_DISTANCE;
     pose[2] = pt[2] + n2 * HOOK_DISTANCE;
     orn[0] = -n0;
     orn[1] = -n1;
     orn[2] = -n2;
+    quat[0] = t8.x;
+    quat[1] = t8.y;
+    quat[2] = t9.x;
+    quat[3] = t9.y;
+    center[0] = pose[0] + t10.x;
+    center[1] = pose[1] + t10.y;
+    center[2] = pose[2] + t11.x;
     STAMP(PH_BARY);
     return true;
 }

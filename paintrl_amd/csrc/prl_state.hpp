@@ -60,24 +60,26 @@ __device__ __forceinline__ void reset_state(PartRef P, EnvState &S, int start) {
 template <int KW>
 __device__ __forceinline__ void load_masks(const StepArgs &a, int env, int n_words, int lane, uint64_t painted[KW_MAX],
                                            uint64_t last[KW_MAX]) {
+    const uint64_t *pe = a.painted + (size_t)env * a.mask_stride, *le = a.last + (size_t)env * a.mask_stride;
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
-        const bool in = w < n_words;
-        painted[k] = in ? a.painted[(size_t)env * a.mask_stride + w] : 0;
-        last[k] = in ? a.last[(size_t)env * a.mask_stride + w] : 0;
+        const uint32_t w = lane + 64 * k;
+        const bool in = (int)w < n_words;
+        painted[k] = in ? pe[w] : 0;
+        last[k] = in ? le[w] : 0;
     }
 }
 
 template <int KW>
 __device__ __forceinline__ void store_masks(const StepArgs &a, int env, int n_words, int lane,
                                             const uint64_t painted[KW_MAX], const uint64_t last[KW_MAX]) {
+    uint64_t *pe = a.painted + (size_t)env * a.mask_stride, *le = a.last + (size_t)env * a.mask_stride;
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
-        if (w < n_words) {
-            a.painted[(size_t)env * a.mask_stride + w] = painted[k];
-            a.last[(size_t)env * a.mask_stride + w] = last[k];
+        const uint32_t w = lane + 64 * k;
+        if ((int)w < n_words) {
+            pe[w] = painted[k];
+            le[w] = last[k];
         }
     }
 }

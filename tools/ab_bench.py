@@ -1,15 +1,16 @@
-#!/usr/bin/env python3
-"""In-process A/B of two versions of csrc/paintrl_hip.hip on the bench workload.
+"""In-process A/B of prebuilt libraries on the bench workload.
 
-    python tools/ab_bench.py tools/_ab/base.hip paintrl_amd/csrc/paintrl_hip.hip [-DFLAG ...]
+    python tools/build_variant.py base            (here: builds tools/_ab/base.so from the working tree)
+    ... edit ...
+    python tools/build_variant.py new
+    gpurun -- python tools/ab_bench.py tools/_ab/base.so tools/_ab/new.so
 
-Builds each source into a scratch library, then alternates timed runs (same GPU, same process,
-HIP-event kernel time) so that device-to-device and DVFS differences cancel.
+Loads each library into its own ctypes handle, then alternates timed runs (same GPU, same process, one HIP event
+pair around 300 back-to-back launches) so that device-to-device and DVFS differences cancel.  Builds nothing.
+PRL_ENVS / PRL_OBS select the batch size and the observation mode.
 """
 import os
-import subprocess
 import sys
-import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -20,44 +21,42 @@ from paintrl_amd.batched_env import BatchedPaintEnv  # noqa: E402
 from paintrl_amd.device_tables import DeviceTables  # noqa: E402
 
 
-def build(src, flags):
-    out = os.path.join(tempfile.mkdtemp(prefix='prl_ab_'), 'libpaintrl_hip.so')
-    subprocess.check_call([hb.hipcc()] + hb.FLAGS + flags + ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, src, hb.POLICY_SOURCE, '-o', out])
-    return out
-
-
 def main():
-    srcs = [a for a in sys.argv[1:] if not a.startswith('-')]
-    flags = [a for a in sys.argv[1:] if a.startswith('-')]
+    libs = [os.path.abspath(a) for a in sys.argv[1:]]
     n = int(os.environ.get('PRL_ENVS', '4096'))
+    obs = os.environ.get('PRL_OBS', 'section')
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
     dt = DeviceTables(tables)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (400, n), generator=gen, device='cuda', dtype=torch.int32)
     envs = []
-    for src in srcs:
-        hb.LIBRARY = build(src, flags)
+    for path in libs:
+        hb.LIBRARY = path
         _lib._lib = None
-        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, obs_mode=os.environ.get('PRL_OBS', 'section'),
-                              overlap_penalty=os.environ.get('PRL_OBS', 'section') == 'grid')
+        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, obs_mode=obs, overlap_penalty=obs == 'grid')
         env.reset()
         for k in range(100):
             env.step_raw(acts[k])
         envs.append(env)
     torch.cuda.synchronize()
+    ref = envs[0].painted_words().clone()
+    for path, env in zip(libs[1:], envs[1:]):
+        same = bool((env.painted_words() == ref).all()) and bool((env.obs == envs[0].obs).all())
+        print('%-40s results after 100 steps %s the first library' % (os.path.basename(path), 'EQUAL' if same else 'DIFFER FROM'))
     times = [[] for _ in envs]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(8):
         for i, env in enumerate(envs):
-            env.timing(True)
+            e0.record()
             for k in range(100, 400):
                 env.step_raw(acts[k])
-            ms, launches = env.timing_read()
-            env.timing(False)
-            times[i].append(1e3 * ms / launches)
-    for src, t in zip(srcs, times):
-        print('%-44s kernel us: median %.2f  min %.2f  (%s)' % (src, np.median(t), np.min(t),
-                                                                ' '.join('%.1f' % v for v in t)))
+            e1.record()
+            torch.cuda.synchronize()
+            times[i].append(1e3 * e0.elapsed_time(e1) / 300)
+    for path, t in zip(libs, times):
+        print('%-40s us/step: median %.2f  min %.2f  (%s)' % (os.path.basename(path), np.median(t), np.min(t),
+                                                              ' '.join('%.1f' % v for v in t)))
 
 
 if __name__ == '__main__':

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Run under `rocprofv3 --pmc FETCH_SIZE` (and again with WRITE_SIZE): launches copy_mask_kernel,
 whose byte count is known exactly, so the counter reading per byte can be calibrated for the
 8-byte-per-lane coalesced pattern the step kernel uses for its masks (MI355X_MICROARCH.md, HBM)."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Build profiles/hbm_traffic.json from four `rocprofv3 --pmc` passes (MI355X_MICROARCH.md, HBM section:
 FETCH_SIZE and WRITE_SIZE in separate passes, KB units, gfx950 FETCH_SIZE correction by calibration):
 

@@ -1,12 +1,13 @@
-#!/usr/bin/env python3
-"""Diagnostic: build libpaintrl_hip.so with -DPRL_PHASE_TIMING into a scratch dir and print the
-share of wave cycles each phase of step_kernel takes on the bench workload.  Never used by the
-product or the tests; the timing build's run time itself is not meaningful (stamps add fences)."""
+"""Diagnostic: print the share of wave cycles each phase of step_kernel takes on the bench workload, from a
+library built with -DPRL_PHASE_TIMING (`python tools/build_variant.py phase -DPRL_PHASE_TIMING`, in the build
+container; this script builds nothing and spawns nothing):
+
+    PAINTRL_LIB=tools/_ab/phase.so python tools/phase_timing.py
+
+Never used by the product or the tests; the timing build's run time itself is not meaningful (stamps add fences)."""
 import ctypes as C
 import os
-import subprocess
 import sys
-import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -16,13 +17,6 @@ NAMES = ['load', 'ray', 'vertex', 'bary', 'math', 'ball', 'apply', 'obs-rest', '
 
 
 def main():
-    out = os.path.join(tempfile.mkdtemp(prefix='prl_phase_'), 'libpaintrl_hip.so')
-    extra = sys.argv[1:]
-    flags = [] if '--no-stamps' in extra else ['-DPRL_PHASE_TIMING']
-    extra = [e for e in extra if e != '--no-stamps']
-    subprocess.check_call([hb.hipcc()] + hb.FLAGS + flags + extra +
-                          ['-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, hb.SOURCE, hb.POLICY_SOURCE, '-o', out])
-    hb.LIBRARY = out                     # make paintrl_amd._lib load the diagnostic build
     import torch
     from paintrl_amd import _lib, part_tables, synth_parts
     from paintrl_amd.batched_env import BatchedPaintEnv
@@ -58,7 +52,6 @@ def main():
     print('wall per step: %.1f us' % ((time.perf_counter() - t0) / 300 * 1e6))
     per_wave = tot / (300 * n)
     print('cycles per env-step (wave lifetime, stamped build): %.0f' % per_wave)
-    print('rays %d, second-stage rays %d (%.1f %%), chunks visited per ray %.2f, MT evaluations per ray %.2f' % (buf[10], buf[11], 100.0 * buf[11] / max(buf[10], 1), buf[12] / max(buf[10], 1), buf[13] / max(buf[10], 1)))
     for name, v in zip(NAMES, buf):
         print('  %-13s %6.1f %%  %8.0f cyc/env-step' % (name, 100.0 * v / tot, v / (300 * n)))
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise rocprofv3 --pmc CSV output for step_kernel (mean per dispatch, and per wave)."""
 import collections
 import csv

@@ -1,0 +1,39 @@
+"""The bench workload, briefly, on whatever library PAINTRL_LIB points at (default: the product build).
+
+For use under the profiler -- it builds nothing and starts no child process:
+
+    PAINTRL_LIB=tools/_ab/x.so rocprofv3 --pmc SQ_INSTS_VALU ... -- python3 tools/run_workload.py [--obs-mode grid] [--steps 80]
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+from paintrl_amd import part_tables, synth_parts  # noqa: E402
+from paintrl_amd.batched_env import BatchedPaintEnv  # noqa: E402
+from paintrl_amd.device_tables import DeviceTables  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--obs-mode', default='section')
+    ap.add_argument('--steps', type=int, default=80)
+    ap.add_argument('--envs', type=int, default=4096)
+    a = ap.parse_args()
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
+    env = BatchedPaintEnv(DeviceTables(tables), a.envs, auto_reset=True, seed=5678, obs_mode=a.obs_mode,
+                          overlap_penalty=a.obs_mode == 'grid')
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234)
+    acts = torch.randint(0, 4, (a.steps, a.envs), generator=gen, device='cuda', dtype=torch.int32)
+    env.reset()
+    for k in range(a.steps):
+        env.step_raw(acts[k])
+    torch.cuda.synchronize()
+    env.close()
+
+
+if __name__ == '__main__':
+    main()

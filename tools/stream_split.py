@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Experiment: one batched step of N envs issued as S launches of N/S envs on S streams (envs are independent),
 so that a sub-batch's slowest wave only delays that sub-batch.  Prints batched steps/s (wall clock) per S."""
 import os
