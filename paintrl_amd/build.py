@@ -48,6 +48,7 @@ def build_library(force=False, verbose=False):
 # replaced by its general counterpart.  The product library never defines these macros.
 VARIANTS = {
     'force_per_shot_paint': ['-DPRL_FORCE_PER_SHOT_PAINT'],
+    'force_f64_paint_wide_band': ['-DPRL_WIDE_PAINT_BAND'],
     'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY'],
 }
 

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
-    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     PROF_BEGIN();
     load_masks<KW>(a, env, P.n_words, lane, painted, last);
@@ -132,16 +134,18 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         delta2 = dy * C.step_size;
         new_angle = delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2;
     }
-    const double angle_diff = fabs(new_angle - S.last_angle);
-    S.last_angle = new_angle;
     const int counter_before = S.terminate_counter;
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
     double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
     tcp_orn_norm(S.pose, S.quat, cur_norm);
+#ifdef PRL_X_UNI
 #pragma unroll
     for (int k = 0; k < 3; ++k) cur_norm[k] = uni_d(cur_norm[k]);
     const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
+#else
+    const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
+#endif
     // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
     int facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
     uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
@@ -179,8 +183,10 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+#ifdef PRL_X_UNI
             pos[k] = uni_d(pos[k]);
             orn[k] = uni_d(orn[k]);
+#endif
             cur_pose[k] = pos[k];
             cur_norm[k] = orn[k];
             S.pose[k] = pos[k];
@@ -261,6 +267,9 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
         }
     }
     STAMP(PH_BALL);
+    load_state_accumulators(state_rec, S);
+    const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
+    S.last_angle = new_angle;
     S.facet_hint = facet_hint;
     const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
     }
     STAMP(PH_OBS);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
-    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
+    store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
     PROF_END();
 }
@@ -436,6 +445,22 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         return fail(PRL_E_UNSUPPORTED, "part has %d samples; this build keeps at most %d per env in registers",
                     t->n_samples, 64 * 64 * KW_MAX);
     for (int k = 0; k < 3; ++k) UP(samp[k], t->sample_xyz[k], t->n_samples_pad);
+    {   // float copy of the sample positions for the conservative paint pre-filter (prl_paint.hpp)
+        if (!t->word_valid) return fail(PRL_E_INVALID, "null table pointer");
+        std::vector<float> f4((size_t)t->n_samples_pad * 4, 0.0f);
+        double amax = 0;
+        for (int i = 0; i < t->n_samples_pad; ++i) {
+            const bool real = (t->word_valid[i >> 6] >> (i & 63)) & 1;
+            for (int k = 0; k < 3; ++k) {
+                const double v = t->sample_xyz[k][i];
+                f4[(size_t)i * 4 + k] = (float)v;
+                if (real && std::fabs(v) > amax) amax = std::fabs(v);
+            }
+        }
+        if (!(amax < 1.0e6)) return fail(PRL_E_UNSUPPORTED, "sample coordinates beyond 1e6 (%g)", amax);
+        d.samp_absmax = amax;
+        UP(samp_f32, f4.data(), f4.size());
+    }
     UP(word_bbox, t->word_bbox, (size_t)d.n_words * 4);
     UP(word_valid, t->word_valid, d.n_words);
     UP(samp_rank, t->sample_rank, t->n_samples_pad);
@@ -455,8 +480,18 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     }
     d.n_vertices = t->n_vertices;
     if (d.n_vertices <= 0) return fail(PRL_E_INVALID, "part has no same-side vertices");
-    for (int k = 0; k < 3; ++k) UP(vert[k], t->vertex_xyz[k], d.n_vertices);
-    UP(vert_rank, t->vertex_rank, d.n_vertices);
+    {
+        for (int k = 0; k < 3; ++k)
+            if (!t->vertex_xyz[k]) return fail(PRL_E_INVALID, "null table pointer");
+        if (!t->vertex_rank) return fail(PRL_E_INVALID, "null table pointer");
+        std::vector<double> v4((size_t)d.n_vertices * 4, 0.0);
+        for (int i = 0; i < d.n_vertices; ++i) {
+            for (int k = 0; k < 3; ++k) v4[(size_t)i * 4 + k] = t->vertex_xyz[k][i];
+            const int32_t pair[2] = {t->vertex_rank[i], 0};
+            std::memcpy(&v4[(size_t)i * 4 + 3], pair, sizeof pair);
+        }
+        UP(vert4, v4.data(), v4.size());
+    }
     d.n_triangles = t->n_triangles;
     d.adj_width = t->adj_width;
     if (d.adj_width < 1 || d.adj_width > 64)

@@ -44,6 +44,8 @@ struct PartDev {
     gu64_p word_valid;
     gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
+    gfloat_p samp_f32;            // [n_samples_pad][4]: x y z 0 rounded to float (derived): the paint pre-filter
+    double samp_absmax;           // largest |coordinate| of a real sample: bounds the pre-filter's rounding error
     double sg_o1, sg_o2, sg_inv;
     int sg_nx, sg_ny;
     gint_p sg_start;
@@ -51,8 +53,8 @@ struct PartDev {
     gu64_p cell_mask;
     gint_p cell_count;
     int n_vertices;
-    gdouble_p vert[3];
-    gint_p vert_rank;
+    gdouble_p vert4;              // [n_vertices][4]: x y z | {i32 reference rank, 0}  (derived in part_fill: one record
+                                  // per candidate = two 16-byte loads instead of four loads from four tables)
     int adj_width;
     gint_p vadj;
     double vg_o1, vg_o2, vg_inv, vg_accept;

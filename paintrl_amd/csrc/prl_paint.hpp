@@ -61,6 +61,18 @@ __device__ void ball_query_wave(PartRef P, double radius, const double c[3], int
 // neighbourhood have no hits in any shot: painted is unchanged and their last-shot bits become 0.
 // The centres are written to LDS by the shot loop (a register array indexed by the runtime shot
 // number would live in scratch) and read back wave-uniformly here.
+//
+// Conservative float pre-filter.  The distance test `d^2 <= r^2` of bpw:569 is float64; here every candidate is
+// first tested in float32 on a float copy of the sample table (one 16-byte load per sample instead of three
+// 8-byte loads, and float32 vector operations issue at twice the float64 rate).  With M the largest |coordinate|
+// of a real sample, a centre within reach of a sample has |c| <= M + r, so rounding sample and centre to float
+// moves each coordinate by at most 2^-24 (M + r), each difference by at most 2^-22 (M + r) including its own
+// rounding, and the float d^2 -- three squares and two sums, each rounded -- differs from the exact one by less
+// than  band = 16 r 2^-23 (M + r) + 2^-20 r^2  for d near r (a factor > 4 above the worst case).  A sample
+// whose float d^2 is <= r^2 - band is inside, one above r^2 + band is outside, bit for bit as in float64; a word
+// with any sample in between (about one shot in a hundred) is recomputed in float64, the original code.
+// -DPRL_FORCE_F64_PAINT sends every word through the float64 branch; -DPRL_WIDE_PAINT_BAND widens the band
+// 4096-fold so that the mixed path runs constantly: both builds must reproduce the product's results exactly.
 struct ShotCentres {
     double c[PAINT_PER_ACTION][3];
 };
@@ -72,12 +84,22 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
                                   int &pixel_counter) {
     const double r2 = radius * radius;
     ShotCentres sc;
+    float cf[PAINT_PER_ACTION][3];
 #pragma unroll
     for (int k = 0; k < PAINT_PER_ACTION; ++k) {
         sc.c[k][0] = cen_lds[3 * k];
         sc.c[k][1] = cen_lds[3 * k + 1];
         sc.c[k][2] = cen_lds[3 * k + 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cf[k][q] = (float)sc.c[k][q];
     }
+    double band = 16.0 * radius * 1.1920928955078125e-07 * (P.samp_absmax + radius) + 9.5367431640625e-07 * r2;
+#ifdef PRL_WIDE_PAINT_BAND
+    band *= 4096.0;
+#endif
+    // thresholds rounded outward, so that the float comparisons are at least as cautious as the double ones
+    const float r2_in = nextafterf((float)(r2 - band), -INFINITY), r2_out = nextafterf((float)(r2 + band), INFINITY);
+    const f32x4 GAS *s4 = reinterpret_cast<const f32x4 GAS *>(P.samp_f32);
     int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
 #pragma unroll
     for (int k = 0; k < PAINT_PER_ACTION; ++k) {
@@ -111,17 +133,33 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
         for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
             WCNT(5, 1);
             const int s = (w << 6) + lane;
-            const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
+            const f32x4 pf = ldg(s4, s);
             // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only
             const bool in = s >= rb[r] && s < re[r];
             uint64_t b[PAINT_PER_ACTION];
-            uint64_t any = 0;
+            uint64_t any = 0, unsure = 0;
 #pragma unroll
             for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-                const double dx = x - sc.c[k][0], dy = y - sc.c[k][1], dz = z - sc.c[k][2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                b[k] = __ballot(in && dd <= r2);
+                const float dx = pf.x - cf[k][0], dy = pf.y - cf[k][1], dz = pf.z - cf[k][2];
+                const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                b[k] = __ballot(in && dd <= r2_in);
+                unsure |= b[k] ^ __ballot(in && dd <= r2_out);
                 any |= b[k];
+            }
+#ifdef PRL_FORCE_F64_PAINT
+            unsure = 1;
+#endif
+            if (unsure) {                           // some sample within rounding reach of the sphere: float64 decides
+                WCNT(6, 1);
+                const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
+                any = 0;
+#pragma unroll
+                for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+                    const double dx = x - sc.c[k][0], dy = y - sc.c[k][1], dz = z - sc.c[k][2];
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    b[k] = __ballot(in && dd <= r2);
+                    any |= b[k];
+                }
             }
             done_w = w;
             const int owner = w & 63, slot = w >> 6;

@@ -27,25 +27,25 @@ __device__ __forceinline__ Rows3 grid_rows3(gint_p start, int nx, int ny, int ic
     return out;
 }
 
+// One vertex record (x y z | rank) as two 16-byte loads.
+__device__ __forceinline__ void load_vertex(PartRef P, int v, double &x, double &y, double &z, int &rank) {
+    const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.vert4);
+    const f64x2 a = ldg(r, 2 * v), b = ldg(r, 2 * v + 1);
+    x = a.x;
+    y = a.y;
+    z = b.x;
+    rank = __double2loint(b.y);
+}
+
 __device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const double pt[3], int lane,
                                         double &best_d, int &best_rank, int &best_idx) {
-    for (int b = begin; b < end; b += 128) {                   // two batches per trip: eight loads in flight
+    for (int b = begin; b < end; b += 128) {                   // two batches per trip: four loads in flight
         const int v0 = b + lane, v1 = v0 + 64;
         const bool k0 = v0 < end, k1 = v1 < end;
         double x0 = 0, y0 = 0, z0 = 0, x1 = 0, y1 = 0, z1 = 0;
         int r0 = 0, r1 = 0;
-        if (k0) {
-            x0 = ldg(P.vert[0], v0);
-            y0 = ldg(P.vert[1], v0);
-            z0 = ldg(P.vert[2], v0);
-            r0 = ldg(P.vert_rank, v0);
-        }
-        if (k1) {
-            x1 = ldg(P.vert[0], v1);
-            y1 = ldg(P.vert[1], v1);
-            z1 = ldg(P.vert[2], v1);
-            r1 = ldg(P.vert_rank, v1);
-        }
+        if (k0) load_vertex(P, v0, x0, y0, z0, r0);
+        if (k1) load_vertex(P, v1, x1, y1, z1, r1);
         if (k0) {
             const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
@@ -104,9 +104,11 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
 #pragma unroll
                 for (int r = 1; r < 7; ++r)
                     if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
-                const double dx = ldg(P.vert[0], v) - pt[0], dy = ldg(P.vert[1], v) - pt[1], dz = ldg(P.vert[2], v) - pt[2];
+                double vx, vy, vz;
+                int rk;
+                load_vertex(P, v, vx, vy, vz, rk);
+                const double dx = vx - pt[0], dy = vy - pt[1], dz = vz - pt[2];
                 const double dd = (dx * dx + dy * dy) + dz * dz;
-                const int rk = ldg(P.vert_rank, v);
                 if (dd < best_d || (dd == best_d && rk < best_rank)) {
                     best_d = dd;
                     best_rank = rk;

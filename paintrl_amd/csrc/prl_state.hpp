@@ -38,6 +38,43 @@ __device__ __forceinline__ void store_state(double *dst, const EnvState &S, int 
     if (lane < PRL_STATE_DOUBLES) dst[lane] = v;
 }
 
+// The step kernel reads the record in two parts, so that the scalar registers of the episode accumulators are
+// not held across the five sub-shots: what the sub-shots need first ...
+constexpr int STATE_LIVE = 13;            // doubles 0..12 change every step; 13..15 only when an episode ends
+__device__ __forceinline__ void load_state_motion(const double *rec, EnvState &S) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S.pose[k] = rec[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S.quat[k] = rec[3 + k];
+    const int *ri = reinterpret_cast<const int *>(rec);
+    S.terminate = ri[20];
+    S.terminate_counter = ri[21];
+    S.last_on_part = ri[22];
+    S.step_counter = ri[23];
+    S.episode = (uint32_t)ri[24];
+    S.facet_hint = ri[25];
+}
+
+// ... and the accumulators once the shots are done.
+__device__ __forceinline__ void load_state_accumulators(const double *rec, EnvState &S) {
+    S.last_angle = rec[7];
+    S.total_reward = rec[8];
+    S.total_return = rec[9];
+}
+
+// Store doubles 0..12, and the last-episode statistics 13..15 only if they were set (`with_stats`, wave-uniform).
+__device__ __forceinline__ void store_state_live(double *dst, const EnvState &S, int lane, bool with_stats) {
+    const double *src = reinterpret_cast<const double *>(&S);
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < STATE_LIVE; ++k) v = lane == k ? src[k] : v;
+    if (with_stats) {
+#pragma unroll
+        for (int k = STATE_LIVE; k < PRL_STATE_DOUBLES; ++k) v = lane == k ? src[k] : v;
+    }
+    if (lane < (with_stats ? PRL_STATE_DOUBLES : STATE_LIVE)) dst[lane] = v;
+}
+
 __device__ __forceinline__ void reset_state(PartRef P, EnvState &S, int start) {   // rge:370-387, rob:366-372
     S.pose[0] = P.start_pos[3 * start];
     S.pose[1] = P.start_pos[3 * start + 1];
