@@ -194,11 +194,11 @@ def main():
     ap.add_argument('--actions', default='random', choices=['random', 'sweep'],
                     help="'sweep': every env follows an on-part serpentine with a random phase (SURVEY 8d item 2), so "
                          'episodes run long instead of ending after ~17 random steps')
-    ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch', 'fragment'],
+    ap.add_argument('--policy', default='random', choices=['random', 'mlp', 'mlp-torch', 'fragment', 'random-fragment'],
                     help="'mlp': actions from the 6-256-128-4 policy network on the same stream (config 4), one fused "
                          "kernel per step (prl_policy_act); 'mlp-torch': the same net in torch eager; 'fragment': "
                          'policy + env step for a whole 100-step rollout fragment in ONE persistent launch '
-                         '(prl_rollout_fragment)')
+                         "(prl_rollout_fragment); 'random-fragment': the same kernel fed the random action rows")
     ap.add_argument('--streams', type=int, default=1,
                     help='issue a batched step as S launches of envs/S envs on S streams (independent env groups: a '
                          "group's slowest wave then only delays that group); default 1 = one launch per step")
@@ -291,10 +291,11 @@ def main():
 
     policy = None
     fragment_runner = None
-    if args.policy == 'fragment':
+    if args.policy in ('fragment', 'random-fragment'):
         from paintrl_amd.rollout import MLPPolicy, FragmentRunner
         torch.manual_seed(1234)
-        fragment_runner = FragmentRunner(env, MLPPolicy(env.obs_dim, 4).to(device), fragment=FRAGMENT, seed=1234 + rank)
+        fragment_runner = FragmentRunner(env, MLPPolicy(env.obs_dim, 4).to(device), fragment=FRAGMENT, seed=1234 + rank,
+                                         given_actions=actions if args.policy == 'random-fragment' else None)
     elif args.policy != 'random':
         from paintrl_amd.rollout import MLPPolicy
         torch.manual_seed(1234)
@@ -416,9 +417,12 @@ def main():
         if args.policy == 'random':
             act_desc = 'on-part serpentine' if args.actions == 'sweep' else 'random'
         else:
-            act_desc = 'policy-MLP (6-256-128-4, fp32, %s)' % {
-                'mlp': 'fused HIP kernel', 'mlp-torch': 'torch eager',
-                'fragment': 'persistent rollout-fragment kernel, %d steps per launch' % FRAGMENT}[args.policy]
+            act_desc = {'mlp': 'policy-MLP (6-256-128-4, fp32, fused HIP kernel)',
+                        'mlp-torch': 'policy-MLP (6-256-128-4, fp32, torch eager)',
+                        'fragment': 'policy-MLP (6-256-128-4, fp32, inside the persistent rollout-fragment kernel, %d steps '
+                                    'per launch)' % FRAGMENT,
+                        'random-fragment': 'random (persistent rollout-fragment kernel reading the action rows, %d steps '
+                                           'per launch)' % FRAGMENT}[args.policy]
         import torch.distributed as dist
         dist_world = dist.get_world_size() if dist.is_initialized() else 1
         out = {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 1
+#define PRL_ABI_VERSION 2
 
 enum { PRL_OK = 0, PRL_E_INVALID = -1, PRL_E_HIP = -2, PRL_E_UNSUPPORTED = -3, PRL_E_NOMEM = -4 };
 enum { PRL_OBS_SECTION = 0, PRL_OBS_GRID = 1, PRL_OBS_SIMPLE = 2, PRL_OBS_DISCRETE = 3 };   /* rge:166-173 */
@@ -211,6 +211,22 @@ int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, co
                    uint32_t *rng_count /* or NULL if uniform is given */, uint64_t rng_seed, int32_t *action,
                    float *logp /* or NULL */, float *value /* or NULL */, float *logits /* or NULL, [N][n_actions] */,
                    void *stream);
+
+/* A whole rollout fragment -- what one RLlib rollout worker does between two learner updates
+ * (paint_ppo.py:170-195, sample_batch_size steps of policy forward + env.step) -- in ONE persistent launch:
+ * sixteen envs per workgroup, policy and step alternate inside the kernel with workgroup barriers only, env state
+ * in registers and coverage masks in LDS for the whole fragment.  The batch must have been created with auto_reset,
+ * discrete actions and PAINT_METHOD 'fast'.  All buffers are device pointers, row-major [t][env]:
+ *   obs        f64[n_steps + 1][N][obs_dim]   row 0: observations before the first step (input), row t + 1: after step t
+ *   final_obs  f64[n_steps][N][obs_dim] or NULL: terminal observation of envs that finished in step t
+ *   reward f64[n_steps][N], done u8[n_steps][N], info f64[n_steps][N][2]
+ *   action     i32[n_steps][N]: written when `weights` is given, otherwise READ (replay / scripted / random actions)
+ *   logp, value f32[n_steps][N], last_value f32[N] (value estimate of row n_steps), rng_count u32[N]: policy only
+ * With `weights` the rows are bit for bit what n_steps rounds of prl_policy_act (in-kernel sampling stream, same
+ * rng_count / rng_seed) + prl_batch_step produce, followed by one more prl_policy_act for last_value. */
+int prl_rollout_fragment(PrlBatch *batch, const PrlPolicyWeights *weights /* or NULL */, int n_steps, double *obs,
+                         double *final_obs, double *reward, uint8_t *done, double *info, int32_t *action, float *logp,
+                         float *value, float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream);
 
 #ifdef __cplusplus
 }

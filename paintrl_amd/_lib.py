@@ -77,6 +77,8 @@ SYMBOLS = {
     'prl_batch_set_pose': (C.c_int, [_vp, C.c_int, _dp, _dp]),
     'prl_batch_observe': (C.c_int, [_vp, _vp, _vp]),
     'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    'prl_rollout_fragment': (C.c_int, [_vp, C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, C.c_uint64, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_state': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_returns': (C.c_int, [_vp, _vp, _vp]),
@@ -84,7 +86,7 @@ SYMBOLS = {
     'prl_batch_timing_enable': (C.c_int, [_vp, C.c_int]),
     'prl_batch_timing_read': (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
@@ -106,14 +108,17 @@ def load():
         raise PaintRLError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc, gfx950). There is no CPU fallback.' % path)
     lib = C.CDLL(path)
+    lax = bool(os.environ.get('PAINTRL_LAX_SYMBOLS'))       # tools/ab_bench.py only: compare against older builds
     for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
+            if lax:
+                continue
             raise PaintRLError('%s does not export %s (stale build?)' % (path, name))
         fn.restype = res
         fn.argtypes = args
-    if lib.prl_abi_version() != ABI_VERSION:
+    if lib.prl_abi_version() != ABI_VERSION and not lax:
         raise PaintRLError('ABI version mismatch: library %d, binding %d' % (lib.prl_abi_version(), ABI_VERSION))
     cb, tb = C.c_int32(0), C.c_int32(0)
     lib.prl_struct_sizes(C.byref(cb), C.byref(tb))

@@ -133,6 +133,20 @@ class BatchedPaintEnv(object):
                                            C.c_void_p(info.data_ptr()), C.c_void_p(final_obs.data_ptr()), None,
                                            self._stream()), 'prl_batch_step')
 
+    def rollout_fragment(self, n_steps, obs, final_obs, reward, done_u8, info, action, weights=None, logp=None,
+                         value=None, last_value=None, rng_count=None, rng_seed=0):
+        """``n_steps`` steps in ONE persistent launch (``prl_rollout_fragment``): with ``weights`` (a
+        ``_lib.PrlPolicyWeights`` holding device pointers) the kernel runs the policy itself and WRITES ``action``
+        (int32 (T, N)), ``logp`` / ``value`` (float32 (T, N)) and ``last_value`` (float32 (N,)); without, it READS
+        ``action``.  ``obs`` is float64 (T + 1, N, obs_dim) with row 0 = the current observations; ``final_obs``
+        float64 (T, N, obs_dim) or None, ``reward`` float64 (T, N), ``done_u8`` uint8 (T, N), ``info`` float64
+        (T, N, 2).  Needs auto_reset=True, discrete actions, fast paint."""
+        p = self._ptr
+        _lib.check(self.lib.prl_rollout_fragment(
+            self._batch, C.byref(weights) if weights is not None else None, int(n_steps), p(obs), p(final_obs), p(reward),
+            p(done_u8), p(info), p(action), p(logp), p(value), p(last_value), p(rng_count), C.c_uint64(int(rng_seed)),
+            self._stream()), 'prl_rollout_fragment')
+
     # RLlib VectorEnv-style names
     def vector_reset(self):
         return self.reset()

@@ -45,6 +45,9 @@
 #include "prl_paint.hpp"
 #include "prl_observe.hpp"
 #include "prl_state.hpp"
+#include "prl_step.hpp"
+#define PRL_HAVE_F32X4
+#include "prl_policy.hpp"
 
 namespace {
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad));
+    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wave_lds<GENSEC>().cnt);
 }
 
 // ---------------------------------------------------------------- observation of the current state (rge:306-319)
@@ -78,260 +81,217 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
     const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     load_masks<KW>(a, env, P.n_words, lane, painted, last);
-    observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad));
+    observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wave_lds<GENSEC>().cnt);
 }
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
-// NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
+// One launch = one batched step: one wavefront per env, four envs per workgroup (prl_step.hpp holds the step).
 template <int KW, bool NORMAL, bool GENSEC>
-__global__ __launch_bounds__(256, 4) void step_kernel(StepArgs a) {
+__global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
+    // the one by-value argument, read in place (constant address space) wherever a field is needed
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
+    const WaveLds wl = wave_lds<GENSEC>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    const int od = obs_dim_of(C.obs_mode, C.obs_grad);
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     PROF_BEGIN();
-    load_masks<KW>(a, env, P.n_words, lane, painted, last);
-    STAMP(PH_LOAD);
-
-    // ---- action -> (delta1, delta2, turning angle)   rge:342-347, rob:390-398, 352-358
+    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;
-    if (C.action_mode == PRL_ACT_DISCRETE) {
-        int act = reinterpret_cast<const int *>(a.actions)[env];
-        act = act < 0 ? 0 : (act >= C.n_discrete ? C.n_discrete - 1 : act);
-        delta1 = C.act_delta1[act];
-        delta2 = C.act_delta2[act];
-        new_angle = C.act_angle[act];
-    } else {
-        const double *av = reinterpret_cast<const double *>(a.actions) + (size_t)env * C.action_dim;
-        double a0 = av[0], a1 = C.action_dim > 1 ? av[1] : 0.0;
-        if (!(-1 <= a0 && a0 <= 1)) a0 = a0 < -1 ? -1 : (a0 > 1 ? 1 : a0);
-        if (!(-1 <= a1 && a1 <= 1)) a1 = a1 < -1 ? -1 : (a1 > 1 ? 1 : a1);
-        double dx, dy;
-        if (C.action_dim == 1) {                       // rob:152-153
-            const double phi = (a0 + 1) * PI;
-            dx = 1 * cos(phi);
-            dy = 1 * sin(phi);
-        } else {                                       // rob:154-160
-            const double phi = atan2(a1, a0);
-            const double ax = fabs(a0), ay = fabs(a1);
-            if (ax == 0 && ay == 0) {
-                dx = ax;
-                dy = ay;
-            } else {
-                const double mx = ax > ay ? ax : ay;
-                dx = mx * cos(phi);
-                dy = mx * sin(phi);
-            }
-        }
-        delta1 = dx * C.step_size;
-        delta2 = dy * C.step_size;
-        new_angle = delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2;
-    }
-    const int counter_before = S.terminate_counter;
-
-    // ---- five chained sub-shots   rob:302-329 + 403-424
-    double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
-    tcp_orn_norm(S.pose, S.quat, cur_norm);
-#ifdef PRL_X_UNI
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cur_norm[k] = uni_d(cur_norm[k]);
-    const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
-#else
-    const double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
-#endif
-    // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
-    int facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
-    uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
-    uint32_t n_succeeded_l = 0;
-    __shared__ double s_centres[4][PAINT_PER_ACTION * 3];
-    double *cen = s_centres[threadIdx.x >> 6];
-    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-        // bpw:865-880 get_guided_point
-        double pt[3] = {cur_pose[0], cur_pose[1], cur_pose[2]};
-        const double delta_2 = d2 * P.lwr;
-        if (P.a1 == 0) pt[0] += d1; else if (P.a1 == 1) pt[1] += d1; else pt[2] += d1;
-        if (P.a2 == 0) pt[0] += delta_2; else if (P.a2 == 1) pt[1] += delta_2; else pt[2] += delta_2;
-        const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
-        double t, hit[3], pos[3], orn[3], quat[4];
-        STAMP(PH_MATH);
-        bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint) >= 0;
-        STAMP(PH_RAY);
-        double center[3];                                  // rob:277-278 shot centre
-        if (on) on = hook_point_wave(P, hit, lane, pos, orn, quat, center PROF_PASS);
-        if (!on) {
-            orn[0] = cur_norm[0];
-            orn[1] = cur_norm[1];
-            orn[2] = cur_norm[2];
-            pose_orn_quat(orn, quat);
-            transform_point(cur_pose, quat, d2, d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
-            transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, center);
-            if (S.last_on_part) {                                    // rob:292-300
-                S.last_on_part = 0;
-            } else {
-                S.terminate_counter += 1;
-                if (S.terminate_counter > NOT_ON_PART_TERMINATE) S.terminate = 1;
-            }
-        } else {
-            S.last_on_part = 1;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#ifdef PRL_X_UNI
-            pos[k] = uni_d(pos[k]);
-            orn[k] = uni_d(orn[k]);
-#endif
-            cur_pose[k] = pos[k];
-            cur_norm[k] = orn[k];
-            S.pose[k] = pos[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) S.quat[k] = quat[k];       // stays in vector registers: scalar registers are the scarce kind
-        // painting is deferred until all five centres are known
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (lane == 0) cen[3 * shot + k] = center[k];
-        STAMP(PH_MATH);
-        if constexpr (NORMAL) {
-            // rob:251-258, 280-285: one ray per cone beam from the tool to the beam's end point on the
-            // plane 0.2 ahead; bpw:562-566: every hit paints the sample nearest to it.  No hit at all:
-            // the reference returns early and leaves the last-shot set untouched.
-            uint64_t cur[KW_MAX] = {0, 0, 0, 0};
-            int beam_hits = 0;
-            // consecutive beams of the cone hit neighbouring facets: a beam starts from the facet the previous
-            // one hit (the first from the tool ray's facet); a wrong hint only costs the general search
-            int beam_hint = facet_hint;
-            for (int bm = 0; bm < P.n_beams; ++bm) {
-                double dst[3], bt, bh[3];
-                transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
-                if (ray_closest_wave(P, pos, dst, lane, bt, bh, beam_hint) < 0) continue;
-                ++beam_hits;
-                const int sidx = nearest_sample_wave(P, bh, lane);
-                if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
-            }
-            if (beam_hits > 0) {
-#pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    n_succeeded_l += __popcll(cur[k] & ~painted[k]);
-                    painted[k] |= cur[k];
-                    n_uni[k] |= cur[k] & ~last[k];
-                    last[k] = cur[k];
-                }
-            }
-        }
-    }
-    // lane 0 wrote the shot centres to LDS, every lane reads them below: order the two within the wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // bpw:568-577 fast_paint + _paint for the five shots
-    int succeeded = 0, pixel_counter = 0;
-    if constexpr (NORMAL) {
-        uint32_t pix_l = 0;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) pix_l += __popcll(n_uni[k]);
-        const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
-        succeeded = (int)(sums >> 32);
-        pixel_counter = (int)(sums & 0xffffffffu);
-    } else {
-        uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
-        if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
-#pragma unroll
-            for (int k = 0; k < KW; ++k) last[k] = new_last[k];
-        } else {                                   // general path: one ball query per shot
-            uint64_t uni[KW_MAX] = {0, 0, 0, 0};
-            uint32_t succeeded_l = 0, pix_l = 0;
-            for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-                uint64_t cur[KW_MAX] = {0, 0, 0, 0};
-                const double c3[3] = {cen[3 * shot], cen[3 * shot + 1], cen[3 * shot + 2]};
-                ball_query_wave<KW>(P, C.paint_radius, c3, lane, cur);
-#pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    succeeded_l += __popcll(cur[k] & ~painted[k]);
-                    painted[k] |= cur[k];
-                    uni[k] |= cur[k] & ~last[k];
-                    last[k] = cur[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
-            const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
-            succeeded = (int)(sums >> 32);
-            pixel_counter = (int)(sums & 0xffffffffu);
-        }
-    }
-    STAMP(PH_BALL);
-    load_state_accumulators(state_rec, S);
-    const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
-    S.last_angle = new_angle;
-    S.facet_hint = facet_hint;
-    const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
-    if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
-
-    // ---- reward, penalty, termination   rge:321-340, 289-304
-    const double rew = (double)succeeded / 100;
-    S.total_reward += rew;
-    double pen = 0.2;
-    if (C.overlap_penalty) pen += 0.1 * (1 - rate);
-    if (C.turning_penalty) pen += 0.1 * (angle_diff / PI);
-    const double actual = rew - pen;
-    S.step_counter += 1;
-    const double max_pts = C.max_possible_point[part_id & 7];
-    const int finished = max_pts > S.total_reward * 100 ? 0 : 1;
-    const double avg = S.total_reward / S.step_counter;
-    const double expected = max_pts / (C.expected_episode_len * 100);
-    int dn;
-    if (avg < expected && C.termination_mode != PRL_TERM_LATE &&
-        (C.termination_mode == PRL_TERM_EARLY || S.total_reward < C.switch_threshold * max_pts / 100))
-        dn = 1;
-    else
-        dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
-    if (!dn) S.total_return += actual;
-    STAMP(PH_APPLY);
-
-    const bool do_reset = dn && C.auto_reset;
-    double *obs_row = a.obs + (size_t)env * od;
-    double *term_row = do_reset ? (a.final_obs ? a.final_obs + (size_t)env * od : nullptr) : obs_row;
-    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row);
-    if (lane == 0) {
-        a.reward[env] = actual;
-        a.done[env] = (uint8_t)dn;
-        a.info[2 * (size_t)env] = rew;
-        a.info[2 * (size_t)env + 1] = pen;
-    }
-    if (dn) {                                   // episode statistics (the RCCL gather payload)
-        uint32_t cnt_l = 0;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) cnt_l += __popcll(painted[k]);
-        S.last_ep_painted = (int)wave_sum_u64(cnt_l);
-        S.last_ep_return = S.total_return;
-        S.last_ep_reward = S.total_reward;
-        S.last_ep_len = S.step_counter;
-    }
-    if (do_reset) {
-        int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
-        start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
-        reset_state(P, S, start);
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            painted[k] = 0;
-            last[k] = 0;
-        }
-        observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row);
-    }
-    STAMP(PH_OBS);
-    store_masks<KW>(a, env, P.n_words, lane, painted, last);
+    decode_action(C, a.actions, env, delta1, delta2, new_angle);
+    const int dn = step_env<KW, NORMAL, GENSEC, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                      new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
     PROF_END();
 }
 
+// ---------------------------------------------------------------- rollout fragment: policy + step, T times, one launch
+// The caller of the step in BASELINE.json configs 3-4 is a rollout worker (paint_ppo.py:170-195, fragments of
+// sample_batch_size = 100 steps).  One launch per step makes every step end with a grid-wide wait for the slowest
+// of all waves, and costs two launches plus an observation round trip through HBM.  Here a four-wave workgroup owns
+// four envs for the whole fragment:
+//     repeat T times:  stage the 4 observations in LDS -> the policy's three layers on the matrix cores (rows 4..15
+//                      of the 16-row MFMA tiles are zero) -> one draw per env -> workgroup barrier
+//                      -> every wave steps its env (prl_step.hpp) -> workgroup barrier
+// so a slow env delays its three neighbours, not the whole batch, there is nothing to launch, and while one
+// workgroup of a CU runs its policy on the matrix pipe the other three step their envs on the vector pipe.  The
+// coverage masks stay in LDS from the first step to the last (no mask traffic to HBM in between); trajectory rows
+// are written straight into the caller's [T][N] buffers, bit for bit what T rounds of prl_policy_act +
+// prl_batch_step write.  All workgroups must be resident together (4 per CU at 4096 envs): 23 KB of LDS each.
+struct FragmentArgs {
+    StepArgs s;                    // batch-level fields; the per-step output rows come from FragmentRows
+    PrlPolicyWeights w;
+    int T, use_policy;
+    double *obs;                   // [T + 1][N][od]: row 0 = the observations before the first step (input)
+    double *final_obs;             // [T][N][od]
+    double *reward, *info;         // [T][N], [T][N][2]
+    uint8_t *done;                 // [T][N]
+    int32_t *action;               // [T][N]: written (policy) or read (given actions)
+    float *logp, *value;           // [T][N], policy only
+    float *last_value;             // [N]: value estimate of the observation after the last step, policy only
+    uint32_t *rng_count;           // [N]
+    uint64_t rng_seed;
+};
+
+constexpr int FRAG_WAVES = 4;      // envs (= waves) per workgroup = real rows of the policy tiles
+
+// Output rows of step t of a fragment (see StepRows in prl_step.hpp).
+struct FragmentRows {
+    const FragmentArgs CAS *f;
+    int t, n, od;
+    __device__ __forceinline__ double *obs() const { return f->obs + (size_t)(t + 1) * n * od; }
+    __device__ __forceinline__ double *final_obs() const { return f->final_obs ? f->final_obs + (size_t)t * n * od : nullptr; }
+    __device__ __forceinline__ double *reward() const { return f->reward + (size_t)t * n; }
+    __device__ __forceinline__ double *info() const { return f->info + (size_t)t * n * 2; }
+    __device__ __forceinline__ uint8_t *done() const { return f->done + (size_t)t * n; }
+    __device__ __forceinline__ const int *start_idx() const { return nullptr; }
+};
+
+// The masks of one env in the workgroup's LDS (same word-to-lane mapping as GlobalMasks).
+struct LdsMasks {
+    uint64_t *painted, *last;
+    int n_words, lane;
+    template <int KW>
+    __device__ __forceinline__ void load(uint64_t p[KW_MAX], uint64_t l[KW_MAX]) const {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int w = lane + 64 * k;
+            const bool in = w < n_words;
+            p[k] = in ? painted[w] : 0;
+            l[k] = in ? last[w] : 0;
+        }
+    }
+    template <int KW>
+    __device__ __forceinline__ void store(const uint64_t p[KW_MAX], const uint64_t l[KW_MAX]) const {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int w = lane + 64 * k;
+            if (w < n_words) {
+                painted[w] = p[k];
+                last[w] = l[k];
+            }
+        }
+    }
+};
+
+// Every iteration of the fragment loop starts from this pointer: the compiler cannot tell that it is the same
+// one each time, so nothing derived from the kernel arguments or the part descriptor is hoisted out of the loop
+// and held in registers across both phases (that cost the first version of this kernel 950 spilled registers).
+__device__ __forceinline__ const FragmentArgs CAS *opaque(const FragmentArgs CAS *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// ... and the same for what is derived from the lane and wave numbers (per-lane offsets, lane predicates).
+__device__ __forceinline__ int opaque_v(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int opaque_s(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+template <int KW>
+__global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(FragmentArgs) {
+    extern __shared__ float lds[];
+    __shared__ int s_act[FRAG_WAVES];
+    const FragmentArgs CAS *f0 = (const FragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane0 = threadIdx.x & 63, wave0 = rfl((int)(threadIdx.x >> 6));
+    const int lane = lane0, wave = wave0, env0 = blockIdx.x * FRAG_WAVES, env = env0 + wave;
+    {   // coverage masks: HBM -> LDS, once
+        const FragmentArgs CAS &f = *opaque(f0);
+        const StepArgs CAS &a = f.s;
+        if (env < a.n_envs) {
+            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
+            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
+            uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
+            g.template load<KW>(p, l);
+            m.template store<KW>(p, l);
+        }
+    }
+    for (int t = 0;; ++t) {
+        const FragmentArgs CAS &f = *opaque(f0);
+        const StepArgs CAS &a = f.s;
+        const int lane = opaque_v(lane0), wave = opaque_s(wave0), tid = 64 * wave + lane;
+        const int env0 = opaque_s((int)blockIdx.x) * FRAG_WAVES, env = env0 + wave;
+        const int n_envs = a.n_envs, T = f.T;
+        const size_t n = (size_t)n_envs;
+        float *pol = lds + (size_t)FRAG_WAVES * 4 * a.mask_stride;       // policy area behind the masks (2 floats per u64)
+        if (f.use_policy) {
+            PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
+            W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
+            W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
+            const PolicyLds L = policy_lds_layout(W, FRAG_WAVES);
+            float *X = pol, *H1 = X + FRAG_WAVES * L.xs, *H2 = H1 + FRAG_WAVES * L.s1, *O = pol + L.o_off;
+            const double *obs_t = f.obs + (size_t)t * n * W.in_dim;
+            for (int i = tid; i < FRAG_WAVES * L.in_pad; i += 64 * FRAG_WAVES) {
+                const int row = i / L.in_pad, k = i - row * L.in_pad, e = env0 + row;
+                X[row * L.xs + k] = (e < n_envs && k < W.in_dim) ? (float)obs_t[(size_t)e * W.in_dim + k] : 0.0f;
+            }
+            __syncthreads();
+            policy_layers<FRAG_WAVES, FRAG_WAVES>(W, X, H1, H2, O, L.xs, L.s1, L.s2, L.in_pad, wave, lane);
+            if (tid < FRAG_WAVES && env0 + tid < n_envs) {
+                const int e = env0 + tid, A = W.n_actions;
+                const float u = policy_uniform(f.rng_seed, e, f.rng_count[e]++);
+                float o[16], lse;
+                const int act = policy_sample_row<FRAG_WAVES>(W, O, tid, u, o, lse);
+                if (t < T) {
+                    s_act[tid] = act;
+                    f.action[(size_t)t * n + e] = act;
+                    f.logp[(size_t)t * n + e] = o[act] - lse;
+                    f.value[(size_t)t * n + e] = o[A];
+                } else {
+                    f.last_value[e] = o[A];                           // the bootstrap value; its draw is discarded
+                }
+            }
+        } else if (t < T && tid < FRAG_WAVES && env0 + tid < n_envs) {
+            s_act[tid] = f.action[(size_t)t * n + env0 + tid];
+        }
+        if (t >= T) break;
+        __syncthreads();
+        if (env < n_envs) {                                           // exactly the per-step kernel's body
+            const int part_id = a.env_part ? a.env_part[env] : 0;
+            PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+            CfgRef C = *(const PrlConfig CAS *)a.cfg;
+            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
+            const LdsMasks masks{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
+            double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+            EnvState S;
+            load_state_motion(state_rec, S);
+            double delta1, delta2, new_angle;
+            decode_discrete_action(C, s_act[wave], delta1, delta2, new_angle);
+            const FragmentRows row{&f, t, n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
+            __shared__ int s_cand[FRAG_WAVES][64];
+            __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
+            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr};
+            const int dn = step_env<KW, false, false, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                            new_angle, row, wl);
+            store_state_live(state_rec, S, lane, dn != 0);
+        }
+        __syncthreads();            // the observations of step t are written (workgroup-scope fences included)
+    }
+    {   // coverage masks: LDS -> HBM
+        const FragmentArgs CAS &f = *opaque(f0);
+        const StepArgs CAS &a = f.s;
+        if (env < a.n_envs) {
+            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
+            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
+            uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
+            m.template load<KW>(p, l);
+            g.template store<KW>(p, l);
+        }
+    }
+}
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
 __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int n, const double *from,
                                                         const double *to, int *tri, double *frac, double *pos) {
@@ -342,7 +302,7 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int
     const double e[3] = {to[3 * r], to[3 * r + 1], to[3 * r + 2]};
     double t, hit[3] = {0, 0, 0};
     int hint = -1;
-    const int idx = ray_closest_wave(*(const PartDev CAS *)part, o, e, lane, t, hit, hint);
+    const int idx = ray_closest_wave(*(const PartDev CAS *)part, o, e, lane, t, hit, hint, wave_lds<false>().cand);
     if (lane == 0) {
         tri[r] = idx;
         frac[r] = t;
@@ -915,6 +875,60 @@ int prl_ray_batch(PrlPart *p, int n, const double *from, const double *to, int32
     if (n == 0) return PRL_OK;
     hipLaunchKernelGGL(ray_batch_kernel, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
                        p->dev_copy, n, from, to, tri, frac, pos);
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, double *obs, double *final_obs,
+                         double *reward, uint8_t *done, double *info, int32_t *action, float *logp, float *value,
+                         float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream) {
+    if (!b || !obs || !reward || !done || !info || !action || n_steps < 1)
+        return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
+    const PrlConfig &c = b->cfg;
+    if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
+    if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
+        return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for "
+                                       "section / discrete observations");
+    FragmentArgs f{};
+    f.s = base_args(b);
+    f.T = n_steps;
+    f.obs = obs;
+    f.final_obs = final_obs;
+    f.reward = reward;
+    f.done = done;
+    f.info = info;
+    f.action = action;
+    size_t lds_floats = 0;
+    if (w) {
+        if (!logp || !value || !last_value || !rng_count)
+            return fail(PRL_E_INVALID, "prl_rollout_fragment: the policy needs logp, value, last_value and rng_count");
+        if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3) return fail(PRL_E_INVALID, "null weights");
+        if (w->in_dim != obs_dim_of(c.obs_mode, c.obs_grad))
+            return fail(PRL_E_INVALID, "prl_rollout_fragment: policy input %d, observation %d", w->in_dim,
+                        obs_dim_of(c.obs_mode, c.obs_grad));
+        if (w->h1 < 16 || w->h1 % 16 || w->h2 < 16 || w->h2 % 16 || w->n_actions != c.n_discrete || w->n_actions > 15)
+            return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: hidden sizes multiples of 16, n_actions = n_discrete <= 15");
+        f.w = *w;
+        f.use_policy = 1;
+        f.logp = logp;
+        f.value = value;
+        f.last_value = last_value;
+        f.rng_count = rng_count;
+        f.rng_seed = rng_seed;
+        lds_floats = (size_t)policy_lds_layout(*w, FRAG_WAVES).floats;
+    }
+    const size_t lds = lds_floats * sizeof(float) + (size_t)FRAG_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
+    if (lds > 64 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
+    const dim3 grid((b->n_envs + FRAG_WAVES - 1) / FRAG_WAVES), block(64 * FRAG_WAVES);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void (*kernel)(FragmentArgs) = nullptr;
+    switch (b->kw) {
+    case 1: kernel = rollout_fragment_kernel<1>; break;
+    case 2: kernel = rollout_fragment_kernel<2>; break;
+    case 3: kernel = rollout_fragment_kernel<3>; break;
+    default: kernel = rollout_fragment_kernel<4>; break;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, f);
     HIP_TRY(hipGetLastError());
     return PRL_OK;
 }

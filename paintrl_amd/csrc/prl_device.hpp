@@ -6,6 +6,7 @@
 namespace {
 
 
+constexpr int MAX_WAVES_PER_WG = 4;              // per-wave LDS scratch rows: every kernel here runs four waves per workgroup
 constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
 constexpr double STEP_SIZE = 0.051;             // bpw:43
@@ -114,6 +115,25 @@ __device__ __forceinline__ T ldg(const T GAS *p, int i) {
 
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Per-wave LDS scratch of a workgroup (MAX_WAVES_PER_WG waves): the ray's candidate list, the five shot centres of
+// a step, the sector counters of the atan2 observation.  The rows are picked ONCE, at kernel entry, from the wave
+// index held in a scalar register: indexed with `threadIdx.x >> 6` at the point of use the compiler keeps
+// threadIdx.x and 64-bit generic row addresses alive in vector registers through the whole kernel -- and, at
+// this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
+struct WaveLds {
+    int *cand;          // [64]
+    double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
+    int *cnt;           // [128], only with the atan2-sector observation
+};
+template <bool GENSEC>
+__device__ __forceinline__ WaveLds wave_lds() {
+    __shared__ int s_cand[MAX_WAVES_PER_WG][64];
+    __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
+    __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
+    const int w = rfl((int)(threadIdx.x >> 6));
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0]};
+}
 
 __device__ __forceinline__ double bcast_d(double v, int src) {
     src = rfl(src);

@@ -77,7 +77,7 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
 // its registers or code.
 template <int KW, bool GENSEC>
 __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
-                                 const uint64_t painted[KW_MAX], int lane, double *out) {
+                                 const uint64_t painted[KW_MAX], int lane, double *out, int *cnt_lds) {
     // bpw:965-978 get_normalized_pose
     const double r = C.paint_radius;
     const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
@@ -128,8 +128,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         return;
     }
     if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
-        __shared__ int s_cnt[4][128];
-        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, s_cnt[threadIdx.x >> 6], out);
+        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, cnt_lds, out);
         if (lane == 0) {
             if (mode == PRL_OBS_SECTION) {
                 out[C.obs_grad] = np0;

@@ -73,9 +73,6 @@ __device__ void ball_query_wave(PartRef P, double radius, const double c[3], int
 // with any sample in between (about one shot in a hundred) is recomputed in float64, the original code.
 // -DPRL_FORCE_F64_PAINT sends every word through the float64 branch; -DPRL_WIDE_PAINT_BAND widens the band
 // 4096-fold so that the mixed path runs constantly: both builds must reproduce the product's results exactly.
-struct ShotCentres {
-    double c[PAINT_PER_ACTION][3];
-};
 
 template <int KW>
 __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane,
@@ -83,15 +80,22 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
                                   const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
                                   int &pixel_counter) {
     const double r2 = radius * radius;
-    ShotCentres sc;
+    // the float64 centres are only needed for the cell ranges and by the rare float64 branch, which reads them
+    // from LDS again: fifteen doubles held across the word loop would be thirty vector registers
     float cf[PAINT_PER_ACTION][3];
+    int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
 #pragma unroll
     for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-        sc.c[k][0] = cen_lds[3 * k];
-        sc.c[k][1] = cen_lds[3 * k + 1];
-        sc.c[k][2] = cen_lds[3 * k + 2];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) cf[k][q] = (float)sc.c[k][q];
+        const double c0 = cen_lds[3 * k], c1 = cen_lds[3 * k + 1], c2 = cen_lds[3 * k + 2];
+        cf[k][0] = (float)c0;
+        cf[k][1] = (float)c1;
+        cf[k][2] = (float)c2;
+        const int icx = cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx);
+        const int icy = cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny);
+        cx_lo = icx < cx_lo ? icx : cx_lo;
+        cx_hi = icx > cx_hi ? icx : cx_hi;
+        cy_lo = icy < cy_lo ? icy : cy_lo;
+        cy_hi = icy > cy_hi ? icy : cy_hi;
     }
     double band = 16.0 * radius * 1.1920928955078125e-07 * (P.samp_absmax + radius) + 9.5367431640625e-07 * r2;
 #ifdef PRL_WIDE_PAINT_BAND
@@ -100,16 +104,6 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
     // thresholds rounded outward, so that the float comparisons are at least as cautious as the double ones
     const float r2_in = nextafterf((float)(r2 - band), -INFINITY), r2_out = nextafterf((float)(r2 + band), INFINITY);
     const f32x4 GAS *s4 = reinterpret_cast<const f32x4 GAS *>(P.samp_f32);
-    int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-        const int icx = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a1), P.sg_o1, P.sg_inv, P.sg_nx);
-        const int icy = cell_coord(sel3(sc.c[k][0], sc.c[k][1], sc.c[k][2], P.a2), P.sg_o2, P.sg_inv, P.sg_ny);
-        cx_lo = icx < cx_lo ? icx : cx_lo;
-        cx_hi = icx > cx_hi ? icx : cx_hi;
-        cy_lo = icy < cy_lo ? icy : cy_lo;
-        cy_hi = icy > cy_hi ? icy : cy_hi;
-    }
 #ifdef PRL_FORCE_PER_SHOT_PAINT                     // diagnostic build: exercise the general path in the parity tests
     return false;
 #endif
@@ -155,7 +149,7 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
                 any = 0;
 #pragma unroll
                 for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-                    const double dx = x - sc.c[k][0], dy = y - sc.c[k][1], dz = z - sc.c[k][2];
+                    const double dx = x - cen_lds[3 * k], dy = y - cen_lds[3 * k + 1], dz = z - cen_lds[3 * k + 2];
                     const double dd = (dx * dx + dy * dy) + dz * dz;
                     b[k] = __ballot(in && dd <= r2);
                     any |= b[k];

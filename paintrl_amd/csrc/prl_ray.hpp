@@ -129,10 +129,9 @@ __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double
 // vertex-neighbourhood of `hint` holds a valid hit whose facet is ENTERED (orient * det > 0), the
 // closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
 // hit there, an exit hit, a facet without a neighbour list) takes the general search below.
+// `cand`: this wave's 64-int LDS row (WaveLds::cand).
 __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3], int lane, double &t_out,
-                                double hit[3], int &hint) {
-    __shared__ int s_cand[4][64];
-    int *cand = s_cand[threadIdx.x >> 6];
+                                double hit[3], int &hint, int *cand) {
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
     double best_t = INFINITY, best_det = 0, tmin = INFINITY;
     int best_r = 0x7fffffff, best_i = -1, win = -1;

@@ -207,8 +207,9 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
 // Also returns what the chosen triangle's normal implies for the tool: the quaternion of rob:93-100 and the shot
 // centre of rob:277-278 (pose + R(quat)(0, 0, 0.1)), read from the triangle record's precomputed tail.
+// `tri` receives the chosen triangle (index into the triangle records).
 __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3], double quat[4],
-                                double center[3] PROF_ARG) {
+                                double center[3], int &tri PROF_ARG) {
     const int vidx = nearest_vertex_wave(P, pt, lane);
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;
@@ -254,6 +255,7 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     }
     // the chosen triangle's normal, quaternion and centre offset: one wave-uniform read of its record's tail
     const int tj = __builtin_amdgcn_readlane(ti, rfl(j));
+    tri = tj;
     const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)tj * (TRI_REC / 2);
     const f64x2 t6 = rj[6], t7 = rj[7], t8 = rj[8], t9 = rj[9], t10 = rj[10], t11 = rj[11];
     n0 = t6.y;

@@ -1,0 +1,316 @@
+// prl_step.hpp -- one PaintGymEnv.step() of one environment by one wavefront (rge:349-368), as a device function
+// shared by the per-step kernel (step_kernel) and the persistent rollout-fragment kernel (rollout_fragment_kernel).
+// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that file for the
+// overall design.  Compile with -ffp-contract=off.
+#pragma once
+
+namespace {
+
+// rge:342-347 _preprocess_action + rob:390-398 + rob:352-358: action -> (delta axis 1, delta axis 2, turning angle)
+__device__ __forceinline__ void decode_discrete_action(CfgRef C, int act, double &delta1, double &delta2, double &new_angle) {
+    act = rfl(act);                                  // wave-uniform: the table is read with scalar loads
+    act = act < 0 ? 0 : (act >= C.n_discrete ? C.n_discrete - 1 : act);
+    delta1 = C.act_delta1[act];
+    delta2 = C.act_delta2[act];
+    new_angle = C.act_angle[act];
+}
+
+__device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int env, double &delta1, double &delta2,
+                                              double &new_angle) {
+    if (C.action_mode == PRL_ACT_DISCRETE) {
+        decode_discrete_action(C, reinterpret_cast<const int *>(actions)[env], delta1, delta2, new_angle);
+    } else {
+        const double *av = reinterpret_cast<const double *>(actions) + (size_t)env * C.action_dim;
+        double a0 = av[0], a1 = C.action_dim > 1 ? av[1] : 0.0;
+        if (!(-1 <= a0 && a0 <= 1)) a0 = a0 < -1 ? -1 : (a0 > 1 ? 1 : a0);
+        if (!(-1 <= a1 && a1 <= 1)) a1 = a1 < -1 ? -1 : (a1 > 1 ? 1 : a1);
+        double dx, dy;
+        if (C.action_dim == 1) {                       // rob:152-153
+            const double phi = (a0 + 1) * PI;
+            dx = 1 * cos(phi);
+            dy = 1 * sin(phi);
+        } else {                                       // rob:154-160
+            const double phi = atan2(a1, a0);
+            const double ax = fabs(a0), ay = fabs(a1);
+            if (ax == 0 && ay == 0) {
+                dx = ax;
+                dy = ay;
+            } else {
+                const double mx = ax > ay ? ax : ay;
+                dx = mx * cos(phi);
+                dy = mx * sin(phi);
+            }
+        }
+        delta1 = uni_d(dx * C.step_size);
+        delta2 = uni_d(dy * C.step_size);
+        new_angle = uni_d(delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2);
+    }
+}
+
+// Advances env `env` by one step.  In: the motion part of S (load_state_motion) and the coverage masks in
+// registers; with LATE_ACC the episode accumulators are read from `state_rec` only after the five sub-shots (the
+// per-step kernel: their scalar registers are then free during the shots), otherwise S is complete on entry (the
+// fragment kernel keeps it in registers from step to step).  Out: S and the masks advanced (reset if the episode
+// ended and C.auto_reset), the observation in row `env` of a.obs (the post-reset one after an auto-reset, the
+// terminal one then goes to a.final_obs if that is not null), reward / done / info rows through lane 0; the
+// output addresses are formed where they are used, so that they hold no registers during the shots.  Returns done.
+// NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
+//
+// The coverage masks are not touched by the five sub-shots of the ball-query paint method, so they are fetched
+// through `masks` (GlobalMasks: HBM, LdsMasks: the fragment kernel's LDS copy) only when painting starts and put
+// back after the observation: twelve vector registers less during the shots.
+//
+// `a` (RowIO) names this step's output rows: obs / final_obs / reward / info / done / start_idx members that are
+// evaluated where they are used.  Both implementations read the kernel arguments through the constant address
+// space at that point; handing the kernel's by-value argument struct down by reference instead makes the compiler
+// copy all of it into registers at kernel entry.
+template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, typename MaskIO, typename RowIO>
+__device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
+                                        const double *state_rec, const MaskIO &masks, double delta1, double delta2,
+                                        double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
+    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    if constexpr (NORMAL) masks.template load<KW>(painted, last);
+    const int counter_before = S.terminate_counter;
+
+    // ---- five chained sub-shots   rob:302-329 + 403-424
+    double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
+    tcp_orn_norm(S.pose, S.quat, cur_norm);
+    // pose and normal stay in vector registers (wave-uniform values): scalar registers are
+    // the scarce kind in this kernel, and every consumer is a vector instruction anyway
+    // (the per-shot deltas and the turning angle are read rarely: those three do live in scalar registers)
+    const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
+    new_angle = uni_d(new_angle);
+    // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
+    int facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
+    // The tool quaternion is a function of the tool normal alone (rob:93-100), so it is not carried through the
+    // shots (eight vector registers): after the last one it is read from the record of the triangle that shot
+    // hooked to, or recomputed from the normal after a miss -- the same arithmetic either way.
+    int last_tri = -1;
+    uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
+    uint32_t n_succeeded_l = 0;
+    double *cen = wl.cen;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        // bpw:865-880 get_guided_point
+        double pt[3] = {cur_pose[0], cur_pose[1], cur_pose[2]};
+        const double delta_2 = d2 * P.lwr;
+        if (P.a1 == 0) pt[0] += d1; else if (P.a1 == 1) pt[1] += d1; else pt[2] += d1;
+        if (P.a2 == 0) pt[0] += delta_2; else if (P.a2 == 1) pt[1] += delta_2; else pt[2] += delta_2;
+        const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
+        double t, hit[3], pos[3], orn[3], quat[4];
+        STAMP(PH_MATH);
+        bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint, wl.cand) >= 0;
+        STAMP(PH_RAY);
+        double center[3];                                  // rob:277-278 shot centre
+        if (on) on = hook_point_wave(P, hit, lane, pos, orn, quat, center, last_tri PROF_PASS);
+        if (!on) {
+            last_tri = -1;
+            orn[0] = cur_norm[0];
+            orn[1] = cur_norm[1];
+            orn[2] = cur_norm[2];
+            pose_orn_quat(orn, quat);
+            transform_point(cur_pose, quat, d2, d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
+            transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, center);
+            if (S.last_on_part) {                                    // rob:292-300
+                S.last_on_part = 0;
+            } else {
+                S.terminate_counter += 1;
+                if (S.terminate_counter > NOT_ON_PART_TERMINATE) S.terminate = 1;
+            }
+        } else {
+            S.last_on_part = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cur_pose[k] = pos[k];
+            cur_norm[k] = orn[k];
+            S.pose[k] = pos[k];
+        }
+        // painting is deferred until all five centres are known
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane == 0) cen[3 * shot + k] = center[k];
+        STAMP(PH_MATH);
+        if constexpr (NORMAL) {
+            // rob:251-258, 280-285: one ray per cone beam from the tool to the beam's end point on the
+            // plane 0.2 ahead; bpw:562-566: every hit paints the sample nearest to it.  No hit at all:
+            // the reference returns early and leaves the last-shot set untouched.
+            uint64_t cur[KW_MAX] = {0, 0, 0, 0};
+            int beam_hits = 0;
+            // consecutive beams of the cone hit neighbouring facets: a beam starts from the facet the previous
+            // one hit (the first from the tool ray's facet); a wrong hint only costs the general search
+            int beam_hint = facet_hint;
+            for (int bm = 0; bm < P.n_beams; ++bm) {
+                double dst[3], bt, bh[3];
+                transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
+                if (ray_closest_wave(P, pos, dst, lane, bt, bh, beam_hint, wl.cand) < 0) continue;
+                ++beam_hits;
+                const int sidx = nearest_sample_wave(P, bh, lane);
+                if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
+            }
+            if (beam_hits > 0) {
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    n_succeeded_l += __popcll(cur[k] & ~painted[k]);
+                    painted[k] |= cur[k];
+                    n_uni[k] |= cur[k] & ~last[k];
+                    last[k] = cur[k];
+                }
+            }
+        }
+    }
+    // lane 0 wrote the shot centres to LDS, every lane reads them below: order the two within the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (last_tri >= 0) {
+        const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)last_tri * (TRI_REC / 2);
+        const f64x2 qa = rj[8], qb = rj[9];
+        S.quat[0] = qa.x;
+        S.quat[1] = qa.y;
+        S.quat[2] = qb.x;
+        S.quat[3] = qb.y;
+    } else {
+        pose_orn_quat(cur_norm, S.quat);
+    }
+    if constexpr (!NORMAL) masks.template load<KW>(painted, last);
+    STAMP(PH_LOAD);
+    // bpw:568-577 fast_paint + _paint for the five shots
+    int succeeded = 0, pixel_counter = 0;
+    if constexpr (NORMAL) {
+        uint32_t pix_l = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) pix_l += __popcll(n_uni[k]);
+        const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
+        succeeded = (int)(sums >> 32);
+        pixel_counter = (int)(sums & 0xffffffffu);
+    } else {
+        uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+        if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) last[k] = new_last[k];
+        } else {                                   // general path: one ball query per shot
+            uint64_t uni[KW_MAX] = {0, 0, 0, 0};
+            uint32_t succeeded_l = 0, pix_l = 0;
+            for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+                uint64_t cur[KW_MAX] = {0, 0, 0, 0};
+                const double c3[3] = {cen[3 * shot], cen[3 * shot + 1], cen[3 * shot + 2]};
+                ball_query_wave<KW>(P, C.paint_radius, c3, lane, cur);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    succeeded_l += __popcll(cur[k] & ~painted[k]);
+                    painted[k] |= cur[k];
+                    uni[k] |= cur[k] & ~last[k];
+                    last[k] = cur[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
+            const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
+            succeeded = (int)(sums >> 32);
+            pixel_counter = (int)(sums & 0xffffffffu);
+        }
+    }
+    STAMP(PH_BALL);
+    if constexpr (LATE_ACC) load_state_accumulators(state_rec, S);
+    const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
+    S.last_angle = new_angle;
+    S.facet_hint = facet_hint;
+    const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
+    if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
+
+    // ---- reward, penalty, termination   rge:321-340, 289-304
+    const double rew = (double)succeeded / 100;
+    S.total_reward += rew;
+    double pen = 0.2;
+    if (C.overlap_penalty) pen += 0.1 * (1 - rate);
+    if (C.turning_penalty) pen += 0.1 * (angle_diff / PI);
+    const double actual = rew - pen;
+    S.step_counter += 1;
+    const double max_pts = C.max_possible_point[part_id & 7];
+    const int finished = max_pts > S.total_reward * 100 ? 0 : 1;
+    const double avg = S.total_reward / S.step_counter;
+    const double expected = max_pts / (C.expected_episode_len * 100);
+    int dn;
+    if (avg < expected && C.termination_mode != PRL_TERM_LATE &&
+        (C.termination_mode == PRL_TERM_EARLY || S.total_reward < C.switch_threshold * max_pts / 100))
+        dn = 1;
+    else
+        dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
+    if (!dn) S.total_return += actual;
+    STAMP(PH_APPLY);
+
+    const bool do_reset = dn && C.auto_reset;
+    const int od = obs_dim_of(C.obs_mode, C.obs_grad);
+    double *obs_row = a.obs() + (size_t)env * od;
+    double *term_row = do_reset ? (a.final_obs() ? a.final_obs() + (size_t)env * od : nullptr) : obs_row;
+    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row, wl.cnt);
+    if (lane == 0) {
+        a.reward()[env] = actual;
+        a.done()[env] = (uint8_t)dn;
+        a.info()[2 * (size_t)env] = rew;
+        a.info()[2 * (size_t)env + 1] = pen;
+    }
+    if (dn) {                                   // episode statistics (the RCCL gather payload)
+        uint32_t cnt_l = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) cnt_l += __popcll(painted[k]);
+        S.last_ep_painted = (int)wave_sum_u64(cnt_l);
+        S.last_ep_return = S.total_return;
+        S.last_ep_reward = S.total_reward;
+        S.last_ep_len = S.step_counter;
+    }
+    if (do_reset) {
+        int start = a.start_idx() ? a.start_idx()[env] : draw_start(C.seed, env, S.episode, P.n_start);
+        start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
+        reset_state(P, S, start);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            painted[k] = 0;
+            last[k] = 0;
+        }
+        observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
+    }
+    STAMP(PH_OBS);
+    masks.template store<KW>(painted, last);
+    return dn;
+}
+
+// Output rows of the per-step kernel: the launch's StepArgs, read from the kernel-argument segment when used.
+struct StepRows {
+    const StepArgs CAS *k;
+    __device__ __forceinline__ double *obs() const { return k->obs; }
+    __device__ __forceinline__ double *final_obs() const { return k->final_obs; }
+    __device__ __forceinline__ double *reward() const { return k->reward; }
+    __device__ __forceinline__ double *info() const { return k->info; }
+    __device__ __forceinline__ uint8_t *done() const { return k->done; }
+    __device__ __forceinline__ const int *start_idx() const { return k->start_idx; }
+};
+
+// The masks of env `env` in HBM: word w of a mask is read / written by lane w & 63 into slot w >> 6.
+struct GlobalMasks {
+    uint64_t *painted, *last;     // rows of this env
+    int n_words, lane;
+    template <int KW>
+    __device__ __forceinline__ void load(uint64_t p[KW_MAX], uint64_t l[KW_MAX]) const {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const uint32_t w = lane + 64 * k;
+            const bool in = (int)w < n_words;
+            p[k] = in ? painted[w] : 0;
+            l[k] = in ? last[w] : 0;
+        }
+    }
+    template <int KW>
+    __device__ __forceinline__ void store(const uint64_t p[KW_MAX], const uint64_t l[KW_MAX]) const {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const uint32_t w = lane + 64 * k;
+            if ((int)w < n_words) {
+                painted[w] = p[k];
+                last[w] = l[k];
+            }
+        }
+    }
+};
+
+}  // namespace

@@ -50,7 +50,12 @@ class RolloutWorker(object):
     observations, rewards, done flags, info and terminal observations into theirs.  The float32 views RLlib
     expects are made once per fragment."""
 
-    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True):
+    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True, persistent=False):
+        """``persistent=True`` (with the fused policy): a whole fragment is ONE launch of the persistent rollout
+        kernel (``prl_rollout_fragment``) instead of 2 T launches; the buffers receive the same bits."""
+        self.persistent = bool(persistent)
+        if self.persistent and not fused:
+            raise ValueError('persistent=True needs the fused policy')
         if not env.cfg.auto_reset:
             raise ValueError('RolloutWorker needs BatchedPaintEnv(auto_reset=True)')
         self.env, self.policy, self.T = env, policy, int(fragment)
@@ -92,7 +97,14 @@ class RolloutWorker(object):
     def collect(self):
         """One fragment.  Returns (batch dict, last value estimates, gathered episode returns)."""
         b, raw, env, T = self.buf, self.raw, self.env, self.T
-        if self.fused is not None:
+        if self.persistent:
+            fp = self.fused
+            if fp._rng_count is None or fp._rng_count.shape[0] != env.n_envs:
+                fp._rng_count = torch.zeros(env.n_envs, dtype=torch.int32, device=env.device)
+            env.rollout_fragment(T, raw['obs'], raw['final_obs'], raw['rewards'], raw['dones'], raw['infos'], b['actions'],
+                                 weights=fp._w, logp=b['action_logp'], value=b['vf_preds'], last_value=self._last_value,
+                                 rng_count=fp._rng_count, rng_seed=fp.seed)
+        elif self.fused is not None:
             for t in range(T):
                 self.fused.act_into(raw['obs'][t], b['actions'][t], b['action_logp'][t], b['vf_preds'][t])
                 env.step_into(b['actions'][t], raw['obs'][t + 1], raw['rewards'][t], raw['dones'][t], raw['infos'][t],
@@ -118,6 +130,44 @@ class RolloutWorker(object):
         self.steps_done += T
         returns = pdist.gather_returns(env.episode_returns())       # once per fragment, RCCL when world > 1
         return b, self._last_value.clone(), returns
+
+
+class FragmentRunner(object):
+    """bench.py --policy fragment: policy + env for up to ``fragment`` steps per launch, rows into a ring of
+    trajectory buffers (what RolloutWorker(persistent=True) does, without the float32 SampleBatch views)."""
+
+    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, given_actions=None):
+        """``given_actions``: int32 (steps, N) device tensor; the kernel then reads its action rows from it (in order,
+        ``fragment`` rows per full launch) instead of running the policy."""
+        from .policy import FusedPolicy
+        self.env, self.T = env, int(fragment)
+        self.given, self.cursor = given_actions, 0
+        self.fused = FusedPolicy(policy, seed=seed)
+        dev, n, od, T = env.device, env.n_envs, env.obs_dim, self.T
+        f64, f32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.float32, device=dev)
+        self.obs = torch.zeros((T + 1, n, od), **f64)
+        self.final_obs = torch.zeros((T, n, od), **f64)
+        self.reward = torch.zeros((T, n), **f64)
+        self.info = torch.zeros((T, n, 2), **f64)
+        self.done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+        self.action = torch.zeros((T, n), dtype=torch.int32, device=dev)
+        self.logp, self.value = torch.zeros((T, n), **f32), torch.zeros((T, n), **f32)
+        self.last_value = torch.zeros(n, **f32)
+        self.rng_count = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.obs[0].copy_(env.obs)
+
+    def run(self, n_steps):
+        """``n_steps`` <= fragment steps in one launch; the next call continues from the last observation."""
+        n_steps = int(n_steps)
+        if self.given is not None:
+            rows = self.given[self.cursor:self.cursor + n_steps]
+            self.cursor += n_steps
+            self.env.rollout_fragment(n_steps, self.obs, self.final_obs, self.reward, self.done, self.info, rows)
+        else:
+            self.env.rollout_fragment(n_steps, self.obs, self.final_obs, self.reward, self.done, self.info, self.action,
+                                      weights=self.fused._w, logp=self.logp, value=self.value, last_value=self.last_value,
+                                      rng_count=self.rng_count, rng_seed=self.fused.seed)
+        self.obs[0].copy_(self.obs[n_steps])
 
 
 def gae(batch, last_value, gamma=0.99, lam=0.95):

@@ -85,3 +85,86 @@ def test_rollout_buffers_replay_through_the_oracle():
         alive = cont
     assert checked > n * 8
     env.close()
+
+
+def _fragment_buffers(env, T):
+    import torch
+    dev, n, od = env.device, env.n_envs, env.obs_dim
+    f64, f32 = dict(dtype=torch.float64, device=dev), dict(dtype=torch.float32, device=dev)
+    return dict(obs=torch.zeros((T + 1, n, od), **f64), final_obs=torch.zeros((T, n, od), **f64),
+                reward=torch.zeros((T, n), **f64), done=torch.zeros((T, n), dtype=torch.uint8, device=dev),
+                info=torch.zeros((T, n, 2), **f64), action=torch.zeros((T, n), dtype=torch.int32, device=dev),
+                logp=torch.zeros((T, n), **f32), value=torch.zeros((T, n), **f32), last_value=torch.zeros(n, **f32))
+
+
+@pytest.mark.parametrize('part,obs_mode,n', [('door_test', 'section', 203), ('square', 'grid', 64), ('door_test', 'grid', 130)])
+def test_persistent_fragment_with_given_actions_equals_step_by_step(part, obs_mode, n):
+    """prl_rollout_fragment without a policy (it reads the action rows): every trajectory row and the final env
+    state equal T launches of prl_batch_step, including envs that finish and restart inside the fragment, batch
+    sizes that are not a multiple of the workgroup's four envs, and both mask widths (3 and 4 words per lane)."""
+    import torch
+    from conftest import start_points_for, synthetic_tables
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = synthetic_tables(part)
+    sp = start_points_for(tables, 'all')
+    T = 37
+    kw = dict(auto_reset=True, seed=21, obs_mode=obs_mode, overlap_penalty=obs_mode == 'grid',
+              max_possible_point=14350 if part == 'square' else 9148)
+    env_a = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
+    env_b = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
+    start = np.random.RandomState(1).randint(0, len(sp), size=n)
+    o0 = env_a.reset(start_idx=start).clone()
+    env_b.reset(start_idx=start)
+    buf = _fragment_buffers(env_a, T)
+    gen = torch.Generator(device=env_a.device)
+    gen.manual_seed(9)
+    buf['action'].copy_(torch.randint(0, 4, (T, n), generator=gen, device=env_a.device, dtype=torch.int32))
+    buf['obs'][0].copy_(o0)
+    env_a.rollout_fragment(T, buf['obs'], buf['final_obs'], buf['reward'], buf['done'], buf['info'], buf['action'])
+    torch.cuda.synchronize()
+    n_done = 0
+    for t in range(T):
+        o, r, d, i = env_b.step(buf['action'][t])
+        assert torch.equal(buf['obs'][t + 1], o), 'obs row %d' % t
+        assert torch.equal(buf['reward'][t], r) and torch.equal(buf['info'][t], i), 'reward row %d' % t
+        assert torch.equal(buf['done'][t].bool(), d), 'done row %d' % t
+        if bool(d.any()):
+            assert torch.equal(buf['final_obs'][t][d], env_b.final_obs[d])
+        n_done += int(d.sum())
+    assert n_done > n // 4
+    assert torch.equal(env_a.painted_words(), env_b.painted_words())
+    sa, sb = env_a.state(), env_b.state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    env_a.close()
+    env_b.close()
+
+
+def test_persistent_fragment_with_policy_equals_two_launches_per_step():
+    """RolloutWorker(persistent=True) -- policy and env step for the whole fragment in one launch -- fills the
+    trajectory buffers with exactly the bits of the two-launches-per-step worker, over two fragments."""
+    import torch
+    from conftest import synthetic_tables
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    tables = synthetic_tables('door_test')
+    n, T = 150, 40
+    envs = [BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=11) for _ in range(2)]
+    torch.manual_seed(3)
+    policy = MLPPolicy(envs[0].obs_dim, 4).to(envs[0].device)
+    workers = [RolloutWorker(envs[0], policy, fragment=T, seed=5), RolloutWorker(envs[1], policy, fragment=T, seed=5, persistent=True)]
+    for frag in range(2):
+        out = [w.collect() for w in workers]
+        torch.cuda.synchronize()
+        (b0, v0, r0), (b1, v1, r1) = out
+        for k in b0:
+            assert torch.equal(b0[k], b1[k]), (frag, k)
+        assert torch.equal(v0, v1) and torch.equal(r0, r1)
+        for k in workers[0].raw:
+            assert torch.equal(workers[0].raw[k], workers[1].raw[k]), (frag, k)
+    assert int(b0['dones'].sum()) > 50
+    assert torch.equal(envs[0].painted_words(), envs[1].painted_words())
+    for e in envs:
+        e.close()

@@ -13,6 +13,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ['PAINTRL_LAX_SYMBOLS'] = '1'          # libraries of earlier commits lack the newest entry points
 sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -2,14 +2,17 @@
 import collections
 import csv
 import glob
+import os
 import sys
+
+KERNEL = os.environ.get('PMC_KERNEL', 'step_kernel')       # substring of the kernel name to summarise
 
 for d in sys.argv[1:]:
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         acc = collections.defaultdict(list)
         meta = None
         for r in csv.DictReader(open(f)):
-            if 'step_kernel' in r['Kernel_Name']:
+            if KERNEL in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
                 meta = r
         waves = float(meta['Grid_Size']) / 64 if meta else 1

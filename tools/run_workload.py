@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--obs-mode', default='section')
     ap.add_argument('--steps', type=int, default=80)
     ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--fragment', action='store_true', help='the steps as ONE launch of the persistent fragment kernel (given actions)')
     a = ap.parse_args()
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
     env = BatchedPaintEnv(DeviceTables(tables), a.envs, auto_reset=True, seed=5678, obs_mode=a.obs_mode,
@@ -29,8 +30,16 @@ def main():
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (a.steps, a.envs), generator=gen, device='cuda', dtype=torch.int32)
     env.reset()
-    for k in range(a.steps):
-        env.step_raw(acts[k])
+    if a.fragment:
+        T, n, od = a.steps, a.envs, env.obs_dim
+        f64 = dict(dtype=torch.float64, device='cuda')
+        obs = torch.zeros((T + 1, n, od), **f64)
+        obs[0].copy_(env.obs)
+        env.rollout_fragment(T, obs, torch.zeros((T, n, od), **f64), torch.zeros((T, n), **f64),
+                             torch.zeros((T, n), dtype=torch.uint8, device='cuda'), torch.zeros((T, n, 2), **f64), acts)
+    else:
+        for k in range(a.steps):
+            env.step_raw(acts[k])
     torch.cuda.synchronize()
     env.close()
 
