@@ -47,8 +47,7 @@ def build_library(force=False, verbose=False):
 # Diagnostic variants used by tests/test_gpu_forced_paths.py: the same sources with every fast path
 # replaced by its general counterpart.  The product library never defines these macros.
 VARIANTS = {
-    'force_per_shot_paint': ['-DPRL_FORCE_PER_SHOT_PAINT'],
-    'force_f64_paint_wide_band': ['-DPRL_WIDE_PAINT_BAND'],
+    'force_paint_row_trips_wide_band': ['-DPRL_PAINT_ONE_ROW_PER_TRIP', '-DPRL_WIDE_PAINT_BAND'],
     'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY'],
 }
 

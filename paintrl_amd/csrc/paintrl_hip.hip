@@ -111,6 +111,85 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     PROF_END();
 }
 
+// ---------------------------------------------------------------- parts with more than 16 384 samples (KW > 4)
+// The reference's other parts (door_lf ... door_rr_big, Part_Dict rge:106-117: 18 000 - 71 000 front samples) do not
+// fit four mask words per lane.  Their kernels keep the env's masks in LDS instead (three copies of n_words words
+// per env in the step kernel, one in reset / observe), sized at launch; everything else is the same code.
+__device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, int n_words, int lane, int copies) {
+    extern __shared__ uint64_t big_lds[];
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    uint64_t *base = big_lds + (size_t)wave * copies * a.mask_stride;
+    return BigMasks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, base,
+                    base + (copies > 1 ? a.mask_stride : 0), base + (copies > 2 ? 2 * a.mask_stride : 0), n_words, lane};
+}
+
+template <bool GENSEC>
+__global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    const WaveLds wl = wave_lds<GENSEC>();
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
+    const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
+    double delta1, delta2, new_angle;
+    decode_action(C, a.actions, env, delta1, delta2, new_angle);
+    const int dn = step_env<0, false, GENSEC, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                    new_angle, StepRows{&a}, wl);
+    store_state_live(state_rec, S, lane, dn != 0);
+}
+
+template <bool GENSEC>
+__global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    if (a.reset_mask && !a.reset_mask[env]) return;
+    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
+    start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
+    reset_state(P, S, start);
+    extern __shared__ uint64_t big_lds[];
+    uint64_t *zero = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
+    for (int w = lane; w < P.n_words; w += 64) {
+        zero[w] = 0;
+        a.painted[(size_t)env * a.mask_stride + w] = 0;
+        a.last[(size_t)env * a.mask_stride + w] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
+    if (a.obs)
+        observation_big<GENSEC>(P, C, S.pose, zero, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
+                                wave_lds<GENSEC>().cnt);
+}
+
+template <bool GENSEC>
+__global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
+    extern __shared__ uint64_t big_lds[];
+    uint64_t *painted = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
+    for (int w = lane; w < P.n_words; w += 64) painted[w] = a.painted[(size_t)env * a.mask_stride + w];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    observation_big<GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
+                            wave_lds<GENSEC>().cnt);
+}
+
 // ---------------------------------------------------------------- rollout fragment: policy + step, T times, one launch
 // The caller of the step in BASELINE.json configs 3-4 is a rollout worker (paint_ppo.py:170-195, fragments of
 // sample_batch_size = 100 steps).  One launch per step makes every step end with a grid-wide wait for the slowest
@@ -401,9 +480,9 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     d.n_samples = t->n_samples;
     d.n_samples_pad = t->n_samples_pad;
     d.n_words = t->n_samples_pad / 64;
-    if (d.n_words > 64 * KW_MAX)
-        return fail(PRL_E_UNSUPPORTED, "part has %d samples; this build keeps at most %d per env in registers",
-                    t->n_samples, 64 * 64 * KW_MAX);
+    if (d.n_words > BIG_MAX_WORDS)
+        return fail(PRL_E_UNSUPPORTED, "part has %d samples; at most %d fit the LDS-resident masks of the large-part kernels",
+                    t->n_samples, 64 * BIG_MAX_WORDS);
     for (int k = 0; k < 3; ++k) UP(samp[k], t->sample_xyz[k], t->n_samples_pad);
     {   // float copy of the sample positions for the conservative paint pre-filter (prl_paint.hpp)
         if (!t->word_valid) return fail(PRL_E_INVALID, "null table pointer");
@@ -612,6 +691,18 @@ void launch_observe(const StepArgs &a, bool gensec, hipStream_t s) {
     else hipLaunchKernelGGL((observe_kernel<KW, false>), grid, block, 0, s, a);
 }
 
+// Large parts (more than 64 * KW_MAX mask words): dynamic LDS = 4 waves x copies x mask_stride words.
+int launch_big(void (*kernel)(StepArgs), const StepArgs &a, int copies, hipStream_t s) {
+    const size_t lds = (size_t)4 * copies * a.mask_stride * sizeof(uint64_t);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(PRL_E_HIP, "hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3((a.n_envs + 3) / 4), dim3(256), lds, s, a);
+    return PRL_OK;
+}
+
 bool general_section(const PrlConfig &c) {
     return (c.obs_mode == PRL_OBS_SECTION || c.obs_mode == PRL_OBS_DISCRETE) && c.obs_grad != 4;
 }
@@ -713,6 +804,12 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     for (int i = 0; i < n_parts; ++i)
         if (parts[i]->dev.n_words > b->mask_stride) b->mask_stride = parts[i]->dev.n_words;
     b->kw = (b->mask_stride + 63) / 64;
+    if (b->kw > KW_MAX && cfg->paint_method == PRL_PAINT_NORMAL) {
+        const int words = b->mask_stride;
+        delete b;
+        return fail(PRL_E_UNSUPPORTED, "PAINT_METHOD 'normal' is built for parts of at most %d samples (this batch: %d mask words)",
+                    64 * 64 * KW_MAX, words);
+    }
     hipError_t e = hipSetDevice(b->device);
     std::vector<PartDev> pd(n_parts);
     for (int i = 0; i < n_parts; ++i) pd[i] = parts[i]->dev;
@@ -768,7 +865,11 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
     case 1: launch_reset<1>(a, general_section(b->cfg), s); break;
     case 2: launch_reset<2>(a, general_section(b->cfg), s); break;
     case 3: launch_reset<3>(a, general_section(b->cfg), s); break;
-    default: launch_reset<4>(a, general_section(b->cfg), s); break;
+    case 4: launch_reset<4>(a, general_section(b->cfg), s); break;
+    default: {
+        const int rc = launch_big(general_section(b->cfg) ? reset_kernel_big<true> : reset_kernel_big<false>, a, 1, s);
+        if (rc) return rc;
+    }
     }
     HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -783,7 +884,11 @@ int prl_batch_observe(PrlBatch *b, double *obs, void *stream) {
     case 1: launch_observe<1>(a, general_section(b->cfg), s); break;
     case 2: launch_observe<2>(a, general_section(b->cfg), s); break;
     case 3: launch_observe<3>(a, general_section(b->cfg), s); break;
-    default: launch_observe<4>(a, general_section(b->cfg), s); break;
+    case 4: launch_observe<4>(a, general_section(b->cfg), s); break;
+    default: {
+        const int rc = launch_big(general_section(b->cfg) ? observe_kernel_big<true> : observe_kernel_big<false>, a, 1, s);
+        if (rc) return rc;
+    }
     }
     HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -817,7 +922,11 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     case 1: launch_step<1>(a, normal, general_section(b->cfg), s); break;
     case 2: launch_step<2>(a, normal, general_section(b->cfg), s); break;
     case 3: launch_step<3>(a, normal, general_section(b->cfg), s); break;
-    default: launch_step<4>(a, normal, general_section(b->cfg), s); break;
+    case 4: launch_step<4>(a, normal, general_section(b->cfg), s); break;
+    default: {                                     // a part with more than 16 384 samples: masks in LDS
+        const int rc = launch_big(general_section(b->cfg) ? step_kernel_big<true> : step_kernel_big<false>, a, 3, s);
+        if (rc) return rc;
+    }
     }
     HIP_TRY(hipGetLastError());
     if (timed) {
@@ -886,6 +995,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
         return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
     const PrlConfig &c = b->cfg;
     if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
+    if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: parts of at most %d samples", 64 * 64 * KW_MAX);
     if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
         return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for "
                                        "section / discrete observations");

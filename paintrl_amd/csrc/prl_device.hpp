@@ -7,7 +7,8 @@ namespace {
 
 
 constexpr int MAX_WAVES_PER_WG = 4;              // per-wave LDS scratch rows: every kernel here runs four waves per workgroup
-constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples
+constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples in registers
+constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3 copies x 4 waves x 1600 x 8 B = 150 KB of 160 KB
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
 constexpr double STEP_SIZE = 0.051;             // bpw:43
 constexpr double HOOK_DISTANCE = 0.1;           // bpw:443

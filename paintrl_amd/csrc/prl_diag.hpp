@@ -3,12 +3,12 @@
 // The product build defines none of the PRL_* diagnostic macros: STAMP / WCNT / PROF_* expand to nothing and the
 // kernels carry no instrumentation.  Diagnostic builds (tools/, tests/test_gpu_forced_paths.py) may define:
 //   PRL_PHASE_TIMING=<k>       s_memtime deltas of phase k summed over all waves (tools/phase_timing.py)
-//   PRL_FORCE_PER_SHOT_PAINT   paint shot by shot instead of the five-shot union pass       } the general paths,
+//   PRL_PAINT_ONE_ROW_PER_TRIP one sample-grid row per trip of the painter (multi-trip path)   } the general paths,
 //   PRL_FORCE_FULL_SCANS       whole-table scans instead of the ring searches                } run by the forced-
 //   PRL_FORCE_GENERAL_RAY      general two-stage ray search instead of the convex fast path  } path parity tests
 //   PRL_FORCE_F64_PAINT        every paint word through the float64 distance test (no float pre-filter)
 //   PRL_WIDE_PAINT_BAND        pre-filter band x 4096: the mixed float / float64 path runs constantly
-// The PRL_FORCE_* switches are read where the fast path is chosen (prl_paint.hpp, prl_search.hpp, prl_ray.hpp).
+// The switches are read where the fast path is chosen (prl_paint.hpp, prl_search.hpp, prl_ray.hpp).
 #pragma once
 
 namespace {

@@ -38,9 +38,11 @@ __device__ __forceinline__ double py_floor_div(double vx, double wx) {
 
 // bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
 // is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
+// `lds_painted`: the LDS-resident mask of a large part, or nullptr (then the register slots `painted` are used).
 template <int KW>
 __device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
-                                     int lane, int *cnt /* LDS: [2][64] for this wave */, double *out) {
+                                     const uint64_t *lds_painted, int lane, int *cnt /* LDS: [2][64] for this wave */,
+                                     double *out) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     cnt[lane] = 0;
     cnt[64 + lane] = 0;
@@ -50,9 +52,13 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
     for (int w = 0; w < P.n_words; ++w) {
         const uint64_t vw = P.word_valid[w];
         uint64_t pw = 0;
+        if (lds_painted) {
+            pw = lds_painted[w];
+        } else {
 #pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
+            for (int k = 0; k < KW; ++k)
+                if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
+        }
         if (!((vw >> lane) & 1)) continue;
         const int s = (w << 6) + lane;
         const double rx = ldg(sx, s) - x1, ry = ldg(sy, s) - x2;
@@ -73,76 +79,37 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
     }
 }
 
-// GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
-// its registers or code.
-template <int KW, bool GENSEC>
-__device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
-                                 const uint64_t painted[KW_MAX], int lane, double *out, int *cnt_lds) {
-    // bpw:965-978 get_normalized_pose
+// bpw:965-978 get_normalized_pose
+__device__ __forceinline__ void normalized_pose(PartRef P, CfgRef C, const double pose[3], double &x1, double &x2,
+                                                double &np0, double &np1) {
     const double r = C.paint_radius;
-    const double x1 = sel3(pose[0], pose[1], pose[2], P.a1), x2 = sel3(pose[0], pose[1], pose[2], P.a2);
+    x1 = sel3(pose[0], pose[1], pose[2], P.a1);
+    x2 = sel3(pose[0], pose[1], pose[2], P.a2);
     const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
     const int gi = grid_index_2(P, x2);
     const double lo = P.grid_lo[gi], hi = P.grid_hi[gi];
     double in1;
     if (hi - lo == 0) in1 = 0;
     else in1 = (x1 - lo + r) / (hi - lo + 2 * r);
-    const double np0 = clip01(in1), np1 = clip01(in2);
-    const int mode = C.obs_mode;
-    if (mode == PRL_OBS_SIMPLE) {
-        if (lane == 0) {
-            out[0] = np0;
-            out[1] = np1;
-        }
-        return;
-    }
-    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
-        // 16 cells per pass: four packed accumulators (4 x 16-bit per u64), four DPP sums, then lane j
-        // finishes cell j (one division per lane, one coalesced store)
-        const int cells = P.n_obs_cells;
-        for (int c0 = 0; c0 < cells; c0 += 16) {
-            uint64_t acc[4] = {0, 0, 0, 0};
+    np0 = clip01(in1);
+    np1 = clip01(in2);
+}
+
+// bpw:1126-1139 grid observation, 16 cells starting at c0: adds popcount(painted word & cell mask) of word w into
+// four packed accumulators (4 x 16-bit per u64; a lane adds at most 64 per word)
+__device__ __forceinline__ void grid_accumulate(PartRef P, int c0, int cells, uint64_t pw, int w, uint64_t acc[4]) {
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int w = lane + 64 * k;
-                if (w < P.n_words) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (c0 + j < cells)
-                            acc[j >> 2] += (uint64_t)__popcll(painted[k] & ldg(P.cell_mask, (c0 + j) * P.n_words + w))
-                                           << (16 * (j & 3));
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = wave_sum_u64(acc[g]);
-            const int cell = c0 + lane;
-            if (lane < 16 && cell < cells) {
-                uint64_t a4 = acc[0];
-#pragma unroll
-                for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
-                const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
-                const int num = ldg(P.cell_count, cell);
-                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
-            }
-        }
-        return;
-    }
-    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
-        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, lane, cnt_lds, out);
-        if (lane == 0) {
-            if (mode == PRL_OBS_SECTION) {
-                out[C.obs_grad] = np0;
-                out[C.obs_grad + 1] = np1;
-            } else {
-                const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);
-                out[C.obs_grad] = 1.0 / (double)position;
-            }
-        }
-        return;
-    } else {
-    // section / discrete, 4-sector rule bpw:1034-1043
+    for (int j = 0; j < 16; ++j)
+        if (c0 + j < cells)
+            acc[j >> 2] += (uint64_t)__popcll(pw & ldg(P.cell_mask, (c0 + j) * P.n_words + w)) << (16 * (j & 3));
+}
+
+// 4-sector rule bpw:1034-1043 for the words  lane + 64 (slot0 + k), k < KW,  whose painted bits are painted[k]:
+// adds the per-sector totals / unpainted counts of those words into tot_l / und_l (4 x 16-bit fields per lane).
+template <int KW>
+__device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double x2, const uint64_t painted[KW_MAX],
+                                                    int slot0, int lane, uint64_t &tot_l, uint64_t &und_l) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    uint64_t tot_l = 0, und_l = 0;                 // 4 x 16-bit counters per lane (total / unpainted per sector)
     uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
     // Pass 1, one word per lane and slot: a word whose box lies in one sector is counted whole.  A word
     // that straddles only the vertical line x1 (its row is clear of x2) is resolved by its own lane
@@ -151,7 +118,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
     uint64_t valid[KW_MAX] = {0, 0, 0, 0}, smask[KW_MAX] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
-        const int w = lane + 64 * k;
+        const int w = lane + 64 * (slot0 + k);
         bool straddle = false;
         if (w < P.n_words) {
             const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), w);
@@ -180,7 +147,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
             int base[KW_MAX], pos[KW_MAX];
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                base[k] = vline[k] ? (lane + 64 * k) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
+                base[k] = vline[k] ? (lane + 64 * (slot0 + k)) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
                 pos[k] = 0;
             }
 #pragma unroll
@@ -216,12 +183,12 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
             WCNT(6, 1);
             const int L = __builtin_ctzll(sm);
             sm &= sm - 1;
-            const int w2 = L + 64 * k;
+            const int w2 = L + 64 * (slot0 + k);
             const double xs = ldg(sx, (w2 << 6) + lane), ys = ldg(sy, (w2 << 6) + lane);
             const uint64_t vs = P.word_valid[w2];
             // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
             // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
-            // 64 straddling words)
+            // 64 straddling words per call)
             const uint64_t pw = bcast_u64(painted[k], L);
             const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs) && !(xs == x1 && ys == x2);
             const bool gy = ys > x2, lx = xs < x1;
@@ -237,22 +204,155 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
         und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
     }
-    tot_l = wave_sum_u64(tot_l);
-    und_l = wave_sum_u64(und_l);
-    if (lane == 0) {
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
-            const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
-            out[q] = t == 0 ? 0.0 : (double)u / (double)t;
+}
+
+// section / discrete tail: out[0..g-1] are written by the caller; the pose part follows
+__device__ __forceinline__ void section_pose_tail(int mode, int g, double np0, double np1, double *out) {
+    if (mode == PRL_OBS_SECTION) {
+        out[g] = np0;
+        out[g + 1] = np1;
+    } else {
+        const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
+        out[g] = 1.0 / (double)position;
+    }
+}
+
+// GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
+// its registers or code.  Masks in registers (parts with at most 16 384 samples).
+template <int KW, bool GENSEC>
+__device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
+                                 const uint64_t painted[KW_MAX], int lane, double *out, int *cnt_lds) {
+    double x1, x2, np0, np1;
+    normalized_pose(P, C, pose, x1, x2, np0, np1);
+    const int mode = C.obs_mode;
+    if (mode == PRL_OBS_SIMPLE) {
+        if (lane == 0) {
+            out[0] = np0;
+            out[1] = np1;
         }
-        if (mode == PRL_OBS_SECTION) {
-            out[4] = np0;
-            out[5] = np1;
-        } else {
-            const int position = (handle_pos(np0) + 1) * 22 + handle_pos(np1);     // rge:101-103
-            out[4] = 1.0 / (double)position;
+        return;
+    }
+    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
+        // 16 cells per pass: four packed accumulators, four DPP sums, then lane j finishes cell j (one division
+        // per lane, one coalesced store)
+        const int cells = P.n_obs_cells;
+        for (int c0 = 0; c0 < cells; c0 += 16) {
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int w = lane + 64 * k;
+                if (w < P.n_words) grid_accumulate(P, c0, cells, painted[k], w, acc);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = wave_sum_u64(acc[g]);
+            const int cell = c0 + lane;
+            if (lane < 16 && cell < cells) {
+                uint64_t a4 = acc[0];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) a4 = (lane >> 2) == g ? acc[g] : a4;
+                const int dn = (int)((a4 >> (16 * (lane & 3))) & 0xffff);
+                const int num = ldg(P.cell_count, cell);
+                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
+            }
+        }
+        return;
+    }
+    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
+        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, nullptr, lane, cnt_lds, out);
+        if (lane == 0) section_pose_tail(mode, C.obs_grad, np0, np1, out);
+        return;
+    } else {
+        uint64_t tot_l = 0, und_l = 0;             // 4 x 16-bit counters per lane (total / unpainted per sector)
+        section4_accumulate<KW>(P, x1, x2, painted, 0, lane, tot_l, und_l);
+        tot_l = wave_sum_u64(tot_l);
+        und_l = wave_sum_u64(und_l);
+        if (lane == 0) {
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
+                const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
+                out[q] = t == 0 ? 0.0 : (double)u / (double)t;
+            }
+            section_pose_tail(mode, 4, np0, np1, out);
         }
     }
+}
+
+// The same observation for a part with more than 16 384 samples: the painted mask lives in LDS (`painted`,
+// n_words words) and is walked 64 words at a time; counts can exceed 16 bits, so the per-lane 16-bit fields (at most
+// 64 x 18 per lane) are split into 32-bit halves before the wave sums.
+template <bool GENSEC>
+__device__ void observation_big(PartRef P, CfgRef C, const double pose[3], const uint64_t *painted, int lane,
+                                double *out, int *cnt_lds) {
+    double x1, x2, np0, np1;
+    normalized_pose(P, C, pose, x1, x2, np0, np1);
+    const int mode = C.obs_mode;
+    if (mode == PRL_OBS_SIMPLE) {
+        if (lane == 0) {
+            out[0] = np0;
+            out[1] = np1;
+        }
+        return;
+    }
+    const int n_slots = (P.n_words + 63) >> 6;
+    if (mode == PRL_OBS_GRID) {
+        const int cells = P.n_obs_cells;
+        for (int c0 = 0; c0 < cells; c0 += 16) {
+            uint64_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};       // 2 x 32-bit per u64: fields 0,1 and 2,3 of acc
+            for (int k = 0; k < n_slots; ++k) {
+                uint64_t acc[4] = {0, 0, 0, 0};
+                const int w = lane + 64 * k;
+                if (w < P.n_words) grid_accumulate(P, c0, cells, painted[w], w, acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    lo[g] += (acc[g] & 0xffffull) | ((acc[g] & 0xffff0000ull) << 16);
+                    hi[g] += ((acc[g] >> 32) & 0xffffull) | ((acc[g] >> 48) << 32);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lo[g] = wave_sum_u64(lo[g]);
+                hi[g] = wave_sum_u64(hi[g]);
+            }
+            const int cell = c0 + lane;
+            if (lane < 16 && cell < cells) {
+                uint64_t l4 = lo[0], h4 = hi[0];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) {
+                    l4 = (lane >> 2) == g ? lo[g] : l4;
+                    h4 = (lane >> 2) == g ? hi[g] : h4;
+                }
+                const uint64_t pair = (lane & 2) ? h4 : l4;
+                const int dn = (int)((lane & 1) ? (pair >> 32) : (pair & 0xffffffffull));
+                const int num = ldg(P.cell_count, cell);
+                out[cell] = num == 0 ? 0.0 : 1.0 - (double)dn / (double)num;
+            }
+        }
+        return;
+    }
+    if constexpr (GENSEC) {
+        const uint64_t none[KW_MAX] = {0, 0, 0, 0};
+        section_general_wave<1>(P, C.obs_grad, x1, x2, none, painted, lane, cnt_lds, out);
+        if (lane == 0) section_pose_tail(mode, C.obs_grad, np0, np1, out);
+        return;
+    } else {
+        uint64_t tot_l = 0, und_l = 0;
+        for (int k = 0; k < n_slots; ++k) {
+            const int w = lane + 64 * k;
+            const uint64_t pk[KW_MAX] = {w < P.n_words ? painted[w] : 0, 0, 0, 0};
+            section4_accumulate<1>(P, x1, x2, pk, k, lane, tot_l, und_l);
+        }
+        uint64_t t01 = (tot_l & 0xffffull) | ((tot_l & 0xffff0000ull) << 16), t23 = ((tot_l >> 32) & 0xffffull) | ((tot_l >> 48) << 32);
+        uint64_t u01 = (und_l & 0xffffull) | ((und_l & 0xffff0000ull) << 16), u23 = ((und_l >> 32) & 0xffffull) | ((und_l >> 48) << 32);
+        t01 = wave_sum_u64(t01);
+        t23 = wave_sum_u64(t23);
+        u01 = wave_sum_u64(u01);
+        u23 = wave_sum_u64(u23);
+        if (lane == 0) {
+            const uint32_t t[4] = {(uint32_t)t01, (uint32_t)(t01 >> 32), (uint32_t)t23, (uint32_t)(t23 >> 32)};
+            const uint32_t u[4] = {(uint32_t)u01, (uint32_t)(u01 >> 32), (uint32_t)u23, (uint32_t)(u23 >> 32)};
+            for (int q = 0; q < 4; ++q) out[q] = t[q] == 0 ? 0.0 : (double)u[q] / (double)t[q];
+            section_pose_tail(mode, 4, np0, np1, out);
+        }
     }
 }
 

@@ -1,55 +1,17 @@
-// prl_paint.hpp -- ball-query painting: one shot, and the five shots of a step together (bpw:568-577).
+// prl_paint.hpp -- ball-query painting: the five shots of a step together (bpw:568-577).
 // Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that
 // file for the overall design.  Compile with -ffp-contract=off.
 #pragma once
 
 namespace {
 
-// ---------------------------------------------------------------- bpw:568-570 fast_paint (ball query)
+// ---------------------------------------------------------------- bit of one sample in a register-resident mask (cone-beam paint)
 template <int KW>
 __device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b, int lane) {
     const int owner = w & 63, slot = w >> 6;
 #pragma unroll
     for (int k = 0; k < KW; ++k)
         if (k == slot && lane == owner) cur[k] |= b;
-}
-
-template <int KW>
-__device__ void ball_query_wave(PartRef P, double radius, const double c[3], int lane,
-                                uint64_t cur[KW_MAX]) {
-    const double r2 = radius * radius;
-    const double c1 = sel3(c[0], c[1], c[2], P.a1), c2 = sel3(c[0], c[1], c[2], P.a2);
-    const int icx = cell_coord(c1, P.sg_o1, P.sg_inv, P.sg_nx), icy = cell_coord(c2, P.sg_o2, P.sg_inv, P.sg_ny);
-    const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int begin = R.begin[r], end = begin + R.count[r];
-        if (R.count[r] <= 0) continue;
-        const int wlast = (end - 1) >> 6;
-        for (int w = begin >> 6; w <= wlast; w += 2) {            // two words per trip: six loads in flight
-            const int s0 = (w << 6) + lane, s1 = s0 + 64;
-            const bool two = w + 1 <= wlast;
-            const double x0 = ldg(P.samp[0], s0), y0 = ldg(P.samp[1], s0), z0 = ldg(P.samp[2], s0);
-            double x1 = 0, y1 = 0, z1 = 0;
-            if (two) {
-                x1 = ldg(P.samp[0], s1);
-                y1 = ldg(P.samp[1], s1);
-                z1 = ldg(P.samp[2], s1);
-            }
-            {
-                const double dx = x0 - c[0], dy = y0 - c[1], dz = z0 - c[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const uint64_t b = __ballot(s0 >= begin && s0 < end && dd <= r2);
-                if (b) set_word<KW>(cur, w, b, lane);
-            }
-            if (two) {
-                const double dx = x1 - c[0], dy = y1 - c[1], dz = z1 - c[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const uint64_t b = __ballot(s1 >= begin && s1 < end && dd <= r2);
-                if (b) set_word<KW>(cur, w + 1, b, lane);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------- the five shots of one step, painted together
@@ -74,11 +36,61 @@ __device__ void ball_query_wave(PartRef P, double radius, const double c[3], int
 // -DPRL_FORCE_F64_PAINT sends every word through the float64 branch; -DPRL_WIDE_PAINT_BAND widens the band
 // 4096-fold so that the mixed path runs constantly: both builds must reproduce the product's results exactly.
 
+// How the painter reads and writes one 64-sample word of the env's masks.  Small parts (<= 16 384 samples) keep
+// the masks in registers: word w lives in lane w & 63, slot w >> 6 ...
 template <int KW>
-__device__ bool paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane,
-                                  uint64_t painted[KW_MAX],
-                                  const uint64_t last[KW_MAX], uint64_t new_last[KW_MAX], int &succeeded,
-                                  int &pixel_counter) {
+struct RegWords {
+    uint64_t *painted;            // [KW_MAX] register arrays of the caller
+    const uint64_t *last;
+    uint64_t *new_last;
+    int lane;
+    __device__ __forceinline__ void get(int w, uint64_t &pw, uint64_t &lw) const {
+        const int owner = w & 63, slot = w >> 6;
+        pw = 0;
+        lw = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == slot) {
+                pw = bcast_u64(painted[k], owner);
+                lw = bcast_u64(last[k], owner);
+            }
+    }
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+        const int owner = w & 63, slot = w >> 6;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == slot && lane == owner) {
+                painted[k] = pw;
+                new_last[k] = lw;
+            }
+    }
+};
+
+// ... larger ones (the 480 x 480 textures: up to ~70 000 samples) keep them in LDS for the length of the kernel.
+struct LdsWords {
+    uint64_t *painted;            // [n_words] in LDS
+    const uint64_t *last;
+    uint64_t *new_last;           // zero on entry
+    int lane;
+    __device__ __forceinline__ void get(int w, uint64_t &pw, uint64_t &lw) const {
+        pw = painted[w];
+        lw = last[w];
+    }
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+        if (lane == 0) {
+            painted[w] = pw;
+            new_last[w] = lw;
+        }
+    }
+};
+
+// Works for any spread of the five centres: the rows cy_lo-1 .. cy_hi+1 of the sample grid are walked four at a
+// time (one trip in practice: the centres of a step are 10 mm apart), columns cx_lo-1 .. cx_hi+1.  A sample outside
+// a shot's own 3 x 3 cell block is more than a cell edge (> radius) away from that centre, so testing every sample
+// of the bounding block against all five centres gives each shot exactly its own ball query.
+template <typename Words>
+__device__ void paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane, const Words &words,
+                                  int &succeeded, int &pixel_counter) {
     const double r2 = radius * radius;
     // the float64 centres are only needed for the cell ranges and by the rare float64 branch, which reads them
     // from LDS again: fifteen doubles held across the word loop would be thirty vector registers
@@ -104,24 +116,27 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
     // thresholds rounded outward, so that the float comparisons are at least as cautious as the double ones
     const float r2_in = nextafterf((float)(r2 - band), -INFINITY), r2_out = nextafterf((float)(r2 + band), INFINITY);
     const f32x4 GAS *s4 = reinterpret_cast<const f32x4 GAS *>(P.samp_f32);
-#ifdef PRL_FORCE_PER_SHOT_PAINT                     // diagnostic build: exercise the general path in the parity tests
-    return false;
-#endif
-    if (cy_hi - cy_lo > 1) return false;            // centres spread over > 2 cell rows: caller paints shot by shot
-    // rows cy_lo-1 .. cy_hi+1 (<= 4), columns cx_lo-1 .. cx_hi+1: lanes 0..7 fetch the range bounds
     const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
-    const int rcy = cy_lo - 1 + (lane >> 1);
-    const bool ok = lane < 8 && rcy <= cy_hi + 1 && rcy >= 0 && rcy < P.sg_ny && cx0 <= cx1;
+    const int row_lo = rfl(cy_lo - 1 < 0 ? 0 : cy_lo - 1), row_hi = rfl(cy_hi + 1 > P.sg_ny - 1 ? P.sg_ny - 1 : cy_hi + 1);
+    int done_w = -1;                                 // a word shared by two rows' ranges is handled once
+#ifdef PRL_PAINT_ONE_ROW_PER_TRIP                   // diagnostic build: the multi-trip path in every parity test
+    constexpr int TRIP = 1;
+#else
+    constexpr int TRIP = 4;
+#endif
+    for (int r0 = row_lo; r0 <= row_hi; r0 += TRIP) {
+    // TRIP rows per trip: lanes 0 .. 2 TRIP - 1 fetch the range bounds
+    const int rcy = r0 + (lane >> 1);
+    const bool ok = lane < 2 * TRIP && rcy <= row_hi && cx0 <= cx1;
     const int bound = ok ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
-    int rb[4], re[4];
+    int rb[TRIP], re[TRIP];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TRIP; ++r) {
         rb[r] = __builtin_amdgcn_readlane(bound, 2 * r);
         re[r] = __builtin_amdgcn_readlane(bound, 2 * r + 1);
     }
-    int done_w = -1;                                 // a word shared by two rows' ranges is handled once
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TRIP; ++r) {
         if (re[r] <= rb[r]) continue;
         const int wlast = (re[r] - 1) >> 6;
         for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
@@ -156,14 +171,8 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
                 }
             }
             done_w = w;
-            const int owner = w & 63, slot = w >> 6;
-            uint64_t pw = 0, lw = 0;
-#pragma unroll
-            for (int k = 0; k < KW; ++k)
-                if (k == slot) {
-                    pw = bcast_u64(painted[k], owner);
-                    lw = bcast_u64(last[k], owner);
-                }
+            uint64_t pw, lw;
+            words.get(w, pw, lw);
             if (any == 0 && lw == 0) continue;       // nothing to record for this word
             // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
             // affected), folded: the newly painted samples of the five shots are the union minus what was
@@ -175,15 +184,10 @@ __device__ bool paint_shots_union(PartRef P, double radius, const double *cen_ld
             for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
             lw = b[PAINT_PER_ACTION - 1];
             pixel_counter += __popcll(uw);
-#pragma unroll
-            for (int k = 0; k < KW; ++k)
-                if (k == slot && lane == owner) {
-                    painted[k] = pw;
-                    new_last[k] = lw;
-                }
+            words.put(w, pw, lw);
         }
     }
-    return true;
+    }
 }
 
 }  // namespace

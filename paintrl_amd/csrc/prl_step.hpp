@@ -68,8 +68,11 @@ template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, typename MaskIO, type
 __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                         const double *state_rec, const MaskIO &masks, double delta1, double delta2,
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
+    // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
+    constexpr bool BIG = KW == 0;
+    static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in registers: small parts only");
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    if constexpr (NORMAL) masks.template load<KW>(painted, last);
+    if constexpr (NORMAL || BIG) masks.template load<KW>(painted, last);
     const int counter_before = S.terminate_counter;
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
@@ -172,7 +175,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     } else {
         pose_orn_quat(cur_norm, S.quat);
     }
-    if constexpr (!NORMAL) masks.template load<KW>(painted, last);
+    if constexpr (!NORMAL && !BIG) masks.template load<KW>(painted, last);
     STAMP(PH_LOAD);
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
@@ -184,30 +187,18 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         succeeded = (int)(sums >> 32);
         pixel_counter = (int)(sums & 0xffffffffu);
     } else {
-        uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
-        if (paint_shots_union<KW>(P, C.paint_radius, cen, lane, painted, last, new_last, succeeded, pixel_counter)) {
+        if constexpr (BIG) {
+            paint_shots_union(P, C.paint_radius, cen, lane, LdsWords{masks.painted, masks.last, masks.new_last, lane},
+                              succeeded, pixel_counter);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+            paint_shots_union(P, C.paint_radius, cen, lane, RegWords<KW>{painted, last, new_last, lane}, succeeded,
+                              pixel_counter);
 #pragma unroll
             for (int k = 0; k < KW; ++k) last[k] = new_last[k];
-        } else {                                   // general path: one ball query per shot
-            uint64_t uni[KW_MAX] = {0, 0, 0, 0};
-            uint32_t succeeded_l = 0, pix_l = 0;
-            for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-                uint64_t cur[KW_MAX] = {0, 0, 0, 0};
-                const double c3[3] = {cen[3 * shot], cen[3 * shot + 1], cen[3 * shot + 2]};
-                ball_query_wave<KW>(P, C.paint_radius, c3, lane, cur);
-#pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    succeeded_l += __popcll(cur[k] & ~painted[k]);
-                    painted[k] |= cur[k];
-                    uni[k] |= cur[k] & ~last[k];
-                    last[k] = cur[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
-            const uint64_t sums = wave_sum_u64(((uint64_t)succeeded_l << 32) | pix_l);
-            succeeded = (int)(sums >> 32);
-            pixel_counter = (int)(sums & 0xffffffffu);
         }
     }
     STAMP(PH_BALL);
@@ -243,7 +234,10 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
     double *obs_row = a.obs() + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs() ? a.final_obs() + (size_t)env * od : nullptr) : obs_row;
-    if (term_row) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row, wl.cnt);
+    if (term_row) {
+        if constexpr (BIG) observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, term_row, wl.cnt);
+        else observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row, wl.cnt);
+    }
     if (lane == 0) {
         a.reward()[env] = actual;
         a.done()[env] = (uint8_t)dn;
@@ -254,6 +248,8 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         uint32_t cnt_l = 0;
 #pragma unroll
         for (int k = 0; k < KW; ++k) cnt_l += __popcll(painted[k]);
+        if constexpr (BIG)
+            for (int w = lane; w < masks.n_words; w += 64) cnt_l += __popcll(masks.painted[w]);
         S.last_ep_painted = (int)wave_sum_u64(cnt_l);
         S.last_ep_return = S.total_return;
         S.last_ep_reward = S.total_reward;
@@ -268,7 +264,12 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             painted[k] = 0;
             last[k] = 0;
         }
-        observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
+        if constexpr (BIG) {
+            masks.clear();
+            observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, obs_row, wl.cnt);
+        } else {
+            observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
+        }
     }
     STAMP(PH_OBS);
     masks.template store<KW>(painted, last);
@@ -284,6 +285,41 @@ struct StepRows {
     __device__ __forceinline__ double *info() const { return k->info; }
     __device__ __forceinline__ uint8_t *done() const { return k->done; }
     __device__ __forceinline__ const int *start_idx() const { return k->start_idx; }
+};
+
+// The masks of an env of a LARGE part: rows in HBM, working copies in LDS for the length of the kernel
+// (painted, last = the previous shot's set, new_last = what this step's last shot affected, zero on entry).
+struct BigMasks {
+    uint64_t *g_painted, *g_last;                 // HBM rows of this env
+    uint64_t *painted, *last, *new_last;          // LDS, n_words each
+    int n_words, lane;
+    template <int KW>
+    __device__ __forceinline__ void load(uint64_t *, uint64_t *) const {
+        for (int w = lane; w < n_words; w += 64) {
+            painted[w] = g_painted[w];
+            last[w] = g_last[w];
+            new_last[w] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void clear() const {               // reset: nothing painted, no last shot
+        for (int w = lane; w < n_words; w += 64) {
+            painted[w] = 0;
+            new_last[w] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    template <int KW>
+    __device__ __forceinline__ void store(const uint64_t *, const uint64_t *) const {
+        for (int w = lane; w < n_words; w += 64) {
+            g_painted[w] = painted[w];
+            g_last[w] = new_last[w];
+        }
+    }
 };
 
 // The masks of env `env` in HBM: word w of a mask is read / written by lane w & 63 into slot w >> 6.

@@ -248,7 +248,11 @@ def quadratic_sheet(seed=1):
     return v, uv, f, fvt
 
 
-PARTS = {'door_test': door_panel, 'square': quadratic_sheet}
+# 'door_rr_big': the door panel on a 480 x 480 texture, like the reference's Part_NO 8 (door_rr_big.urdf with
+# pattern_big.jpg): ~38 000 front samples, i.e. a part whose coverage masks do not fit four words per lane.
+PARTS = {'door_test': door_panel, 'square': quadratic_sheet, 'door_rr_big': door_panel}
+TEXTURES = {'door_test': ((240, 240), 'pattern.jpg'), 'square': ((240, 240), 'pattern.jpg'),
+            'door_rr_big': ((480, 480), 'pattern_big.jpg')}
 
 
 def write_synthetic_parts(root, names=('door_test', 'square')):
@@ -258,7 +262,8 @@ def write_synthetic_parts(root, names=('door_test', 'square')):
     for name in names:
         v, uv, f, fvt = PARTS[name]()
         v = np.round(v, 6)                  # what the OBJ text carries
-        out[name] = obj_io.write_part(directory, name, v, uv, f, fvt)
+        tex_size, tex_name = TEXTURES[name]
+        out[name] = obj_io.write_part(directory, name, v, uv, f, fvt, tex_size=tex_size, texture_name=tex_name)
     return out
 
 

@@ -18,12 +18,14 @@ def pytest_configure(config):
 _TABLES = {}
 
 
-def synthetic_tables(name, paint_radius=0.051):
-    """Session cache of PartTables for the synthetic parts ('door_test' | 'square')."""
-    key = (name, paint_radius)
+def synthetic_tables(name, paint_radius=0.051, tex_size=None):
+    """Session cache of PartTables for the synthetic parts ('door_test' | 'square' | 'door_rr_big'); ``tex_size``
+    overrides the part's texture size (more texels = more coverage samples on the same mesh)."""
+    from paintrl_amd import part_tables, synth_parts
+    tex_size = tuple(tex_size or synth_parts.TEXTURES[name][0])
+    key = (name, paint_radius, tex_size)
     if key not in _TABLES:
-        from paintrl_amd import part_tables, synth_parts
-        _TABLES[key] = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(name), tex_size=(240, 240),
+        _TABLES[key] = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(name), tex_size=tex_size,
                                                      name=name, paint_radius=paint_radius)
     return _TABLES[key]
 

@@ -1,0 +1,100 @@
+"""Golden data for the parts beyond door_test / square -- TEST INFRASTRUCTURE, development container only.
+
+1. g0_reference_parts.json: static-table digests (G0) of EVERY entry of the reference's Part_Dict
+   (PaintRLEnv/robot_gym_env.py:106-117), produced by importing the reference on its own meshes under
+   /root/reference (construction takes the reference 15 s - 10 min per part).  Only digests are stored.
+2. episodes_door_big.npz + g0_tables_door_big.npz: the synthetic door on a 480 x 480 texture ('door_rr_big',
+   ~38 000 front samples: the large-part kernels), recorded from the reference like every other fixture.
+3. episodes_reference_door_rr.npz: one episode on the reference's own door_rr.urdf (Part_NO 5), for the
+   in-container check of the CPU oracle against the reference on a real large part (tables are rebuilt from
+   /root/reference at test time; the test is skipped where the reference is absent).
+
+    python tests/golden/make_golden_parts.py [digests] [big] [door_rr]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_import  # noqa: E402
+from make_golden import RefDriver, random_policy, table_digest, zigzag_policy_grid  # noqa: E402
+from paintrl_amd import synth_parts  # noqa: E402
+
+DIGEST_KEYS = ('P', 'P_back', 'T', 'V', 'side_counts', 'axes', 'ranges', 'lwr', 'density', 'n_start_all', 'n_start_edge',
+               'sha_pix', 'sha_pos', 'sha_sides', 'sha_front_normals', 'sha_start_points', 'sha_start_points_edge',
+               'sha_side_vertices', 'sha_cells4', 'grid_lo', 'grid_hi', 'beams', 'construct_s')
+
+
+def jsonable(v):
+    v = np.asarray(v)
+    if v.ndim == 0:
+        return v.item()
+    return v.tolist()
+
+
+def reference_digests():
+    root = os.path.join(ref_import.REFERENCE_ROOT, 'PaintRLEnv')
+    path = os.path.join(HERE, 'g0_reference_parts.json')
+    out = json.load(open(path)) if os.path.isfile(path) else {}
+    rge = ref_import.load_reference('hull')[0]
+    for part_no in sorted(rge.Part_Dict):
+        name = rge.Part_Dict[part_no][0]
+        if name in out:
+            continue
+        drv = RefDriver(root, part_no)
+        d = table_digest(drv)
+        out[name] = {k: jsonable(d[k]) for k in DIGEST_KEYS}
+        out[name]['part_no'] = part_no
+        print(name, 'P', out[name]['P'], 'constructed in %.0f s' % out[name]['construct_s'], flush=True)
+        with open(path, 'w') as f:                      # written part by part: the big ones take minutes
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
+def save_episodes(path, eps):
+    flat = {'episodes': json.dumps(sorted(eps))}
+    for name, ep in eps.items():
+        for k, v in ep.items():
+            flat['%s/%s' % (name, k)] = v
+    np.savez_compressed(path, **flat)
+
+
+def big_synthetic():
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root, names=('door_rr_big',))
+    big = RefDriver(root, 8)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_door_big.npz'), **table_digest(big))
+    eps = {}
+    big.configure('section', 4, 'all')
+    for s in range(3):
+        eps['g11_big_all_%d' % s] = big.episode(400 + s, random_policy(70 + s), max_steps=120)
+    big.configure('grid', 4, 'anchor', overlap=True)
+    eps['g11_big_grid_overlap'] = big.episode(21, zigzag_policy_grid(), max_steps=60, want_idx=0)
+    big.configure('section', 6, 'anchor')
+    eps['g11_big_section6'] = big.episode(410, random_policy(75), max_steps=40, want_idx=1)
+    save_episodes(os.path.join(HERE, 'episodes_door_big.npz'), eps)
+
+
+def reference_door_rr():
+    root = os.path.join(ref_import.REFERENCE_ROOT, 'PaintRLEnv')
+    drv = RefDriver(root, 5)
+    eps = {}
+    drv.configure('section', 4, 'all')
+    for s in range(2):
+        eps['g12_door_rr_%d' % s] = drv.episode(500 + s, random_policy(80 + s), max_steps=80)
+    drv.configure('grid', 4, 'anchor', overlap=True)
+    eps['g12_door_rr_grid'] = drv.episode(21, zigzag_policy_grid(), max_steps=50, want_idx=0)
+    save_episodes(os.path.join(HERE, 'episodes_reference_door_rr.npz'), eps)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['digests', 'big', 'door_rr']
+    if 'big' in what:
+        big_synthetic()
+    if 'door_rr' in what:
+        reference_door_rr()
+    if 'digests' in what:
+        reference_digests()

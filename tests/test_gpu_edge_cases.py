@@ -97,7 +97,7 @@ def test_error_codes_and_messages():
     st.adj_width = 0
     assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -3
     st = dt.c_struct()
-    st.n_samples, st.n_samples_pad = 64 * 64 * 4 + 64, 64 * 64 * 4 + 64    # beyond the register-resident limit
+    st.n_samples, st.n_samples_pad = 64 * 1600 + 64, 64 * 1600 + 64      # beyond what the LDS-resident masks hold
     assert lib.prl_part_create(C.byref(st), 0, C.byref(h)) == -3 and b'at most' in lib.prl_last_error()
     bad = dt.sgrid_start.copy()
     bad[3] = bad[2] - 1                                                # not monotone

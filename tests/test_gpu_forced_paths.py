@@ -1,9 +1,9 @@
 """Every fast path of the step kernel against its general counterpart.
 
 __graft_entry__.build() also compiles two diagnostic variants of the library in which the fast paths are
-disabled (per-shot painting instead of the five-shot union pass; whole-table scans instead of ring searches
-and the general two-stage ray instead of the convex-neighbourhood path; the float pre-filter of the paint
-distance test with its uncertainty band widened 4096-fold, so that the float64 confirmation runs constantly).  The parity suites are run against
+disabled or stressed (whole-table scans instead of ring searches and the general two-stage ray instead of the
+convex-neighbourhood path; the painter walking one sample-grid row per trip instead of four, with the uncertainty
+band of its float pre-filter widened 4096-fold so that the float64 confirmation runs constantly).  The parity suites are run against
 each variant in a fresh child process (PAINTRL_LIB selects the library before anything is loaded); the product
 build never defines these macros.
 """
@@ -18,7 +18,7 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('variant', ['force_per_shot_paint', 'force_general_search', 'force_f64_paint_wide_band'])
+@pytest.mark.parametrize('variant', ['force_general_search', 'force_paint_row_trips_wide_band'])
 def test_parity_suites_on_forced_general_paths(variant):
     from paintrl_amd import build
     lib = build.variant_path(variant)
