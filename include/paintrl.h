@@ -34,6 +34,7 @@ enum { PRL_OBS_SECTION = 0, PRL_OBS_GRID = 1, PRL_OBS_SIMPLE = 2, PRL_OBS_DISCRE
 enum { PRL_ACT_DISCRETE = 0, PRL_ACT_CONTINUOUS = 1 };                                     /* rge:159-165 */
 enum { PRL_TERM_LATE = 0, PRL_TERM_EARLY = 1, PRL_TERM_HYBRID = 2 };                       /* rge:142-147 */
 enum { PRL_PAINT_FAST = 0, PRL_PAINT_NORMAL = 1 };                                         /* rob:171-172 */
+enum { PRL_COLOR_RGB = 0, PRL_COLOR_HSI = 1 };                                            /* rge:156 COLOR_MODE */
 
 #define PRL_STATE_DOUBLES 16     /* per-env scalar state record, see prl_batch_get_state */
 #define PRL_MAX_DISCRETE 64
@@ -116,6 +117,10 @@ typedef struct {
     int32_t paint_method;
     int32_t max_episode_len, expected_episode_len;
     int32_t auto_reset;              /* 1: a finished env is reset inside the step kernel */
+    int32_t color_mode;              /* PRL_COLOR_RGB: a texel is painted or not.  PRL_COLOR_HSI (bpw:384-434): every
+                                        front texel carries a uint8 that shots lower by 1..26 per hit (wrapping, as
+                                        the reference's numpy uint8 does); "painted" for observations stays byte == 255 */
+    int32_t reserved_;
     double switch_threshold;
     double paint_radius, step_size;  /* PaintToolProfile.PAINT_RADIUS / STEP_SIZE (bpw:40-43), default 0.051 both;
                                         the part must have been built and packed for the same radius */
@@ -169,6 +174,9 @@ int prl_batch_observe(PrlBatch *batch, double *obs, void *stream);
 /* Replaces get_job_status / get_texture_image style read-back (bpw:727-738): coverage bits in
  * device sample order, u64[N][mask_stride]. */
 int prl_batch_get_mask(PrlBatch *batch, uint64_t *painted, void *stream);
+/* COLOR_MODE 'HSI' only: the thickness byte of every sample, u8[N][64 * mask_stride] in device sample order
+ * (what bpw texels[get_texel(i, j)] holds for the front samples). */
+int prl_batch_get_thickness(PrlBatch *batch, uint8_t *thick, void *stream);
 /* Per-env scalar state f64[N][PRL_STATE_DOUBLES]: pose[3] quat[4] last_turning_angle total_reward
  * total_return {i32 terminate, terminate_counter} {i32 last_on_part, step_counter}
  * {u32 episode_count, i32 facet_hint} last_episode_return last_episode_reward

@@ -44,6 +44,7 @@ enum { OBS_SECTION = 0, OBS_GRID = 1, OBS_SIMPLE = 2, OBS_DISCRETE = 3 };
 enum { ACT_DISCRETE = 0, ACT_CONTINUOUS = 1 };
 enum { TERM_LATE = 0, TERM_EARLY = 1, TERM_HYBRID = 2 };
 enum { PAINT_FAST = 0, PAINT_NORMAL = 1 };
+enum { COLOR_RGB = 0, COLOR_HSI = 1 };
 
 typedef struct {
     /* samples, canonical order (ascending j*W+i) */
@@ -86,6 +87,8 @@ typedef struct {
     double switch_threshold, max_possible_point;
     double paint_radius, step_size;                      /* PaintToolProfile (bpw:40-43) */
     const double *act_delta1, *act_delta2, *act_angle;   /* [n_discrete] host table */
+    int32_t color_mode;                                  /* 0 = 'RGB', 1 = 'HSI' (rge:156, bpw:384-434) */
+    int32_t pad_;
 } OrConfig;
 
 typedef struct {
@@ -281,6 +284,48 @@ static int apply_paint(int words, uint64_t *painted, uint64_t *last, const uint6
     return succeeded;
 }
 
+/* COLOR_MODE = 'HSI' (bpw:384-434 HSIColorHandler.change_pixels + bpw:572-577 _paint), as the reference behaves:
+ * every front texel carries a uint8 (255 after the label pass, bpw:586); a shot subtracts from each hit texel
+ *     quantity = int(TARGET_MAX * (1 - (d / r)**2) ** (BETA - 1)) + 1,   TARGET_MAX = 25, BETA = 2,
+ * d = distance of the sample to the shot centre (scipy minkowski_distance: sqrt((dx^2 + dy^2) + dz^2)), r = the
+ * largest d of the shot, unless the byte is already 0 (is_changed, bpw:392-394); the subtraction is numpy uint8
+ * arithmetic and wraps below zero (the "bugs here" of bpw:393).  The shot's "succeed counter" is the float sum of
+ * quantity / 255 over the texels it changed (summed here in ascending sample order: the reference sums in cKDTree
+ * traversal order, so the last bits of rewards are not pinned -- tests compare them to 1e-12).  What the
+ * observation and get_job_status call "painted" stays RGBColorHandler.is_changed, byte == 255 (bpw:723-725): every
+ * texel reads painted until its first deposit.  `painted` holds that status bit, `thick` the bytes.
+ * A shot that hits no sample raises ValueError in the reference (max of an empty array); here it deposits nothing. */
+static double apply_paint_hsi(const OrPart *p, int words, uint64_t *painted, uint64_t *last, const uint64_t *cur,
+                              uint64_t *uni, uint8_t *thick, const double *c) {
+    double r = -1.0, succeeded = 0.0;
+    for (int s = 0; s < p->n_samples; ++s)
+        if ((cur[s >> 6] >> (s & 63)) & 1) {
+            const double *x = p->sample_pos + 3 * s;
+            double dx = c[0] - x[0], dy = c[1] - x[1], dz = c[2] - x[2];
+            double d = sqrt((dx * dx + dy * dy) + dz * dz);
+            if (d > r) r = d;
+        }
+    for (int s = 0; s < p->n_samples; ++s)
+        if ((cur[s >> 6] >> (s & 63)) & 1) {
+            const double *x = p->sample_pos + 3 * s;
+            double dx = c[0] - x[0], dy = c[1] - x[1], dz = c[2] - x[2];
+            double d = sqrt((dx * dx + dy * dy) + dz * dz);
+            double q = d / r;
+            int quantity = (int)(25 * (1 - q * q)) + 1;
+            if (thick[s] != 0) {
+                thick[s] = (uint8_t)(thick[s] - quantity);
+                succeeded += quantity / 255.0;
+            }
+            if (thick[s] == 255) painted[s >> 6] |= (uint64_t)1 << (s & 63);
+            else painted[s >> 6] &= ~((uint64_t)1 << (s & 63));
+        }
+    for (int w = 0; w < words; ++w) {
+        uni[w] |= cur[w] & ~last[w];
+        last[w] = cur[w];
+    }
+    return succeeded;
+}
+
 /* bpw:568-570 fast_paint: all samples with |x - c|^2 <= r^2 */
 static void ball_query(const OrPart *p, double radius, const double *c, uint64_t *cur) {
     const double r2 = radius * radius;
@@ -418,7 +463,7 @@ static void observation(const OrPart *p, const OrConfig *c, const OrEnv *e, cons
 
 /* rge:370-387 reset + rob:366-372 + bpw:706-712 */
 void or_reset(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted, uint64_t *last,
-              int n, const uint8_t *mask, const int32_t *start_idx, double *obs) {
+              int n, const uint8_t *mask, const int32_t *start_idx, double *obs, uint8_t *thick) {
     int words = or_mask_words(p), od = or_obs_dim(c);
     for (int i = 0; i < n; ++i) {
         if (mask && !mask[i]) continue;
@@ -426,6 +471,10 @@ void or_reset(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted,
         int si = start_idx[i];
         memset(painted + (size_t)i * words, 0, sizeof(uint64_t) * words);
         memset(last + (size_t)i * words, 0, sizeof(uint64_t) * words);
+        if (c->color_mode == COLOR_HSI) {               /* bpw:586 front label (1,1,1): every byte 255 = "painted" */
+            memset(thick + (size_t)i * p->n_samples, 255, (size_t)p->n_samples);
+            for (int s = 0; s < p->n_samples; ++s) painted[(size_t)i * words + (s >> 6)] |= (uint64_t)1 << (s & 63);
+        }
         memcpy(e->pose, p->start_pos + 3 * si, sizeof(double) * 3);
         memcpy(e->quat, p->start_quat + 4 * si, sizeof(double) * 4);
         e->terminate = 0; e->terminate_counter = 0; e->last_on_part = 1; e->last_turning_angle = 0;
@@ -456,7 +505,7 @@ static void direction(const OrConfig *c, const double *a, double *x, double *y) 
 
 /* rge:349-368 step, rob:383-433 apply_action, rob:302-329 _get_actions */
 void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_all, uint64_t *last_all,
-             int n, const void *actions, double *obs, double *reward, uint8_t *done, double *info) {
+             int n, const void *actions, double *obs, double *reward, uint8_t *done, double *info, uint8_t *thick_all) {
     int words = or_mask_words(p), od = or_obs_dim(c);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 8) num_threads(or_threads)
@@ -488,7 +537,7 @@ void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_a
         tcp_orn_norm(e->pose, e->quat, cur_norm);
         double d1 = delta1 / PAINT_PER_ACTION, d2 = delta2 / PAINT_PER_ACTION;
         memset(uni, 0, sizeof(uint64_t) * words);
-        int succeeded = 0;
+        double succeeded = 0;                                   /* an integer count in RGB mode, a float sum in HSI mode */
         for (int k = 0; k < PAINT_PER_ACTION; ++k) {
             double pos[3], orn[3], quat[4];
             int on = guided_point(p, cur_pose, cur_norm, d1, d2, pos, orn);
@@ -511,17 +560,20 @@ void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_a
                 double center[3];
                 transform_point(pos, quat, tip, center);        /* rob:277-278 */
                 ball_query(p, c->paint_radius, center, cur);
-                succeeded += apply_paint(words, painted, last, cur, uni);
+                if (c->color_mode == COLOR_HSI)
+                    succeeded += apply_paint_hsi(p, words, painted, last, cur, uni, thick_all + (size_t)i * p->n_samples, center);
+                else
+                    succeeded += apply_paint(words, painted, last, cur, uni);
             } else if (cone_query(p, pos, quat, cur) > 0) {
                 succeeded += apply_paint(words, painted, last, cur, uni);
             }
         }
         int pixel_counter = 0;
         for (int w = 0; w < words; ++w) pixel_counter += popcount64(uni[w]);
-        double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;
+        double rate = pixel_counter ? succeeded / (double)pixel_counter : 0.0;
         if (e->terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) e->terminate = 1;
 
-        double rew = (double)succeeded / 100;                   /* rge:321-325 */
+        double rew = succeeded / 100;                           /* rge:321-325 */
         e->total_reward += rew;
         double pen = 0.2;                                       /* rge:327-340 */
         if (c->overlap_penalty) pen += 0.1 * (1 - rate);

@@ -36,7 +36,7 @@ class OrConfig(C.Structure):
                 ('paint_method', C.c_int32), ('max_episode_len', C.c_int32), ('expected_episode_len', C.c_int32),
                 ('switch_threshold', C.c_double), ('max_possible_point', C.c_double),
                 ('paint_radius', C.c_double), ('step_size', C.c_double),
-                ('act_delta1', _dp), ('act_delta2', _dp), ('act_angle', _dp)]
+                ('act_delta1', _dp), ('act_delta2', _dp), ('act_angle', _dp), ('color_mode', C.c_int32), ('pad_', C.c_int32)]
 
 
 class OrEnv(C.Structure):
@@ -129,7 +129,8 @@ class Oracle(object):
     def __init__(self, tables, n_envs, obs_mode='section', obs_grad=4, action_mode='discrete', action_dim=1,
                  n_discrete=4, termination_mode='late', turning_penalty=False, overlap_penalty=False,
                  paint_method='fast', max_episode_len=245, expected_episode_len=245, switch_threshold=0.9,
-                 max_possible_point=9148, start_points=None, threads=1, paint_radius=None, step_size=0.051):
+                 max_possible_point=9148, start_points=None, threads=1, paint_radius=None, step_size=0.051,
+                 color_mode='RGB'):
         self.lib = _load()
         t = tables
         self.tables = t
@@ -190,6 +191,9 @@ class Oracle(object):
         c.switch_threshold, c.max_possible_point = switch_threshold, max_possible_point
         c.paint_radius = float(getattr(t, 'paint_radius', 0.051) if paint_radius is None else paint_radius)
         c.step_size = float(step_size)
+        c.color_mode = {'RGB': 0, 'HSI': 1}[color_mode]
+        if color_mode == 'HSI' and paint_method != 'fast':
+            raise NotImplementedError("COLOR_MODE='HSI' is restated for PAINT_METHOD='fast' only")
         self._act = discrete_action_table(n_discrete, step_size)
         c.act_delta1, c.act_delta2, c.act_angle = (_ptr(a) for a in self._act)
         self.cfg = c
@@ -199,6 +203,7 @@ class Oracle(object):
         self.env = (OrEnv * self.n)()
         self.painted = np.zeros((self.n, self.words), dtype=np.uint64)
         self.last = np.zeros((self.n, self.words), dtype=np.uint64)
+        self.thick = np.zeros((self.n, p.n_samples), dtype=np.uint8)     # HSI mode: the texel bytes
         self.n_start = sp.shape[0]
         self.set_threads(threads)
 
@@ -214,7 +219,8 @@ class Oracle(object):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         self.lib.or_reset(C.byref(self.part), C.byref(self.cfg), self.env, self.painted.ctypes.data_as(C.c_void_p),
                           self.last.ctypes.data_as(C.c_void_p), C.c_int(self.n),
-                          None if m is None else m.ctypes.data_as(C.c_void_p), _ptr(start_idx), _ptr(obs))
+                          None if m is None else m.ctypes.data_as(C.c_void_p), _ptr(start_idx), _ptr(obs),
+                          self.thick.ctypes.data_as(C.c_void_p))
         return obs
 
     def step(self, actions):
@@ -229,7 +235,8 @@ class Oracle(object):
         info = np.zeros((self.n, 2), dtype=np.float64)
         self.lib.or_step(C.byref(self.part), C.byref(self.cfg), self.env, self.painted.ctypes.data_as(C.c_void_p),
                          self.last.ctypes.data_as(C.c_void_p), C.c_int(self.n), a.ctypes.data_as(C.c_void_p),
-                         _ptr(obs), _ptr(rew), done.ctypes.data_as(C.c_void_p), _ptr(info))
+                         _ptr(obs), _ptr(rew), done.ctypes.data_as(C.c_void_p), _ptr(info),
+                         self.thick.ctypes.data_as(C.c_void_p))
         return obs, rew, done.astype(bool), info
 
     def set_pose(self, i, pose, orn):

@@ -51,7 +51,7 @@ class PrlConfig(C.Structure):
         ('action_mode', C.c_int32), ('action_dim', C.c_int32), ('n_discrete', C.c_int32),
         ('termination_mode', C.c_int32), ('turning_penalty', C.c_int32), ('overlap_penalty', C.c_int32),
         ('paint_method', C.c_int32), ('max_episode_len', C.c_int32), ('expected_episode_len', C.c_int32),
-        ('auto_reset', C.c_int32), ('switch_threshold', C.c_double), ('paint_radius', C.c_double),
+        ('auto_reset', C.c_int32), ('color_mode', C.c_int32), ('reserved_', C.c_int32), ('switch_threshold', C.c_double), ('paint_radius', C.c_double),
         ('step_size', C.c_double), ('max_possible_point', C.c_double * 8),
         ('seed', C.c_uint64),
         ('act_delta1', C.c_double * MAX_DISCRETE), ('act_delta2', C.c_double * MAX_DISCRETE),
@@ -81,6 +81,7 @@ SYMBOLS = {
                                        _vp, _vp, C.c_uint64, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_state': (C.c_int, [_vp, _vp, _vp]),
+    'prl_batch_get_thickness': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_returns': (C.c_int, [_vp, _vp, _vp]),
     'prl_ray_batch': (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'prl_batch_timing_enable': (C.c_int, [_vp, C.c_int]),

@@ -193,6 +193,20 @@ class BatchedPaintEnv(object):
         words = self.painted_words()[env].cpu().numpy().view(np.uint64)
         return self.parts[int(self.env_part_id[env])].mask_to_canonical(words)
 
+    def thickness(self, env=None):
+        """COLOR_MODE='HSI': uint8 thickness bytes in canonical sample order -- (N, P) array, or (P,) for one env."""
+        torch = _torch()
+        raw = torch.zeros((self.n_envs, self.mask_stride * 64), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.prl_batch_get_thickness(self._batch, self._ptr(raw), self._stream()),
+                       'prl_batch_get_thickness')
+        raw = raw.cpu().numpy()
+        if env is not None:
+            return raw[env][self.parts[int(self.env_part_id[env])].inv_perm]
+        if len(self.parts) != 1:
+            raise ValueError('thickness() of a whole mixed batch: ask per env')
+        return raw[:, self.parts[0].inv_perm]
+
     def state(self):
         """dict of numpy arrays decoded from the per-env state records (include/paintrl.h)."""
         torch = _torch()

@@ -9,6 +9,7 @@ OBS_MODES = {'section': 0, 'grid': 1, 'simple': 2, 'discrete': 3}
 ACTION_MODES = {'discrete': 0, 'continuous': 1}
 TERMINATION_MODES = {'late': 0, 'early': 1, 'hybrid': 2}
 PAINT_METHODS = {'fast': 0, 'normal': 1}
+COLOR_MODES = {'RGB': 0, 'HSI': 1}
 
 
 class PaintToolProfile(object):
@@ -54,7 +55,7 @@ def discrete_action_table(n, step_size=0.051):
 def make_config(obs_mode='section', obs_grad=4, action_mode='discrete', action_dim=1, n_discrete=4,
                 termination_mode='late', turning_penalty=False, overlap_penalty=False, paint_method='fast',
                 max_episode_len=245, expected_episode_len=245, switch_threshold=0.9, max_possible_point=9148,
-                auto_reset=False, seed=0, paint_radius=0.051, step_size=0.051):
+                auto_reset=False, seed=0, paint_radius=0.051, step_size=0.051, color_mode='RGB'):
     """Build the PrlConfig POD.  ``max_possible_point`` is a number or one number per part id."""
     c = _lib.PrlConfig()
     c.obs_mode, c.obs_grad = OBS_MODES[obs_mode], int(obs_grad)
@@ -62,6 +63,7 @@ def make_config(obs_mode='section', obs_grad=4, action_mode='discrete', action_d
     c.termination_mode = TERMINATION_MODES[termination_mode]
     c.turning_penalty, c.overlap_penalty = int(bool(turning_penalty)), int(bool(overlap_penalty))
     c.paint_method = PAINT_METHODS[paint_method]
+    c.color_mode = COLOR_MODES[color_mode]
     c.max_episode_len, c.expected_episode_len = int(max_episode_len), int(expected_episode_len)
     c.auto_reset = int(bool(auto_reset))
     c.switch_threshold = float(switch_threshold)

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
     reset_state(P, S, start);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    if (C.color_mode == PRL_COLOR_HSI) reset_thickness<KW>(P, a.thick + (size_t)env * 64 * a.mask_stride, lane, painted);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wave_lds<GENSEC>().cnt);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // One launch = one batched step: one wavefront per env, four envs per workgroup (prl_step.hpp holds the step).
-template <int KW, bool NORMAL, bool GENSEC>
+template <int KW, bool NORMAL, bool GENSEC, bool HSI = false>
 __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<KW, NORMAL, GENSEC, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+    const int dn = step_env<KW, NORMAL, GENSEC, true, HSI>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                       new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<0, false, GENSEC, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+    const int dn = step_env<0, false, GENSEC, true, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                     new_angle, StepRows{&a}, wl);
     store_state_live(state_rec, S, lane, dn != 0);
 }
@@ -224,6 +225,8 @@ constexpr int FRAG_WAVES = 4;      // envs (= waves) per workgroup = real rows o
 struct FragmentRows {
     const FragmentArgs CAS *f;
     int t, n, od;
+    __device__ __forceinline__ uint8_t *thick() const { return nullptr; }
+    __device__ __forceinline__ int mask_stride() const { return 0; }
     __device__ __forceinline__ double *obs() const { return f->obs + (size_t)(t + 1) * n * od; }
     __device__ __forceinline__ double *final_obs() const { return f->final_obs ? f->final_obs + (size_t)t * n * od : nullptr; }
     __device__ __forceinline__ double *reward() const { return f->reward + (size_t)t * n; }
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             __shared__ int s_cand[FRAG_WAVES][64];
             __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
             const WaveLds wl{s_cand[wave], s_centres[wave], nullptr};
-            const int dn = step_env<KW, false, false, true>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+            const int dn = step_env<KW, false, false, true, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                             new_angle, row, wl);
             store_state_live(state_rec, S, lane, dn != 0);
         }
@@ -437,6 +440,7 @@ struct PrlBatch {
     PrlConfig *cfg_dev = nullptr;
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
+    uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     double *state = nullptr;
     int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
     long long launch_no = 0;
@@ -663,15 +667,20 @@ int check_config(const PrlConfig *c) {
     }
     if (c->termination_mode < 0 || c->termination_mode > 2) return fail(PRL_E_INVALID, "termination_mode");
     if (c->paint_method != PRL_PAINT_FAST && c->paint_method != PRL_PAINT_NORMAL) return fail(PRL_E_INVALID, "paint_method");
+    if (c->color_mode != PRL_COLOR_RGB && c->color_mode != PRL_COLOR_HSI) return fail(PRL_E_INVALID, "color_mode");
+    if (c->color_mode == PRL_COLOR_HSI && c->paint_method != PRL_PAINT_FAST)
+        return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for PAINT_METHOD 'fast'");
     if (c->max_episode_len < 1 || c->expected_episode_len < 1) return fail(PRL_E_INVALID, "episode lengths");
     if (!(c->paint_radius > 0) || !(c->step_size > 0)) return fail(PRL_E_INVALID, "paint_radius and step_size must be positive");
     return PRL_OK;
 }
 
 template <int KW>
-void launch_step(const StepArgs &a, bool normal, bool gensec, hipStream_t s) {
+void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, hipStream_t s) {
     const dim3 grid((a.n_envs + 3) / 4), block(256);
-    if (normal && gensec) hipLaunchKernelGGL((step_kernel<KW, true, true>), grid, block, 0, s, a);
+    if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true>), grid, block, 0, s, a);
+    else if (hsi) hipLaunchKernelGGL((step_kernel<KW, false, false, true>), grid, block, 0, s, a);
+    else if (normal && gensec) hipLaunchKernelGGL((step_kernel<KW, true, true>), grid, block, 0, s, a);
     else if (normal) hipLaunchKernelGGL((step_kernel<KW, true, false>), grid, block, 0, s, a);
     else if (gensec) hipLaunchKernelGGL((step_kernel<KW, false, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((step_kernel<KW, false, false>), grid, block, 0, s, a);
@@ -716,6 +725,7 @@ StepArgs base_args(PrlBatch *b) {
     a.mask_stride = b->mask_stride;
     a.painted = b->painted;
     a.last = b->last;
+    a.thick = b->thick;
     a.state = b->state;
     return a;
 }
@@ -804,6 +814,10 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     for (int i = 0; i < n_parts; ++i)
         if (parts[i]->dev.n_words > b->mask_stride) b->mask_stride = parts[i]->dev.n_words;
     b->kw = (b->mask_stride + 63) / 64;
+    if (b->kw > KW_MAX && cfg->color_mode == PRL_COLOR_HSI) {
+        delete b;
+        return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for parts of at most %d samples", 64 * 64 * KW_MAX);
+    }
     if (b->kw > KW_MAX && cfg->paint_method == PRL_PAINT_NORMAL) {
         const int words = b->mask_stride;
         delete b;
@@ -826,6 +840,10 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->painted), mask_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last), mask_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->state), state_bytes);
+    if (e == hipSuccess && cfg->color_mode == PRL_COLOR_HSI) {
+        e = hipMalloc(reinterpret_cast<void **>(&b->thick), mask_bytes * 8);        // one byte per sample
+        if (e == hipSuccess) e = hipMemset(b->thick, 255, mask_bytes * 8);
+    }
     if (e == hipSuccess) e = hipMemset(b->painted, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->last, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->state, 0, state_bytes);
@@ -848,6 +866,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->env_part_dev);
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
+    (void)hipFree(b->thick);
     (void)hipFree(b->state);
     delete b;
 }
@@ -906,7 +925,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     a.final_obs = final_obs;
     a.start_idx = start_idx;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL;
+    const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL, hsi = b->cfg.color_mode == PRL_COLOR_HSI;
     const bool timed = b->timing_every > 0 && (b->launch_no++ % b->timing_every) == 0;
     if (timed) {
         if (b->ev_used == b->ev_start.size()) {
@@ -919,10 +938,10 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
     switch (b->kw) {
-    case 1: launch_step<1>(a, normal, general_section(b->cfg), s); break;
-    case 2: launch_step<2>(a, normal, general_section(b->cfg), s); break;
-    case 3: launch_step<3>(a, normal, general_section(b->cfg), s); break;
-    case 4: launch_step<4>(a, normal, general_section(b->cfg), s); break;
+    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, s); break;
+    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, s); break;
+    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, s); break;
+    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, s); break;
     default: {                                     // a part with more than 16 384 samples: masks in LDS
         const int rc = launch_big(general_section(b->cfg) ? step_kernel_big<true> : step_kernel_big<false>, a, 3, s);
         if (rc) return rc;
@@ -963,6 +982,14 @@ int prl_batch_get_mask(PrlBatch *b, uint64_t *painted, void *stream) {
     return PRL_OK;
 }
 
+int prl_batch_get_thickness(PrlBatch *b, uint8_t *thick, void *stream) {
+    if (!b || !thick) return fail(PRL_E_INVALID, "null argument");
+    if (!b->thick) return fail(PRL_E_INVALID, "prl_batch_get_thickness: the batch was not created with COLOR_MODE 'HSI'");
+    HIP_TRY(hipMemcpyAsync(thick, b->thick, (size_t)b->n_envs * b->mask_stride * 64, hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return PRL_OK;
+}
+
 int prl_batch_get_state(PrlBatch *b, double *state, void *stream) {
     if (!b || !state) return fail(PRL_E_INVALID, "null argument");
     HIP_TRY(hipMemcpyAsync(state, b->state, (size_t)b->n_envs * PRL_STATE_DOUBLES * sizeof(double),
@@ -996,6 +1023,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     const PrlConfig &c = b->cfg;
     if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
     if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: parts of at most %d samples", 64 * 64 * KW_MAX);
+    if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: COLOR_MODE 'RGB'");
     if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
         return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for "
                                        "section / discrete observations");

@@ -94,6 +94,7 @@ struct StepArgs {
     const int *env_part;          // device, or nullptr
     int n_envs, mask_stride;
     uint64_t *painted, *last;
+    uint8_t *thick;               // COLOR_MODE 'HSI': one byte per sample, [n_envs][64 * mask_stride]; else nullptr
     double *state;
     const void *actions;
     double *obs, *reward, *info, *final_obs;
@@ -213,6 +214,25 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     v += dpp0_u64<0x142, 0xa>(v);
     v += dpp0_u64<0x143, 0xc>(v);
     return bcast_u64(v, 63);
+}
+
+// Wave-wide sum of doubles (same shifts; a lane without a source adds +0.0).  The order of the additions is this
+// tree's, not any reference order: only used where the result is compared with a tolerance (HSI deposits).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp0_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp0_d<0x111, 0xf>(v);
+    v += dpp0_d<0x112, 0xf>(v);
+    v += dpp0_d<0x114, 0xf>(v);
+    v += dpp0_d<0x118, 0xf>(v);
+    v += dpp0_d<0x142, 0xa>(v);
+    v += dpp0_d<0x143, 0xc>(v);
+    return bcast_d(v, 63);
 }
 
 // A wave-uniform double computed by the vector ALU sits in a VGPR pair; moving it to scalar

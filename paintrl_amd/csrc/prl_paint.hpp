@@ -190,4 +190,78 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     }
 }
 
+// ---------------------------------------------------------------- COLOR_MODE = 'HSI': thickness bytes (bpw:384-434)
+// As the reference behaves (oracle/paint_oracle.c apply_paint_hsi states it in full): each front texel carries a
+// uint8, 255 after reset; shot by shot every hit texel whose byte is not 0 loses
+//     quantity = int(25 (1 - (d / r)^2)) + 1,     d = distance to the shot centre, r = the shot's largest d,
+// in wrapping uint8 arithmetic, and contributes quantity / 255 to the shot's "succeed counter".  The status bit the
+// observation reads stays "byte == 255" (bpw:723-725).  The five shots run one after the other here -- r belongs
+// to a shot, and a byte may be hit by several -- two passes over a shot's 3 x 3 cell block each: the largest
+// distance, then the deposits.  `thick` is this env's row of bytes in HBM (device sample order); only the words a
+// shot touches are read and written.  The float sum is reduced in lane order: tests allow 1e-12 on rewards.
+template <int KW>
+__device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
+                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter) {
+    const double r2 = radius * radius;
+    uint64_t uni[KW_MAX] = {0, 0, 0, 0};
+    double succ_l = 0.0;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        const double c0 = cen_lds[3 * shot], c1 = cen_lds[3 * shot + 1], c2 = cen_lds[3 * shot + 2];
+        const int icx = rfl(cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx));
+        const int icy = rfl(cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny));
+        const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
+        uint64_t cur[KW_MAX] = {0, 0, 0, 0};
+        double dmax_l = -1.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double rmax = pass ? sqrt(wave_max_d(dmax_l)) : 0.0;       // = max of the sqrt's: sqrt is monotone
+            if (pass && !(rmax >= 0.0)) break;                               // no sample hit: nothing to deposit
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int begin = R.begin[r], end = begin + R.count[r];
+                if (R.count[r] <= 0) continue;
+                for (int w = begin >> 6; w <= ((end - 1) >> 6); ++w) {
+                    const int s = (w << 6) + lane;
+                    const double dx = c0 - ldg(P.samp[0], s), dy = c1 - ldg(P.samp[1], s), dz = c2 - ldg(P.samp[2], s);
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const bool hit = s >= begin && s < end && dd <= r2;
+                    if (!pass) {
+                        if (hit) dmax_l = dd > dmax_l ? dd : dmax_l;
+                        continue;
+                    }
+                    const uint64_t b = __ballot(hit);
+                    if (b == 0) continue;
+                    uint8_t v = thick[s];
+                    if (hit) {
+                        const double q = sqrt(dd) / rmax;
+                        const int quantity = (int)(25 * (1 - q * q)) + 1;
+                        if (v != 0) {
+                            v = (uint8_t)(v - quantity);
+                            succ_l += quantity / 255.0;
+                            thick[s] = v;
+                        }
+                    }
+                    const uint64_t stat = __ballot(hit && v == 255);
+                    const int owner = w & 63, slot = w >> 6;
+#pragma unroll
+                    for (int k = 0; k < KW; ++k)
+                        if (k == slot && lane == owner) {
+                            painted[k] = (painted[k] & ~b) | stat;
+                            cur[k] |= b;                 // (a word can be visited from two rows' ranges: disjoint lanes)
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {                   // bpw:575-576: valid = affected minus the previous shot's
+            uni[k] |= cur[k] & ~last[k];
+            last[k] = cur[k];
+        }
+    }
+    uint32_t pix_l = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
+    pixel_counter = (int)wave_sum_u64(pix_l);
+    succeeded = wave_sum_d(succ_l);
+}
+
 }  // namespace

@@ -47,6 +47,18 @@ __device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int
     }
 }
 
+// COLOR_MODE 'HSI' reset (bpw:586 front label (1,1,1), bpw:706-707): every byte 255, every real sample "painted".
+template <int KW>
+__device__ __forceinline__ void reset_thickness(PartRef P, uint8_t *thick, int lane, uint64_t painted[KW_MAX]) {
+    uint64_t *t8 = reinterpret_cast<uint64_t *>(thick);
+    for (int i = lane; i < 8 * P.n_words; i += 64) t8[i] = ~0ull;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int w = lane + 64 * k;
+        painted[k] = w < P.n_words ? ldg(P.word_valid, w) : 0;
+    }
+}
+
 // Advances env `env` by one step.  In: the motion part of S (load_state_motion) and the coverage masks in
 // registers; with LATE_ACC the episode accumulators are read from `state_rec` only after the five sub-shots (the
 // per-step kernel: their scalar registers are then free during the shots), otherwise S is complete on entry (the
@@ -64,13 +76,15 @@ __device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int
 // evaluated where they are used.  Both implementations read the kernel arguments through the constant address
 // space at that point; handing the kernel's by-value argument struct down by reference instead makes the compiler
 // copy all of it into registers at kernel entry.
-template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, typename MaskIO, typename RowIO>
+// HSI = COLOR_MODE 'HSI' (bpw:384-434): thickness bytes in a.thick, float "succeed counter" (prl_paint.hpp).
+template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, bool HSI, typename MaskIO, typename RowIO>
 __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                         const double *state_rec, const MaskIO &masks, double delta1, double delta2,
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
     // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
     constexpr bool BIG = KW == 0;
     static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in registers: small parts only");
+    static_assert(!(HSI && (BIG || NORMAL)), "thickness mode is built for ball-query painting of small parts");
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     if constexpr (NORMAL || BIG) masks.template load<KW>(painted, last);
     const int counter_before = S.terminate_counter;
@@ -179,7 +193,11 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     STAMP(PH_LOAD);
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
-    if constexpr (NORMAL) {
+    double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
+    if constexpr (HSI) {
+        paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
+                            succeeded_f, pixel_counter);
+    } else if constexpr (NORMAL) {
         uint32_t pix_l = 0;
 #pragma unroll
         for (int k = 0; k < KW; ++k) pix_l += __popcll(n_uni[k]);
@@ -206,11 +224,12 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
     S.last_angle = new_angle;
     S.facet_hint = facet_hint;
-    const double rate = pixel_counter ? (double)succeeded / (double)pixel_counter : 0.0;      // rob:425-426
+    if constexpr (!HSI) succeeded_f = (double)succeeded;
+    const double rate = pixel_counter ? succeeded_f / (double)pixel_counter : 0.0;           // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
 
     // ---- reward, penalty, termination   rge:321-340, 289-304
-    const double rew = (double)succeeded / 100;
+    const double rew = succeeded_f / 100;
     S.total_reward += rew;
     double pen = 0.2;
     if (C.overlap_penalty) pen += 0.1 * (1 - rate);
@@ -264,7 +283,10 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             painted[k] = 0;
             last[k] = 0;
         }
-        if constexpr (BIG) {
+        if constexpr (HSI) {                         // every byte 255 again, every status bit "painted" (bpw:586, 706-707)
+            reset_thickness<KW>(P, a.thick() + (size_t)env * 64 * a.mask_stride(), lane, painted);
+            observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
+        } else if constexpr (BIG) {
             masks.clear();
             observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, obs_row, wl.cnt);
         } else {
@@ -279,6 +301,8 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
 // Output rows of the per-step kernel: the launch's StepArgs, read from the kernel-argument segment when used.
 struct StepRows {
     const StepArgs CAS *k;
+    __device__ __forceinline__ uint8_t *thick() const { return k->thick; }
+    __device__ __forceinline__ int mask_stride() const { return k->mask_stride; }
     __device__ __forceinline__ double *obs() const { return k->obs; }
     __device__ __forceinline__ double *final_obs() const { return k->final_obs; }
     __device__ __forceinline__ double *reward() const { return k->reward; }

@@ -133,7 +133,7 @@ class PaintGymEnv(spaces.Env):
             overlap_penalty=self.OVERLAP_PENALTY, paint_method=Robot.PAINT_METHOD, max_episode_len=self.EPISODE_MAX_LENGTH,
             expected_episode_len=self.Expected_Episode_Length, switch_threshold=self.SWITCH_THRESHOLD,
             max_possible_point=self._max_possible_point, paint_radius=PaintToolProfile.PAINT_RADIUS,
-            step_size=PaintToolProfile.STEP_SIZE)
+            step_size=PaintToolProfile.STEP_SIZE, color_mode=self.COLOR_MODE)
         self.robot = Robot(self)
         # one device buffer for everything a step returns, so that step() costs ONE device-to-host copy:
         # obs[od] | reward | info[2] | state record[16] | done (u8 in the last 8 bytes)
@@ -161,8 +161,8 @@ class PaintGymEnv(spaces.Env):
         self.TURNING_PENALTY = config['TURNING_PENALTY']
         self.OVERLAP_PENALTY = config['OVERLAP_PENALTY']
         self.COLOR_MODE = config['COLOR_MODE']
-        if self.COLOR_MODE != 'RGB':
-            raise NotImplementedError("COLOR_MODE='HSI' (thickness mode) is out of scope, see DESIGN.md")
+        if self.COLOR_MODE not in _config.COLOR_MODES:
+            raise ValueError("COLOR_MODE must be 'RGB' or 'HSI', not %r" % (self.COLOR_MODE,))
 
     def _obs_out(self, row):
         return np.array(row.cpu().numpy(), dtype=np.float64)
@@ -217,8 +217,11 @@ class PaintGymEnv(spaces.Env):
         """(H, W, 3) uint8 texture: painted texels red, unpainted front texels grey (bpw:585-592, 737-738)."""
         t = self._tables
         img = np.zeros((t.tex_h, t.tex_w, 3), dtype=np.uint8)
-        bits = self._batch.painted_bits(0)
         pix = t.sample_pix
+        if self.COLOR_MODE == 'HSI':              # the three channels of a front texel carry the same byte (bpw:404-406)
+            img[pix[:, 1], pix[:, 0]] = self._batch.thickness(0)[:, None]
+            return img
+        bits = self._batch.painted_bits(0)
         img[pix[:, 1], pix[:, 0]] = (191, 191, 191)
         img[pix[bits, 1], pix[bits, 0]] = (255, 0, 0)
         return img

@@ -40,7 +40,7 @@ def sha(a):
 class RefDriver(object):
     """One constructed reference env (START_POINT_MODE='all'), re-configured in place per episode."""
 
-    def __init__(self, root, part_no, paint_radius=None, step_size=None):
+    def __init__(self, root, part_no, paint_radius=None, step_size=None, extra=None):
         ref_import.load_reference('hull')
         prof = sys.modules['bullet_paint_wrapper'].PaintToolProfile
         prof.PAINT_RADIUS = 0.051 if paint_radius is None else paint_radius
@@ -48,7 +48,7 @@ class RefDriver(object):
         self.tool = (prof.PAINT_RADIUS, prof.STEP_SIZE)
         t0 = time.time()
         self.env, self.part = ref_import.make_env(root, part_no=part_no, obs_mode='section', obs_grad=4,
-                                                  extra={'START_POINT_MODE': 'all'})
+                                                  extra=dict({'START_POINT_MODE': 'all'}, **(extra or {})))
         self.construct_s = time.time() - t0
         self.bpw = sys.modules['bullet_paint_wrapper']
         self.rob = sys.modules['robot']

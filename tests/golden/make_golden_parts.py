@@ -67,6 +67,9 @@ def big_synthetic():
     synth_parts.write_synthetic_parts(root, names=('door_rr_big',))
     big = RefDriver(root, 8)
     np.savez_compressed(os.path.join(HERE, 'g0_tables_door_big.npz'), **table_digest(big))
+    # Part_Dict gives Part_NO 8 a "max possible points" of 0 (rge:115), with which every episode is "finished" after
+    # its first step (rge:292); the constant is the hand-entered knob of that table, set here to 95 % of the samples
+    big.env._max_possible_point = 36000
     eps = {}
     big.configure('section', 4, 'all')
     for s in range(3):
@@ -90,8 +93,43 @@ def reference_door_rr():
     save_episodes(os.path.join(HERE, 'episodes_reference_door_rr.npz'), eps)
 
 
+def hsi_door():
+    """COLOR_MODE='HSI' (thickness bytes, bpw:384-434) on the synthetic door: on-part policies only -- a shot that
+    hits no sample makes the reference raise (max of an empty array), such an episode is cut before that step."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    drv = RefDriver(root, 0, extra={'COLOR_MODE': 'HSI'})
+    eps = {}
+
+    def run(name, seed, policy, max_steps, want_idx):
+        try:
+            ep = drv.episode(seed, policy, max_steps=max_steps, want_idx=want_idx)
+        except ValueError:                       # off-part shot: record the part before it
+            for cut in range(max_steps - 1, 0, -1):
+                try:
+                    ep = drv.episode(seed, policy, max_steps=cut, want_idx=want_idx)
+                    break
+                except ValueError:
+                    continue
+        part = drv.part
+        ep['final_thick'] = np.array([int(part.texels[part.get_texel(*p)]) for p in drv.pix], dtype=np.uint8)
+        cfg = json.loads(str(ep['cfg']))
+        cfg['color_mode'] = 'HSI'
+        ep['cfg'] = json.dumps(cfg)
+        eps[name] = ep
+
+    drv.configure('section', 4, 'anchor')
+    run('g13_hsi_serpentine', 8, zigzag_policy_grid(), 150, 0)
+    run('g13_hsi_random', 101, random_policy(11), 30, 2)
+    drv.configure('grid', 4, 'anchor', overlap=True, turning=True)
+    run('g13_hsi_grid_overlap', 21, zigzag_policy_grid(), 80, 0)
+    save_episodes(os.path.join(HERE, 'episodes_door_hsi.npz'), eps)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['digests', 'big', 'door_rr']
+    if 'hsi' in what:
+        hsi_door()
     if 'big' in what:
         big_synthetic()
     if 'door_rr' in what:

@@ -6,8 +6,14 @@ import pytest
 import oracle
 from conftest import env_kwargs_from_cfg, load_episodes, start_points_for, synthetic_tables
 
-CASES = [(tag, n) for tag in ('door', 'sheet', 'sheet_tool') for n in sorted(load_episodes(tag))]
-PART = {'door': 'door_test', 'sheet': 'square', 'sheet_tool': 'square'}
+import os
+
+from conftest import GOLDEN
+
+TAGS = [t for t in ('door', 'sheet', 'sheet_tool', 'door_big', 'door_hsi')
+        if os.path.isfile(os.path.join(GOLDEN, 'episodes_%s.npz' % t))]
+CASES = [(tag, n) for tag in TAGS for n in sorted(load_episodes(tag))]
+PART = {'door': 'door_test', 'sheet': 'square', 'sheet_tool': 'square', 'door_big': 'door_rr_big', 'door_hsi': 'door_test'}
 
 
 def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
@@ -37,8 +43,9 @@ def test_oracle_replays_reference_episode(tag, name):
     ep = load_episodes(tag)[name]
     cfg = ep['cfg']
     tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
+    hsi = cfg.get('color_mode', 'RGB') == 'HSI'
     orc = oracle.Oracle(tables, 1, start_points=start_points_for(tables, cfg['start_mode']),
-                        **env_kwargs_from_cfg(cfg))
+                        color_mode=cfg.get('color_mode', 'RGB'), **env_kwargs_from_cfg(cfg))
     continuous = cfg['action_mode'] == 'continuous'
 
     def reset(idx):
@@ -48,9 +55,13 @@ def test_oracle_replays_reference_episode(tag, name):
         obs, rew, done, info = orc.step([a])
         return obs[0], rew[0], done[0], info[0], orc.painted_bits(0)
 
-    # continuous actions go through libm sin/cos/atan2 on both sides: tolerance, not bit-exact
-    replay(step, reset, ep, exact=not continuous, atol=1e-9)
+    # continuous actions go through libm sin/cos/atan2 on both sides: tolerance, not bit-exact; the float deposit
+    # sums of COLOR_MODE='HSI' are added in cKDTree traversal order by the reference: 1e-12
+    replay(step, reset, ep, exact=not (continuous or hsi), atol=1e-12 if hsi else 1e-9)
     st = orc.state(0)
-    if not continuous:
+    if hsi:
+        assert np.array_equal(orc.thick[0], ep['final_thick'])           # the bytes themselves are exact
+        assert np.array_equal(st['pose'], ep['final_pose']) and np.array_equal(st['quat'], ep['final_quat'])
+    elif not continuous:
         assert np.array_equal(st['pose'], ep['final_pose']) and np.array_equal(st['quat'], ep['final_quat'])
         assert st['total_return'] == float(ep['total_return'])
