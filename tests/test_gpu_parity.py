@@ -24,7 +24,10 @@ def test_gpu_replays_reference_episode(tag, name):
     ep = load_episodes(tag)[name]
     cfg = ep['cfg']
     tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
-XX
+    hsi = cfg.get('color_mode', 'RGB') == 'HSI'
+    env = _gpu_env(tables, 1, start_points_for(tables, cfg['start_mode']), color_mode=cfg.get('color_mode', 'RGB'),
+                   **env_kwargs_from_cfg(cfg))
+    continuous = cfg['action_mode'] == 'continuous'
 
     def reset(idx):
         return env.reset(start_idx=[idx]).cpu().numpy()[0]
