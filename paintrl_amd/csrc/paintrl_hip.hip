@@ -32,7 +32,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <array>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -42,6 +44,7 @@
 #include "prl_device.hpp"
 #include "prl_ray.hpp"
 #include "prl_search.hpp"
+#include "prl_cone.hpp"
 #include "prl_paint.hpp"
 #include "prl_observe.hpp"
 #include "prl_state.hpp"
@@ -608,6 +611,42 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             r[11] = (double)t->col_orient[i];                                   // 0 for pads: never entered
         }
         UP(col_rec, rec.data(), rec.size());
+        // edge neighbours for the cone beams' surface walk (prl_cone.hpp): the corners v0, v0 + e1, v0 + e2 of facets
+        // that share a vertex agree to rounding, so corners are matched on a 1e-9 m lattice; an edge that does not
+        // end up with exactly two facets (a non-manifold soup, or a corner that straddles a lattice line) gets no
+        // neighbour and the walk falls back to the wave-wide search there -- a speed matter only
+        {
+            std::map<std::array<long long, 3>, int> vid;
+            std::vector<std::array<int, 3>> corner((size_t)d.n_col_pad, std::array<int, 3>{-1, -1, -1});
+            for (int i = 0; i < d.n_col_pad; ++i) {
+                if (t->col_orient[i] == 0) continue;                           // pad
+                const double *r = rec.data() + (size_t)i * 12;
+                const double c[3][3] = {{r[0], r[1], r[2]},
+                                        {r[0] + r[3], r[1] + r[4], r[2] + r[5]},
+                                        {r[0] + r[6], r[1] + r[7], r[2] + r[8]}};
+                for (int k = 0; k < 3; ++k) {
+                    const std::array<long long, 3> q = {std::llround(c[k][0] * 1e9), std::llround(c[k][1] * 1e9),
+                                                        std::llround(c[k][2] * 1e9)};
+                    corner[i][k] = vid.emplace(q, (int)vid.size()).first->second;
+                }
+            }
+            std::map<std::pair<int, int>, std::vector<int>> edge_facets;
+            auto key = [](int a, int b) { return a < b ? std::make_pair(a, b) : std::make_pair(b, a); };
+            // edge e of a facet with corners (c0, c1 = c0 + e1, c2 = c0 + e2):  0: u = 0 -> (c0, c2);  1: v = 0 -> (c0, c1);
+            // 2: u + v = 1 -> (c1, c2)
+            static const int ea[3] = {0, 0, 1}, eb[3] = {2, 1, 2};
+            for (int i = 0; i < d.n_col_pad; ++i)
+                if (corner[i][0] >= 0)
+                    for (int e = 0; e < 3; ++e) edge_facets[key(corner[i][ea[e]], corner[i][eb[e]])].push_back(i);
+            std::vector<int32_t> enbr((size_t)d.n_col_pad * 3, -1);
+            for (int i = 0; i < d.n_col_pad; ++i)
+                if (corner[i][0] >= 0)
+                    for (int e = 0; e < 3; ++e) {
+                        const std::vector<int> &fs = edge_facets[key(corner[i][ea[e]], corner[i][eb[e]])];
+                        if (fs.size() == 2) enbr[(size_t)i * 3 + e] = fs[0] == i ? fs[1] : fs[0];
+                    }
+            UP(col_enbr, enbr.data(), enbr.size());
+        }
     }
     d.n_col_chunks = t->n_col_chunks;
     if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
@@ -714,6 +753,16 @@ int launch_big(void (*kernel)(StepArgs), const StepArgs &a, int copies, hipStrea
 
 bool general_section(const PrlConfig &c) {
     return (c.obs_mode == PRL_OBS_SECTION || c.obs_mode == PRL_OBS_DISCRETE) && c.obs_grad != 4;
+}
+
+// Launches go to the CALLER's current device and stream (one process per GPU): a batch used while another device is
+// current would launch there on pointers of this one.  Cheap to check (thread-local), so every entry point does.
+int check_device(const PrlBatch *b) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != b->device)
+        return fail(PRL_E_INVALID, "the batch lives on device %d but the calling thread's current device is %d "
+                                   "(hipSetDevice / torch.cuda.set_device first)", b->device, cur);
+    return PRL_OK;
 }
 
 StepArgs base_args(PrlBatch *b) {
@@ -875,6 +924,7 @@ int prl_batch_mask_stride(const PrlBatch *b) { return b ? b->mask_stride : fail(
 
 int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start_idx, double *obs, void *stream) {
     if (!b) return fail(PRL_E_INVALID, "null batch");
+    if (int rc = check_device(b)) return rc;
     StepArgs a = base_args(b);
     a.reset_mask = reset_mask;
     a.start_idx = start_idx;
@@ -896,6 +946,7 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
 
 int prl_batch_observe(PrlBatch *b, double *obs, void *stream) {
     if (!b || !obs) return fail(PRL_E_INVALID, "null argument");
+    if (int rc = check_device(b)) return rc;
     StepArgs a = base_args(b);
     a.obs = obs;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -916,6 +967,7 @@ int prl_batch_observe(PrlBatch *b, double *obs, void *stream) {
 int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward, uint8_t *done, double *info,
                    double *final_obs, const int32_t *start_idx, void *stream) {
     if (!b || !actions || !obs || !reward || !done || !info) return fail(PRL_E_INVALID, "null argument");
+    if (int rc = check_device(b)) return rc;
     StepArgs a = base_args(b);
     a.actions = actions;
     a.obs = obs;
@@ -1020,6 +1072,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
                          float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream) {
     if (!b || !obs || !reward || !done || !info || !action || n_steps < 1)
         return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
+    if (int rc = check_device(b)) return rc;
     const PrlConfig &c = b->cfg;
     if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
     if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: parts of at most %d samples", 64 * 64 * KW_MAX);

@@ -70,6 +70,7 @@ struct PartDev {
     gint_p col_rank;
     int col_convex, nbr_width;
     gint_p col_nbr, col_orient;
+    gint_p col_enbr;              // convex sets: [n_col_pad][3] facet across the edge u = 0 / v = 0 / u + v = 1, or -1 (derived)
     gdouble_p col_rec;            // convex sets: [n_col_pad][12] v0 e1 e2 | edge margin | |e1 x e2|^2 | orient (derived in part_fill)
     int n_col_chunks;
     gfloat_p col_chunk_bbox;

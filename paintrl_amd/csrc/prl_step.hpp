@@ -153,16 +153,18 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             // the reference returns early and leaves the last-shot set untouched.
             uint64_t cur[KW_MAX] = {0, 0, 0, 0};
             int beam_hits = 0;
-            // consecutive beams of the cone hit neighbouring facets: a beam starts from the facet the previous
-            // one hit (the first from the tool ray's facet); a wrong hint only costs the general search
-            int beam_hint = facet_hint;
-            for (int bm = 0; bm < P.n_beams; ++bm) {
-                double dst[3], bt, bh[3];
-                transform_point(pos, quat, P.beams[3 * bm], P.beams[3 * bm + 1], P.beams[3 * bm + 2], dst);
-                if (ray_closest_wave(P, pos, dst, lane, bt, bh, beam_hint, wl.cand) < 0) continue;
-                ++beam_hits;
-                const int sidx = nearest_sample_wave(P, bh, lane);
-                if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
+            for (int b0 = 0; b0 < P.n_beams; b0 += 64) {          // 64 beams per trip, one per lane (prl_cone.hpp)
+                double bh[3];
+                const bool hit = cone_rays_lanes(P, pos, quat, b0, facet_hint, lane, wl.cand, bh);
+                uint64_t hm = __ballot(hit);
+                beam_hits += __popcll(hm);
+                while (hm) {                                      // nearest sample of every hit point
+                    const int L = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    const double h3[3] = {bcast_d(bh[0], L), bcast_d(bh[1], L), bcast_d(bh[2], L)};
+                    const int sidx = nearest_sample_wave(P, h3, lane);
+                    if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
+                }
             }
             if (beam_hits > 0) {
 #pragma unroll

@@ -188,13 +188,16 @@ def table_digest(drv):
     edge = np.array(drv.all_points[:n_anchor] + part._get_edge_start_points(drv.all_points[n_anchor:]),
                     dtype=np.float64)           # what get_start_points(mode='edge') returns (bpw:775-778)
     kd = np.asarray(part.vertices_kd_tree[F].data, dtype=np.float64)
-    gp = drv.bpw.GridObservation(part, 4)._grid_pixels[F]
-    cell = {}
-    for i in gp:
-        for j in gp[i]:
-            for p in gp[i][j]:
-                cell[(int(p[0]), int(p[1]))] = i * 4 + j
-    cells = np.array([cell[(int(p[0]), int(p[1]))] for p in drv.pix], dtype=np.int32)
+    try:
+        gp = drv.bpw.GridObservation(part, 4)._grid_pixels[F]
+        cell = {}
+        for i in gp:
+            for j in gp[i]:
+                for p in gp[i][j]:
+                    cell[(int(p[0]), int(p[1]))] = i * 4 + j
+        cells = np.array([cell[(int(p[0]), int(p[1]))] for p in drv.pix], dtype=np.int32)
+    except KeyError:          # the reference's grid observation does not build on every part (bpw:1101)
+        cells = np.zeros(0, dtype=np.int32)
     return dict(P=np.int32(len(drv.pix)), P_back=np.int32(len(part.profile[drv.bpw.Side.back])),
                 T=np.int32(len(part.bary_list)), V=np.int32(len(part.vertices)),
                 side_counts=np.array([(sides == k).sum() for k in (1, 2, 3)], dtype=np.int32),

@@ -45,6 +45,9 @@ def reference_digests():
         name = rge.Part_Dict[part_no][0]
         if name in out:
             continue
+        # one env per process in the reference: with renders=True nothing resets the (stub) physics world, and the
+        # previous part's body would intercept this part's rays (bpw:874 checks the body id of the closest hit)
+        sys.modules['pybullet'].resetSimulation()
         drv = RefDriver(root, part_no)
         d = table_digest(drv)
         out[name] = {k: jsonable(d[k]) for k in DIGEST_KEYS}
@@ -88,8 +91,9 @@ def reference_door_rr():
     drv.configure('section', 4, 'all')
     for s in range(2):
         eps['g12_door_rr_%d' % s] = drv.episode(500 + s, random_policy(80 + s), max_steps=80)
-    drv.configure('grid', 4, 'anchor', overlap=True)
-    eps['g12_door_rr_grid'] = drv.episode(21, zigzag_policy_grid(), max_steps=50, want_idx=0)
+    # (the reference's GridObservation raises KeyError on this part, bpw:1101: section observations only)
+    drv.configure('section', 4, 'anchor', overlap=True, turning=True)
+    eps['g12_door_rr_sweep'] = drv.episode(21, zigzag_policy_grid(), max_steps=50, want_idx=0)
     save_episodes(os.path.join(HERE, 'episodes_reference_door_rr.npz'), eps)
 
 
