@@ -75,6 +75,14 @@ typedef struct {
     /* cone beams (PAINT_METHOD='normal') */
     int32_t n_beams;
     const double *beams;           /* [B][3] */
+    /* the reference's STALE vertex kd-tree, only for parts whose vertex rows _set_grid_dict moved after the tree was
+     * built (bpw:943-946; paintrl_amd/part_tables.py stale_kd_query); n_kd_nodes = 0: exact nearest vertex */
+    int32_t n_kd_nodes;
+    const int32_t *kd_split_dim;   /* [n] -1 = leaf */
+    const double *kd_split;        /* [n] */
+    const int32_t *kd_less, *kd_greater, *kd_start, *kd_end;   /* [n] children / leaf range into kd_points */
+    const int32_t *kd_points;      /* compact side-vertex ids in scipy's tree order, -1 = a row of another side */
+    const double *kd_box;          /* [2][3] bounding box of the rows when the tree was built */
 } OrPart;
 
 typedef struct {
@@ -215,10 +223,78 @@ static void bary_coord(const OrPart *p, int ti, const double *pt, double *u, dou
     if (inv == 0) { *u = -1; *v = -1; *w = -1; }
 }
 
+/* scipy cKDTree.query(k=1) (ckdtree/src/query.cxx, p = 2, eps = 0) on the stale tree, leaf distances from the current
+ * (moved) rows: descend to the near child, queue a far child whose lower bound is <= the best distance, scan a leaf in
+ * tree order keeping strictly smaller distances, stop when the queue is empty or its nearest cell is beyond the best */
+typedef struct { double mind, side[3]; int node; } KdItem;
+static int stale_kd_query(const OrPart *p, const double *x) {
+    KdItem heap[128];
+    int n_heap = 0, best = -1;
+    double dub = INFINITY;
+    KdItem cur;
+    cur.node = 0;
+    for (int k = 0; k < 3; ++k) {
+        double a = x[k] - p->kd_box[3 + k], b = p->kd_box[k] - x[k];
+        double s = a > b ? a : b;
+        s = s > 0 ? s : 0;
+        cur.side[k] = s * s;
+    }
+    cur.mind = (cur.side[0] + cur.side[1]) + cur.side[2];
+    for (;;) {
+        int sd = p->kd_split_dim[cur.node];
+        if (sd < 0) {
+            for (int i = p->kd_start[cur.node]; i < p->kd_end[cur.node]; ++i) {
+                int v = p->kd_points[i];
+                if (v < 0) continue;                       /* a row parked at (10, 10, 10): never the nearest */
+                const double *q = p->vertex_pos + 3 * v;
+                double d0 = q[0] - x[0], d1 = q[1] - x[1], d2 = q[2] - x[2];
+                double d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (d < dub) { dub = d; best = v; }
+            }
+            if (n_heap == 0) break;
+            int m = 0;                                     /* pop the nearest queued cell */
+            for (int i = 1; i < n_heap; ++i) if (heap[i].mind < heap[m].mind) m = i;
+            cur = heap[m];
+            heap[m] = heap[--n_heap];
+        } else {
+            if (cur.mind > dub) break;
+            double sp = p->kd_split[cur.node];
+            KdItem near = cur, far = cur;
+            if (x[sd] < sp) { near.node = p->kd_less[cur.node]; far.node = p->kd_greater[cur.node]; }
+            else { near.node = p->kd_greater[cur.node]; far.node = p->kd_less[cur.node]; }
+            double tmp = sp - x[sd], nw = tmp * tmp;
+            far.mind = cur.mind + (nw - far.side[sd]);
+            far.side[sd] = nw;
+            if (near.mind > far.mind) { KdItem t = near; near = far; far = t; }
+            if (far.mind <= dub && n_heap < 128) heap[n_heap++] = far;
+            cur = near;
+        }
+    }
+    return best;
+}
+
+/* test hook: the vertex bpw:526 would return for `x` (compact side-vertex id) */
+int or_nearest_vertex(const OrPart *p, const double *x) {
+    if (p->n_kd_nodes > 0) return stale_kd_query(p, x);
+    int best_v = -1;
+    double best_d = INFINITY;
+    for (int i = 0; i < p->n_vertices; ++i) {
+        const double *q = p->vertex_pos + 3 * i;
+        double dx = q[0] - x[0], dy = q[1] - x[1], dz = q[2] - x[2];
+        double d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best_d) { best_d = d2; best_v = i; }
+    }
+    return best_v;
+}
+
 /* bpw:525-534 _get_hook_point (+ 508-523 _get_closest_bary); returns 0 if no triangle */
 static int hook_point(const OrPart *p, const double *pt, double *pose, double *orn) {
     int best_v = 0;
     double best_d = INFINITY;
+    if (p->n_kd_nodes > 0) {                               /* rows were moved under the reference's tree */
+        best_v = stale_kd_query(p, pt);
+        if (best_v < 0) return 0;
+    } else
     for (int i = 0; i < p->n_vertices; ++i) {
         const double *x = p->vertex_pos + 3 * i;
         double dx = x[0] - pt[0], dy = x[1] - pt[1], dz = x[2] - pt[2];

@@ -26,7 +26,9 @@ class OrPart(C.Structure):
                 ('range2_min', C.c_double), ('range2_max', C.c_double), ('lwr', C.c_double),
                 ('a0', C.c_int32), ('a1', C.c_int32), ('a2', C.c_int32),
                 ('n_start', C.c_int32), ('start_pos', _dp), ('start_quat', _dp),
-                ('n_beams', C.c_int32), ('beams', _dp)]
+                ('n_beams', C.c_int32), ('beams', _dp),
+                ('n_kd_nodes', C.c_int32), ('kd_split_dim', _ip), ('kd_split', _dp), ('kd_less', _ip), ('kd_greater', _ip),
+                ('kd_start', _ip), ('kd_end', _ip), ('kd_points', _ip), ('kd_box', _dp)]
 
 
 class OrConfig(C.Structure):
@@ -165,8 +167,16 @@ class Oracle(object):
                     col_v0=_f64(t.col_v0), col_e1=_f64(t.col_e1), col_e2=_f64(t.col_e2),
                     grid_lo=_f64(t.grid_lo), grid_hi=_f64(t.grid_hi), start_pos=sp, start_quat=sq,
                     beams=_f64(t.beams))
+        n_kd = len(getattr(t, 'kd_split_dim', ()))
+        if n_kd:                                   # the reference's stale vertex tree (part_tables.stale_kd_query)
+            compact = -np.ones(t.vertices.shape[0], dtype=np.int64)
+            compact[side_ids] = np.arange(side_ids.size)
+            keep.update(kd_split_dim=_i32(t.kd_split_dim), kd_split=_f64(t.kd_split), kd_less=_i32(t.kd_less),
+                        kd_greater=_i32(t.kd_greater), kd_start=_i32(t.kd_start), kd_end=_i32(t.kd_end),
+                        kd_points=_i32(compact[np.asarray(t.kd_indices, dtype=np.int64)]), kd_box=_f64(t.kd_box))
         self._keep = keep
         p = OrPart()
+        p.n_kd_nodes = n_kd
         p.n_samples = keep['sample_pos'].shape[0]
         p.n_vertices = side_ids.size
         p.n_triangles = front_ids.size

@@ -33,6 +33,8 @@ class PrlPartTables(C.Structure):
         ('adj_width', C.c_int32), ('vertex_adj', _ip),
         ('vgrid_origin', C.c_double * 2), ('vgrid_inv_cell', C.c_double), ('vgrid_accept', C.c_double),
         ('vgrid_nx', C.c_int32), ('vgrid_ny', C.c_int32), ('vgrid_start', _ip),
+        ('n_kd_nodes', C.c_int32), ('kd_node', _ip), ('kd_split', _dp), ('n_kd_points', C.c_int32), ('kd_points', _ip),
+        ('kd_box', C.c_double * 6),
         ('n_triangles', C.c_int32), ('tri_records', _dp),
         ('n_collision', C.c_int32), ('n_collision_pad', C.c_int32), ('col_v0e1e2', _dp * 9), ('col_bbox', _fp), ('col_rank', _ip),
         ('col_convex', C.c_int32), ('nbr_width', C.c_int32), ('col_nbr', _ip), ('col_orient', _ip),

@@ -90,14 +90,14 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // One launch = one batched step: one wavefront per env, four envs per workgroup (prl_step.hpp holds the step).
-template <int KW, bool NORMAL, bool GENSEC, bool HSI = false>
+template <int KW, bool NORMAL, bool GENSEC, bool HSI = false, bool KD = false>
 __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC>();
+    const WaveLds wl = wave_lds<GENSEC, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<KW, NORMAL, GENSEC, true, HSI>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+    const int dn = step_env<KW, NORMAL, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                       new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
@@ -127,13 +127,13 @@ __device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, in
                     base + (copies > 1 ? a.mask_stride : 0), base + (copies > 2 ? 2 * a.mask_stride : 0), n_words, lane};
 }
 
-template <bool GENSEC>
+template <bool GENSEC, bool KD>
 __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC>();
+    const WaveLds wl = wave_lds<GENSEC, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<0, false, GENSEC, true, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+    const int dn = step_env<0, false, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                     new_angle, StepRows{&a}, wl);
     store_state_live(state_rec, S, lane, dn != 0);
 }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             __shared__ int s_cand[FRAG_WAVES][64];
             __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
             const WaveLds wl{s_cand[wave], s_centres[wave], nullptr};
-            const int dn = step_env<KW, false, false, true, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+            const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                             new_angle, row, wl);
             store_state_live(state_rec, S, lane, dn != 0);
         }
@@ -438,6 +438,7 @@ struct PrlPart {
 
 struct PrlBatch {
     int device = 0, n_envs = 0, n_parts = 0, mask_stride = 0, kw = 0;
+    bool kd = false;               // some part carries the reference's stale vertex kd-tree
     PrlConfig cfg{};
     PartDev *parts_dev = nullptr;
     PrlConfig *cfg_dev = nullptr;
@@ -558,6 +559,24 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (!monotone_starts(t->vgrid_start, (size_t)d.vg_nx * d.vg_ny + 1, d.n_vertices) ||
         t->vgrid_start[(size_t)d.vg_nx * d.vg_ny] != d.n_vertices)
         return fail(PRL_E_INVALID, "vertex grid starts must be non-decreasing and end at n_vertices");
+    d.n_kd_nodes = t->n_kd_nodes;
+    if (d.n_kd_nodes > 0) {       // the reference's stale vertex kd-tree: every index is checked, the device walks it blindly
+        if (!t->kd_node || !t->kd_split || !t->kd_points || t->n_kd_points < 1) return fail(PRL_E_INVALID, "null kd-tree table");
+        for (int i = 0; i < d.n_kd_nodes; ++i) {
+            const int32_t *nd = t->kd_node + 4 * (size_t)i;
+            const bool leaf = nd[0] < 0;
+            if (nd[0] > 2) return fail(PRL_E_INVALID, "kd node %d: split dimension %d", i, nd[0]);
+            if (leaf ? (nd[1] < 0 || nd[2] < nd[1] || nd[2] > t->n_kd_points)
+                     : (nd[1] <= i || nd[2] <= i || nd[1] >= d.n_kd_nodes || nd[2] >= d.n_kd_nodes))
+                return fail(PRL_E_INVALID, "kd node %d: children / point range out of order", i);   // children follow
+        }                                                                                           // their parent: no cycles
+        for (int i = 0; i < t->n_kd_points; ++i)
+            if (t->kd_points[i] < -1 || t->kd_points[i] >= d.n_vertices) return fail(PRL_E_INVALID, "kd point %d out of range", i);
+        UP(kd_node, t->kd_node, (size_t)d.n_kd_nodes * 4);
+        UP(kd_split, t->kd_split, d.n_kd_nodes);
+        UP(kd_points, t->kd_points, t->n_kd_points);
+        for (int k = 0; k < 6; ++k) d.kd_box[k] = t->kd_box[k];
+    }
     {   // device triangle records: the host's 16 doubles + the quaternion and shot-centre offset a hit on the
         // triangle produces (prl_device.hpp TRI_REC), so that the step kernel reads them instead of running a
         // square root, four divisions and a rotation per sub-shot
@@ -715,9 +734,11 @@ int check_config(const PrlConfig *c) {
 }
 
 template <int KW>
-void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, hipStream_t s) {
+void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, bool kd, hipStream_t s) {
     const dim3 grid((a.n_envs + 3) / 4), block(256);
-    if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true>), grid, block, 0, s, a);
+    if (kd && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, true>), grid, block, 0, s, a);
+    else if (kd) hipLaunchKernelGGL((step_kernel<KW, false, false, false, true>), grid, block, 0, s, a);
+    else if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true>), grid, block, 0, s, a);
     else if (hsi) hipLaunchKernelGGL((step_kernel<KW, false, false, true>), grid, block, 0, s, a);
     else if (normal && gensec) hipLaunchKernelGGL((step_kernel<KW, true, true>), grid, block, 0, s, a);
     else if (normal) hipLaunchKernelGGL((step_kernel<KW, true, false>), grid, block, 0, s, a);
@@ -863,6 +884,12 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     for (int i = 0; i < n_parts; ++i)
         if (parts[i]->dev.n_words > b->mask_stride) b->mask_stride = parts[i]->dev.n_words;
     b->kw = (b->mask_stride + 63) / 64;
+    for (int i = 0; i < n_parts; ++i) b->kd = b->kd || parts[i]->dev.n_kd_nodes > 0;
+    if (b->kd && (cfg->paint_method == PRL_PAINT_NORMAL || cfg->color_mode == PRL_COLOR_HSI)) {
+        delete b;
+        return fail(PRL_E_UNSUPPORTED, "a part with the reference's stale vertex kd-tree (moved vertex rows) runs with "
+                                       "PAINT_METHOD 'fast' and COLOR_MODE 'RGB' only");
+    }
     if (b->kw > KW_MAX && cfg->color_mode == PRL_COLOR_HSI) {
         delete b;
         return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for parts of at most %d samples", 64 * 64 * KW_MAX);
@@ -990,12 +1017,14 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
     switch (b->kw) {
-    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, s); break;
-    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, s); break;
-    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, s); break;
-    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, s); break;
+    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
+    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
+    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
+    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
     default: {                                     // a part with more than 16 384 samples: masks in LDS
-        const int rc = launch_big(general_section(b->cfg) ? step_kernel_big<true> : step_kernel_big<false>, a, 3, s);
+        const bool gs = general_section(b->cfg);
+        const int rc = launch_big(b->kd ? (gs ? step_kernel_big<true, true> : step_kernel_big<false, true>)
+                                        : (gs ? step_kernel_big<true, false> : step_kernel_big<false, false>), a, 3, s);
         if (rc) return rc;
     }
     }
@@ -1077,6 +1106,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
     if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: parts of at most %d samples", 64 * 64 * KW_MAX);
     if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: COLOR_MODE 'RGB'");
+    if (b->kd) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: not for parts with the reference's stale vertex kd-tree");
     if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
         return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for "
                                        "section / discrete observations");

@@ -62,6 +62,11 @@ struct PartDev {
     double vg_o1, vg_o2, vg_inv, vg_accept;
     int vg_nx, vg_ny;
     gint_p vg_start;
+    int n_kd_nodes;               // > 0: the reference's stale vertex kd-tree (include/paintrl.h); nearest_vertex_kd walks it
+    gint_p kd_node;               // [n][4] split dim | lesser or first point | greater or end | 0
+    gdouble_p kd_split;
+    gint_p kd_points;
+    double kd_box[6];
     int n_triangles;
     gdouble_p tri_rec;            // [n_triangles][TRI_REC]: the 16 doubles of the host table + derived tail (part_fill)
     int n_col, n_col_pad;
@@ -124,18 +129,21 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // index held in a scalar register: indexed with `threadIdx.x >> 6` at the point of use the compiler keeps
 // threadIdx.x and 64-bit generic row addresses alive in vector registers through the whole kernel -- and, at
 // this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
+constexpr int KD_HEAP = 64;         // queued cells of the stale kd-tree walk (5 doubles each)
 struct WaveLds {
     int *cand;          // [64]
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
     int *cnt;           // [128], only with the atan2-sector observation
+    double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
 };
-template <bool GENSEC>
+template <bool GENSEC, bool KD = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[MAX_WAVES_PER_WG][64];
     __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
+    __shared__ double s_kd[KD ? MAX_WAVES_PER_WG : 1][KD ? KD_HEAP * 5 : 1];
     const int w = rfl((int)(threadIdx.x >> 6));
-    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0]};
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0]};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

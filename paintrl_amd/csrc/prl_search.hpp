@@ -138,6 +138,92 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
 
+// ---------------------------------------------------------------- bpw:526 on a part whose vertex rows the reference moved
+// scipy's cKDTree.query(k = 1) on the STALE tree (include/paintrl.h kd_node; oracle/paint_oracle.c stale_kd_query is
+// the scalar statement): descend to the near child, queue the far child if its lower bound is <= the best squared
+// distance, scan a leaf's points in tree order keeping strictly smaller distances (distances to the rows as they
+// are NOW), continue with the nearest queued cell until none is left or it lies beyond the best.  The walk is
+// wave-uniform; the (at most 16) points of a leaf are one per lane; the queue lives in this wave's LDS rows.
+__device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap) {
+    double side0, side1, side2;
+    {
+        const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
+                     a2 = pt[2] - P.kd_box[5], b2 = P.kd_box[2] - pt[2];
+        double s0 = a0 > b0 ? a0 : b0, s1 = a1 > b1 ? a1 : b1, s2 = a2 > b2 ? a2 : b2;
+        s0 = s0 > 0 ? s0 : 0;
+        s1 = s1 > 0 ? s1 : 0;
+        s2 = s2 > 0 ? s2 : 0;
+        side0 = s0 * s0;
+        side1 = s1 * s1;
+        side2 = s2 * s2;
+    }
+    double mind = (side0 + side1) + side2, dub = INFINITY;
+    int node = 0, best = -1, n_heap = 0;
+    for (int guard = 0; guard < 4 * 4096; ++guard) {                // every path ends far earlier; a bound all the same
+        const int nd0 = rfl(ldg(P.kd_node, 4 * node)), nd1 = rfl(ldg(P.kd_node, 4 * node + 1)),
+                  nd2 = rfl(ldg(P.kd_node, 4 * node + 2));
+        if (nd0 < 0) {                                              // leaf: points nd1 .. nd2 - 1
+            for (int i0 = nd1; i0 < nd2; i0 += 64) {
+                const int i = i0 + lane;
+                const int v = i < nd2 ? ldg(P.kd_points, i) : -1;   // -1: a row parked at (10, 10, 10)
+                double d = INFINITY;
+                if (v >= 0) {
+                    double x, y, z;
+                    int rk;
+                    load_vertex(P, v, x, y, z, rk);
+                    const double d0 = x - pt[0], d1 = y - pt[1], d2 = z - pt[2];
+                    d = (d0 * d0 + d1 * d1) + d2 * d2;
+                }
+                const double dmin = wave_min_d(d);
+                if (dmin < dub) {                                   // the first point (tree order) reaching the minimum
+                    dub = dmin;
+                    best = __builtin_amdgcn_readlane(v, rfl(__builtin_ctzll(__ballot(d == dmin))));
+                }
+            }
+            if (n_heap == 0) break;
+            // pop the nearest queued cell: lane l looks at entry l
+            const double key = lane < n_heap ? heap[5 * lane] : INFINITY;
+            const double kmin = wave_min_d(key);
+            const int m = rfl(__builtin_ctzll(__ballot(key == kmin)));
+            mind = heap[5 * m];
+            side0 = heap[5 * m + 1];
+            side1 = heap[5 * m + 2];
+            side2 = heap[5 * m + 3];
+            node = rfl((int)heap[5 * m + 4]);
+            --n_heap;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 5 && m != n_heap) heap[5 * m + lane] = heap[5 * n_heap + lane];      // the last entry fills the hole
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            if (mind > dub) break;
+            const double sp = ldg(P.kd_split, node);
+            const double xs = sel3(pt[0], pt[1], pt[2], nd0), old = sel3(side0, side1, side2, nd0);
+            const bool low = xs < sp;
+            const int near = low ? nd1 : nd2, far = low ? nd2 : nd1;
+            const double tmp = sp - xs, nw = tmp * tmp;
+            const double far_mind = mind + (nw - old);
+            // (query.cxx also swaps the two if the near child came out farther; with new >= old that needs a NaN)
+            if (far_mind <= dub && n_heap < KD_HEAP) {
+                if (lane == 0) {
+                    heap[5 * n_heap] = far_mind;
+                    heap[5 * n_heap + 1] = nd0 == 0 ? nw : side0;
+                    heap[5 * n_heap + 2] = nd0 == 1 ? nw : side1;
+                    heap[5 * n_heap + 3] = nd0 == 2 ? nw : side2;
+                    heap[5 * n_heap + 4] = (double)far;
+                }
+                ++n_heap;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            node = rfl(near);
+        }
+    }
+    return best;
+}
+
 // ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1): nearest sample
 // Same exact expanding-ring search as for vertices, over the sample grid; equal distances resolve
 // to the lowest reference-order index.  Returns the device position of the sample, or -1.
@@ -207,10 +293,14 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
 // Also returns what the chosen triangle's normal implies for the tool: the quaternion of rob:93-100 and the shot
 // centre of rob:277-278 (pose + R(quat)(0, 0, 0.1)), read from the triangle record's precomputed tail.
-// `tri` receives the chosen triangle (index into the triangle records).
+// `tri` receives the chosen triangle (index into the triangle records).  KD: the part carries the reference's stale
+// vertex kd-tree (kd_heap = this wave's LDS rows for its walk); otherwise the exact nearest vertex.
+template <bool KD>
 __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3], double quat[4],
-                                double center[3], int &tri PROF_ARG) {
-    const int vidx = nearest_vertex_wave(P, pt, lane);
+                                double center[3], int &tri, double *kd_heap PROF_ARG) {
+    int vidx;
+    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap) : nearest_vertex_wave(P, pt, lane);
+    else vidx = nearest_vertex_wave(P, pt, lane);
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;
     const int ti = lane < P.adj_width ? ldg(P.vadj, vidx * P.adj_width + lane) : -1;   // file order, -1 = pad

@@ -77,7 +77,8 @@ __device__ __forceinline__ void reset_thickness(PartRef P, uint8_t *thick, int l
 // space at that point; handing the kernel's by-value argument struct down by reference instead makes the compiler
 // copy all of it into registers at kernel entry.
 // HSI = COLOR_MODE 'HSI' (bpw:384-434): thickness bytes in a.thick, float "succeed counter" (prl_paint.hpp).
-template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, bool HSI, typename MaskIO, typename RowIO>
+// KD: parts of the batch may carry the reference's stale vertex kd-tree (prl_search.hpp nearest_vertex_kd).
+template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, typename MaskIO, typename RowIO>
 __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                         const double *state_rec, const MaskIO &masks, double delta1, double delta2,
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
@@ -118,7 +119,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint, wl.cand) >= 0;
         STAMP(PH_RAY);
         double center[3];                                  // rob:277-278 shot centre
-        if (on) on = hook_point_wave(P, hit, lane, pos, orn, quat, center, last_tri PROF_PASS);
+        if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, last_tri, wl.kd_heap PROF_PASS);
         if (!on) {
             last_tri = -1;
             orn[0] = cur_norm[0];

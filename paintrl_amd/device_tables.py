@@ -120,6 +120,23 @@ class DeviceTables(object):
         self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
         self.vgrid = (vo1, vo2, inv, vnx, vny)
         self.vgrid_accept = 0.99 * self.vcell
+        # the reference's stale vertex kd-tree (part_tables._fill_stale_kd_tree), leaf points as device positions
+        n_kd = len(getattr(t, 'kd_split_dim', ()))
+        self.kd_node = np.zeros((max(n_kd, 1), 4), dtype=np.int32)
+        self.kd_split = np.zeros(max(n_kd, 1), dtype=np.float64)
+        self.kd_points = np.zeros(1, dtype=np.int32)
+        self.kd_box = np.zeros(6, dtype=np.float64)
+        self.n_kd_nodes = n_kd
+        if n_kd:
+            dev_of_full = -np.ones(t.vertices.shape[0], dtype=np.int64)
+            dev_of_full[side_ids[vorder]] = np.arange(vorder.size)
+            leaf = np.asarray(t.kd_split_dim) < 0
+            self.kd_node[:, 0] = t.kd_split_dim
+            self.kd_node[:, 1] = np.where(leaf, t.kd_start, t.kd_less)
+            self.kd_node[:, 2] = np.where(leaf, t.kd_end, t.kd_greater)
+            self.kd_split = np.ascontiguousarray(t.kd_split, dtype=np.float64)
+            self.kd_points = dev_of_full[np.asarray(t.kd_indices, dtype=np.int64)].astype(np.int32)
+            self.kd_box = np.ascontiguousarray(np.asarray(t.kd_box, dtype=np.float64).reshape(6))
         front_ids = np.nonzero(t.tri_side == pt.SIDE_FRONT)[0]
         compact = -np.ones(t.tri_side.shape[0], dtype=np.int64)
         compact[front_ids] = np.arange(front_ids.size)
@@ -263,6 +280,10 @@ class DeviceTables(object):
         s.vgrid_origin[0], s.vgrid_origin[1], s.vgrid_inv_cell, s.vgrid_nx, s.vgrid_ny = self.vgrid
         s.vgrid_accept = self.vgrid_accept
         s.vgrid_start = ip(self.vgrid_start)
+        s.n_kd_nodes, s.kd_node, s.kd_split = self.n_kd_nodes, ip(self.kd_node), dp(self.kd_split)
+        s.n_kd_points, s.kd_points = int(self.kd_points.shape[0]), ip(self.kd_points)
+        for k in range(6):
+            s.kd_box[k] = float(self.kd_box[k])
         s.n_triangles = self.tri_records.shape[0]
         s.tri_records = dp(self.tri_records)
         s.n_collision, s.n_collision_pad = self.n_collision, self.n_collision_pad

@@ -248,11 +248,21 @@ def quadratic_sheet(seed=1):
     return v, uv, f, fvt
 
 
+def sparse_sheet(seed=2):
+    """The quadratic sheet meshed four times coarser (vertex spacing ~0.11 m): most of the reference's 100 grid rows
+    hold no vertex, so its _set_grid_dict moves vertex rows in place under the kd-tree (bpw:943-946) -- the case the
+    reference's own coarse parts (door_lf, door_rr, ...) exercise and the fine synthetic parts never do."""
+    v, uv, f, fvt, _ = _panel(0.96, 0.96, 0.11, None, (5, 5), (0.012, 0.012, 0.014), 0.0006,
+                              0.002, 1, seed, uv_front=(0.3, 0.3, 121.7, 121.7), uv_back=(120.6, 0.3, 118.6, 118.6))
+    v = v + np.array([0.0, 0.0, 0.001])
+    return v, uv, f, fvt
+
+
 # 'door_rr_big': the door panel on a 480 x 480 texture, like the reference's Part_NO 8 (door_rr_big.urdf with
 # pattern_big.jpg): ~38 000 front samples, i.e. a part whose coverage masks do not fit four words per lane.
-PARTS = {'door_test': door_panel, 'square': quadratic_sheet, 'door_rr_big': door_panel}
+PARTS = {'door_test': door_panel, 'square': quadratic_sheet, 'door_rr_big': door_panel, 'test': sparse_sheet}
 TEXTURES = {'door_test': ((240, 240), 'pattern.jpg'), 'square': ((240, 240), 'pattern.jpg'),
-            'door_rr_big': ((480, 480), 'pattern_big.jpg')}
+            'door_rr_big': ((480, 480), 'pattern_big.jpg'), 'test': ((240, 240), 'pattern.jpg')}
 
 
 def write_synthetic_parts(root, names=('door_test', 'square')):

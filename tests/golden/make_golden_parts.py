@@ -97,6 +97,21 @@ def reference_door_rr():
     save_episodes(os.path.join(HERE, 'episodes_reference_door_rr.npz'), eps)
 
 
+def sparse_synthetic():
+    """The coarse synthetic sheet ('test', Part_NO 9): the reference moves vertex rows under its kd-tree there."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root, names=('test',))
+    drv = RefDriver(root, 9)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_sparse.npz'), **table_digest(drv))
+    eps = {}
+    drv.configure('section', 4, 'all')
+    for s in range(6):
+        eps['g14_sparse_all_%d' % s] = drv.episode(600 + s, random_policy(90 + s), max_steps=150)
+    drv.configure('grid', 4, 'anchor', overlap=True)
+    eps['g14_sparse_grid'] = drv.episode(21, zigzag_policy_grid(), max_steps=120, want_idx=0)
+    save_episodes(os.path.join(HERE, 'episodes_sparse.npz'), eps)
+
+
 def hsi_door():
     """COLOR_MODE='HSI' (thickness bytes, bpw:384-434) on the synthetic door: on-part policies only -- a shot that
     hits no sample makes the reference raise (max of an empty array), such an episode is cut before that step."""
@@ -134,6 +149,8 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['digests', 'big', 'door_rr']
     if 'hsi' in what:
         hsi_door()
+    if 'sparse' in what:
+        sparse_synthetic()
     if 'big' in what:
         big_synthetic()
     if 'door_rr' in what:

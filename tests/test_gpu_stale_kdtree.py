@@ -1,0 +1,109 @@
+"""Parts whose vertex rows the reference moves under its kd-tree (bpw:943-946): the device walks the stale tree the
+way scipy does (nearest_vertex_kd), so trajectories stay those of the reference.  Synthetic coarse sheet ('test')."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, env_kwargs_from_cfg, load_episodes, start_points_for, synthetic_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(tables, n, sp=None, **kw):
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    return BatchedPaintEnv(DeviceTables(tables, obs_grad=kw.get('obs_grad', 4), start_points=sp), n, **kw)
+
+
+@pytest.mark.parametrize('kw', [dict(obs_mode='section'), dict(obs_mode='grid', overlap_penalty=True),
+                                dict(obs_mode='section', obs_grad=6)])
+def test_stale_tree_part_matches_oracle(kw):
+    tables = synthetic_tables('test')
+    assert len(tables.vertices_mutated) > 0 and len(tables.kd_split_dim) > 0
+    sp = start_points_for(tables, 'all')
+    n, steps = 192, 40
+    env = _env(tables, n, sp, max_possible_point=14000, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=14000, **kw)
+    rng = np.random.RandomState(3)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(d.cpu().numpy(), dd), 'step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    st = env.state()
+    for e in range(n):
+        so = orc.state(e)
+        assert np.array_equal(st['pose'][e], so['pose']) and np.array_equal(st['quat'][e], so['quat'])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    assert np.array_equal(env.parts[0].mask_to_canonical(words), np.stack([orc.painted_bits(e) for e in range(n)]))
+    env.close()
+
+
+def test_stale_tree_on_a_large_part_and_in_a_mixed_batch():
+    """The same tree under the LDS-mask kernels (the reference's door_lf / door_rf carry both properties), next to a
+    part without a tree in one batch."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    sparse_big = synthetic_tables('test', tex_size=(360, 360))
+    assert sparse_big.sample_pos.shape[0] > 16384 and len(sparse_big.kd_split_dim) > 0
+    door = synthetic_tables('door_test')
+    sp_b, sp_d = start_points_for(sparse_big, 'all'), start_points_for(door, 'all')
+    n = 64
+    ids = (np.arange(n) % 2).astype(np.int32)
+    env = BatchedPaintEnv([DeviceTables(sparse_big, start_points=sp_b), DeviceTables(door, start_points=sp_d)], n,
+                          env_part_id=ids, max_possible_point=[30000, 9148])
+    o_b = oracle.Oracle(sparse_big, n // 2, start_points=sp_b, max_possible_point=30000)
+    o_d = oracle.Oracle(door, n // 2, start_points=sp_d, max_possible_point=9148)
+    rng = np.random.RandomState(4)
+    start = np.where(ids == 0, rng.randint(0, len(sp_b), size=n), rng.randint(0, len(sp_d), size=n))
+    obs = env.reset(start_idx=start).cpu().numpy()
+    assert np.array_equal(obs[0::2], o_b.reset(start[0::2])) and np.array_equal(obs[1::2], o_d.reset(start[1::2]))
+    for k in range(25):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        o, r, d = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy()
+        o1, r1, d1, _ = o_b.step(a[0::2])
+        o2, r2, d2, _ = o_d.step(a[1::2])
+        assert np.array_equal(o[0::2], o1) and np.array_equal(o[1::2], o2), 'step %d' % k
+        assert np.array_equal(r[0::2], r1) and np.array_equal(r[1::2], r2)
+        assert np.array_equal(d[0::2], d1) and np.array_equal(d[1::2], d2)
+    env.close()
+
+
+def test_stale_tree_limits_are_reported():
+    from paintrl_amd import _lib
+    tables = synthetic_tables('test')
+    with pytest.raises(_lib.PaintRLError, match='kd-tree'):
+        _env(tables, 4, paint_method='normal')
+    with pytest.raises(_lib.PaintRLError, match='kd-tree'):
+        _env(tables, 4, color_mode='HSI')
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(GOLDEN, 'episodes_sparse.npz')), reason='fixture not generated')
+def test_stale_tree_part_replays_reference_episodes():
+    from test_oracle_golden import replay
+    for name, ep in sorted(load_episodes('sparse').items()):
+        cfg = ep['cfg']
+        tables = synthetic_tables('test')
+        env = _env(tables, 1, start_points_for(tables, cfg['start_mode']), **env_kwargs_from_cfg(cfg))
+
+        def reset(idx):
+            return env.reset(start_idx=[idx]).cpu().numpy()[0]
+
+        def step(a, want_bits):
+            obs, rew, done, info = env.step([a])
+            bits = env.painted_bits(0) if want_bits else None
+            return obs.cpu().numpy()[0], float(rew[0]), bool(done[0]), info.cpu().numpy()[0], bits
+
+        replay(step, reset, ep, exact=True)
+        st = env.state()
+        assert np.array_equal(st['pose'][0], ep['final_pose']) and st['total_return'][0] == float(ep['total_return']), name
+        env.close()

@@ -191,3 +191,35 @@ def test_tables_round_trip_on_disk(tmp_path, door_tables):
     assert preprocess.main(['--synthetic', 'square', out]) == 0
     t3 = part_tables.load_tables(out)
     assert np.array_equal(t3.sample_pos, synthetic_tables('square').sample_pos)
+
+
+def test_stale_kd_tree_walk_equals_scipy_on_moved_rows():
+    """Parts on which the reference moves vertex rows under its cKDTree (bpw:943-946; the synthetic coarse sheet):
+    part_tables.stale_kd_query and the oracle's C statement of it give what scipy's query gives on a tree built from
+    the old rows whose data was then overwritten in place -- and that is NOT always the exact nearest vertex."""
+    from scipy.spatial import cKDTree
+    import ctypes as C
+    t = synthetic_tables('test')
+    assert len(t.vertices_mutated) > 0
+    side = t._side_data
+    # the rows as they were when the tree was built: moved rows back to their vertex positions
+    old = side.copy()
+    old[t.vertices_mutated] = t.vertices[t.vertices_mutated]
+    tree = cKDTree(old)
+    tree.data[:] = side                                  # what bpw:943-946 does to vertices_kd_tree[side].data
+    rng = np.random.RandomState(0)
+    qs = t.sample_pos[rng.randint(0, len(t.sample_pos), 4000)] + rng.normal(0, 0.01, (4000, 3))
+    want = tree.query(qs, k=1)[1]
+    got = np.array([part_tables.stale_kd_query(t, q) for q in qs])
+    assert np.array_equal(got, want)
+    exact = np.argmin(((side[None, :, :] - qs[:, None, :]) ** 2).sum(-1), axis=1)
+    assert 0 < (exact != want).sum() < 400               # the stale tree does change answers, rarely
+    # the same walk in the oracle's C (hook point of each query: its normal identifies the vertex's triangle choice)
+    orc = oracle.Oracle(t, 1)
+    side_ids = np.nonzero(t.vertex_is_side)[0]
+    lib = orc.lib
+    lib.or_nearest_vertex.restype = C.c_int
+    for q, w in zip(qs[:1500], want[:1500]):
+        qq = np.ascontiguousarray(q, dtype=np.float64)
+        v = lib.or_nearest_vertex(C.byref(orc.part), qq.ctypes.data_as(C.POINTER(C.c_double)))
+        assert side_ids[v] == w
