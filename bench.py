@@ -58,13 +58,15 @@ def algorithmic_bytes(dt, n_envs, obs_dim):
                + 2 * 16 * 8               # 128-byte scalar state record, read and write
                + 4                        # action (int32)
                + obs_dim * 8 + 8 + 1 + 16)  # obs, reward, done, info (float64 like the reference)
+    n_tri = dt.tri_records.shape[0]
     static = (3 * dt.n_samples_pad * 8 + dt.word_bbox.nbytes + dt.word_valid.nbytes + dt.sample_rank.nbytes + dt.sgrid_start.nbytes
-              + sum(a.nbytes for a in dt.vertex_xyz) + dt.vertex_rank.nbytes + dt.vertex_adj.nbytes
-              + dt.vgrid_start.nbytes + dt.tri_records.nbytes
+              + dt.n_samples_pad * 16                                           # float copy of the samples (paint pre-filter)
+              + dt.vertex_rank.shape[0] * 32 + dt.vertex_adj.nbytes             # x y z | rank vertex records
+              + dt.vgrid_start.nbytes + n_tri * 24 * 8                          # triangle records incl. quaternion / centre tail
               + sum(a.nbytes for a in dt.col) + dt.col_bbox.nbytes + dt.col_rank.nbytes + dt.col_nbr.nbytes + dt.col_orient.nbytes + dt.col_chunk_bbox.nbytes + dt.grid_lo.nbytes + dt.grid_hi.nbytes
               + dt.start_pos.nbytes + dt.start_quat.nbytes
               + dt.n_samples_pad                                                # equal-run ends (u8), derived on upload
-              + (dt.n_collision_pad * 96 if dt.col_convex else 0))              # hull facet records, derived on upload
+              + (dt.n_collision_pad * (96 + 12) if dt.col_convex else 0))       # hull facet records + edge neighbours
     return survey_env, survey_launch, per_env, static, per_env * n_envs + static
 
 

@@ -1,0 +1,50 @@
+#!/bin/bash
+# Round evidence in one go (run on the GPU box: `gpurun -- bash tools/collect_profiles.sh r02`).  Everything lands in
+# gpurun_out/<tag>/; tools/summarise_profiles.py (run in the build container afterwards) turns it into profiles/<tag>_*.
+# Counter passes carry --pmc only (no --kernel-trace / --stats with them); the program after `--` is python3 itself.
+set -u
+TAG=${1:-r02}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py"
+W="python3 $ROOT/tools/run_workload.py"
+
+echo "== bench lines"
+$B > "$OUT/bench.json" 2> "$OUT/bench.err"
+$B --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_driver_shape.json" 2>> "$OUT/bench.err"
+$B --obs-mode grid --no-cpu-baseline > "$OUT/bench_grid.json" 2>> "$OUT/bench.err"
+$B --mixed --no-cpu-baseline > "$OUT/bench_mixed.json" 2>> "$OUT/bench.err"
+$B --actions sweep --no-cpu-baseline > "$OUT/bench_sweep.json" 2>> "$OUT/bench.err"
+$B --envs 32768 --steps 400 --warmup 50 --no-cpu-baseline > "$OUT/bench_n32768.json" 2>> "$OUT/bench.err"
+$B --policy mlp --no-cpu-baseline > "$OUT/bench_mlp.json" 2>> "$OUT/bench.err"
+$B --policy fragment --no-cpu-baseline > "$OUT/bench_fragment.json" 2>> "$OUT/bench.err"
+$B --policy random-fragment --no-cpu-baseline > "$OUT/bench_random_fragment.json" 2>> "$OUT/bench.err"
+$B --streams 2 --no-cpu-baseline > "$OUT/bench_streams2.json" 2>> "$OUT/bench.err"
+$B --paint-method normal --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/bench_normal.json" 2>> "$OUT/bench.err"
+echo "== kernel trace"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- $B --no-cpu-baseline > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace_grid" --output-format csv -- $B --obs-mode grid --no-cpu-baseline > "$OUT/trace_grid.log" 2>&1
+echo "== SQ / TA counters"
+G1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH"
+G2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH"
+G3="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
+G4="TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE"
+for MODE in section grid; do
+  i=0
+  for G in "$G1" "$G2" "$G3" "$G4"; do
+    i=$((i+1))
+    rocprofv3 --pmc $G -d "$OUT/pmc_${MODE}_$i" --output-format csv -- $W --obs-mode $MODE --steps 100 > "$OUT/pmc_${MODE}_$i.log" 2>&1 || echo "pmc $MODE pass $i failed"
+  done
+done
+echo "== HBM bytes (FETCH_SIZE and WRITE_SIZE in separate passes) + calibration on copy_mask_kernel"
+for MODE in section grid; do
+  rocprofv3 --pmc FETCH_SIZE -d "$OUT/hbm_fetch_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_fetch_$MODE.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d "$OUT/hbm_write_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_write_$MODE.log" 2>&1
+done
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/cal_fetch" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/cal_write" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_write.log" 2>&1
+# keep what is merged back small: counter CSVs of 100-200 dispatches are fine, the per-dispatch kernel trace is not
+find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
+du -sh "$OUT"
