@@ -71,7 +71,41 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     if (C.color_mode == PRL_COLOR_HSI) reset_thickness<KW>(P, a.thick + (size_t)env * 64 * a.mask_stride, lane, painted);
     store_masks<KW>(a, env, P.n_words, lane, painted, last);
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wave_lds<GENSEC>().cnt);
+    if (a.obs) {
+        const int od = obs_dim_of(C.obs_mode, C.obs_grad);
+        for (int k = lane; k < od; k += 64) a.obs[(size_t)env * od + k] = ldg(P.reset_obs, start * od + k);
+    }
+}
+
+// The observation a reset to start point s returns, for every s of one part (PartDev::reset_obs): one wave per start
+// point, run once when a batch is created.  KW = 0: LDS-resident mask (large parts).
+template <int KW, bool GENSEC>
+__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const PrlConfig *cfg, double *out) {
+    const int lane = threadIdx.x & 63;
+    const int s = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    PartRef P = *(const PartDev CAS *)part;
+    CfgRef C = *(const PrlConfig CAS *)cfg;
+    if (s >= P.n_start) return;
+    const double pose[3] = {P.start_pos[3 * s], P.start_pos[3 * s + 1], P.start_pos[3 * s + 2]};
+    const int od = obs_dim_of(C.obs_mode, C.obs_grad);
+    const bool hsi = C.color_mode == PRL_COLOR_HSI;           // thickness mode: every texel reads "painted" after a reset
+    if constexpr (KW == 0) {
+        extern __shared__ uint64_t big_lds[];
+        uint64_t *m = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * P.n_words;
+        for (int w = lane; w < P.n_words; w += 64) m[w] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
+    } else {
+        uint64_t painted[KW_MAX] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int w = lane + 64 * k;
+            painted[k] = (hsi && w < P.n_words) ? ldg(P.word_valid, w) : 0;
+        }
+        observation_wave<KW, GENSEC>(P, C, pose, painted, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
+    }
 }
 
 // ---------------------------------------------------------------- observation of the current state (rge:306-319)
@@ -160,20 +194,15 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
     int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
     reset_state(P, S, start);
-    extern __shared__ uint64_t big_lds[];
-    uint64_t *zero = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
     for (int w = lane; w < P.n_words; w += 64) {
-        zero[w] = 0;
         a.painted[(size_t)env * a.mask_stride + w] = 0;
         a.last[(size_t)env * a.mask_stride + w] = 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs)
-        observation_big<GENSEC>(P, C, S.pose, zero, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
-                                wave_lds<GENSEC>().cnt);
+    if (a.obs) {
+        const int od = obs_dim_of(C.obs_mode, C.obs_grad);
+        for (int k = lane; k < od; k += 64) a.obs[(size_t)env * od + k] = ldg(P.reset_obs, start * od + k);
+    }
 }
 
 template <bool GENSEC>
@@ -445,6 +474,7 @@ struct PrlBatch {
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
+    std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     double *state = nullptr;
     int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
     long long launch_no = 0;
@@ -902,7 +932,13 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     }
     hipError_t e = hipSetDevice(b->device);
     std::vector<PartDev> pd(n_parts);
-    for (int i = 0; i < n_parts; ++i) pd[i] = parts[i]->dev;
+    const int od = obs_dim_of(cfg->obs_mode, cfg->obs_grad);
+    b->reset_obs.assign(n_parts, nullptr);
+    for (int i = 0; i < n_parts; ++i) {
+        pd[i] = parts[i]->dev;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->reset_obs[i]), sizeof(double) * (size_t)pd[i].n_start * od);
+        pd[i].reset_obs = (gdouble_p)b->reset_obs[i];
+    }
     const size_t mask_bytes = (size_t)n_envs * b->mask_stride * sizeof(uint64_t);
     const size_t state_bytes = (size_t)n_envs * PRL_STATE_DOUBLES * sizeof(double);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->parts_dev), sizeof(PartDev) * n_parts);
@@ -923,6 +959,31 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess) e = hipMemset(b->painted, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->last, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->state, 0, state_bytes);
+    // the observation a reset to each start point returns (PartDev::reset_obs), once per part
+    for (int i = 0; i < n_parts && e == hipSuccess; ++i) {
+        const bool gs = general_section(*cfg);
+        const dim3 grid((pd[i].n_start + 3) / 4), block(256);
+        const int words = pd[i].n_words;
+        if (words > 64 * KW_MAX) {
+            void (*k)(const PartDev *, const PrlConfig *, double *) = gs ? reset_obs_kernel<0, true> : reset_obs_kernel<0, false>;
+            const size_t lds = (size_t)4 * words * sizeof(uint64_t);
+            if (lds > 64 * 1024)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i]);
+        } else {
+            const int kw = (words + 63) / 64;
+#define RESET_OBS_LAUNCH(KWV)                                                                                         \
+    if (gs) hipLaunchKernelGGL((reset_obs_kernel<KWV, true>), grid, block, 0, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i]); \
+    else hipLaunchKernelGGL((reset_obs_kernel<KWV, false>), grid, block, 0, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i])
+            if (kw <= 1) { RESET_OBS_LAUNCH(1); }
+            else if (kw == 2) { RESET_OBS_LAUNCH(2); }
+            else if (kw == 3) { RESET_OBS_LAUNCH(3); }
+            else { RESET_OBS_LAUNCH(4); }
+#undef RESET_OBS_LAUNCH
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         rc = fail(PRL_E_HIP, "batch allocation: %s", hipGetErrorString(e));
         prl_batch_destroy(b);
@@ -943,6 +1004,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
+    for (double *p : b->reset_obs) (void)hipFree(p);
     (void)hipFree(b->state);
     delete b;
 }
@@ -963,7 +1025,7 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
     case 3: launch_reset<3>(a, general_section(b->cfg), s); break;
     case 4: launch_reset<4>(a, general_section(b->cfg), s); break;
     default: {
-        const int rc = launch_big(general_section(b->cfg) ? reset_kernel_big<true> : reset_kernel_big<false>, a, 1, s);
+        const int rc = launch_big(general_section(b->cfg) ? reset_kernel_big<true> : reset_kernel_big<false>, a, 0, s);
         if (rc) return rc;
     }
     }

@@ -86,6 +86,11 @@ struct PartDev {
     gdouble_p start_pos, start_quat;
     int n_beams;
     gdouble_p beams;
+    // Per BATCH (filled in the batch's own copy of the descriptor, prl_batch_create): the observation a reset to each
+    // start point returns, [n_start][obs_dim].  Right after a reset nothing is painted, so that observation depends
+    // on the start point and the configuration only; computing it once (reset_obs_kernel, the same device code)
+    // takes a whole observation pass out of every step in which an episode ends.
+    gdouble_p reset_obs;
 };
 
 // The part descriptor and the batch configuration are read-only for every kernel: typed as constant

@@ -286,15 +286,10 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             painted[k] = 0;
             last[k] = 0;
         }
-        if constexpr (HSI) {                         // every byte 255 again, every status bit "painted" (bpw:586, 706-707)
-            reset_thickness<KW>(P, a.thick() + (size_t)env * 64 * a.mask_stride(), lane, painted);
-            observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
-        } else if constexpr (BIG) {
-            masks.clear();
-            observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, obs_row, wl.cnt);
-        } else {
-            observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, obs_row, wl.cnt);
-        }
+        // every byte 255 again, every status bit "painted" (bpw:586, 706-707) / the LDS copies cleared
+        if constexpr (HSI) reset_thickness<KW>(P, a.thick() + (size_t)env * 64 * a.mask_stride(), lane, painted);
+        if constexpr (BIG) masks.clear();
+        for (int k = lane; k < od; k += 64) obs_row[k] = ldg(P.reset_obs, start * od + k);     // see PartDev::reset_obs
     }
     STAMP(PH_OBS);
     masks.template store<KW>(painted, last);
