@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
+    TRACE_BEGIN();
     load_state_motion(state_rec, S);
     PROF_BEGIN();
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
     PROF_END();
+    TRACE_END(env, dn);
 }
 
 // ---------------------------------------------------------------- parts with more than 16 384 samples (KW > 4)
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
+    PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
     const int dn = step_env<0, false, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                    new_angle, StepRows{&a}, wl);
+                                                    new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
 
@@ -386,8 +389,9 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             __shared__ int s_cand[FRAG_WAVES][64];
             __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
             const WaveLds wl{s_cand[wave], s_centres[wave], nullptr};
+            PROF_BEGIN();
             const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                            new_angle, row, wl);
+                                                            new_angle, row, wl PROF_PASS);
             store_state_live(state_rec, S, lane, dn != 0);
         }
         __syncthreads();            // the observations of step t are written (workgroup-scope fences included)
@@ -718,8 +722,10 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     {   // the samples of a word ascend on axis a1 (paintrl.h); derive the equal-run ends the observation uses
         const double *x = t->sample_xyz[d.a1];
         std::vector<uint8_t> ub((size_t)t->n_samples_pad);
+        std::vector<double> pivot((size_t)d.n_words * 8);
         for (int w = 0; w < d.n_words; ++w) {
             const double *xw = x + (size_t)w * 64;
+            for (int j = 0; j < 8; ++j) pivot[(size_t)w * 8 + j] = xw[8 * j + 7];
             for (int j = 1; j < 64; ++j)
                 if (!(xw[j - 1] <= xw[j]))
                     return fail(PRL_E_INVALID, "samples of word %d do not ascend on axis %d", w, d.a1);
@@ -730,6 +736,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             }
         }
         UP(samp_ub, ub.data(), ub.size());
+        UP(word_pivot, pivot.data(), pivot.size());
     }
     d.n_start = t->n_start;
     if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
@@ -1224,6 +1231,15 @@ int prl_debug_phase_cycles(unsigned long long *out, int n) {
     for (int k = 0; k < n && k < 16; ++k) out[k] = host[k];
     unsigned long long zero[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
+    return PRL_OK;
+}
+#endif
+
+#ifdef PRL_WAVE_TRACE
+// diagnostic build only: the last launch's per-env trace rows (start, end, path counters, done)
+int prl_debug_wave_trace(unsigned long long *out, int n_envs) {
+    if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;
 }
 #endif

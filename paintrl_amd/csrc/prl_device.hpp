@@ -46,6 +46,7 @@ struct PartDev {
     gu64_p word_valid;
     gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
+    gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
     gfloat_p samp_f32;            // [n_samples_pad][4]: x y z 0 rounded to float (derived): the paint pre-filter
     double samp_absmax;           // largest |coordinate| of a real sample: bounds the pre-filter's rounding error
     double sg_o1, sg_o2, sg_inv;
@@ -201,6 +202,32 @@ __device__ __forceinline__ double wave_min_d(double v) {
     return bcast_d(v, 63);
 }
 
+// The same for values known to be >= +0.0 or NaN (squared distances, ray parameters): such doubles order like their
+// bit patterns, and a 32-bit unsigned minimum takes its DPP operand directly (one instruction per step instead of
+// two moves, a compare and two selects per half).  High words first, then the low words of the lanes that hold the
+// smallest high word.  A NaN orders above +inf here instead of poisoning nothing: callers compare lanes with `==`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin(uint32_t v) {
+    return min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_umin<0x111, 0xf>(v);
+    v = dpp_umin<0x112, 0xf>(v);
+    v = dpp_umin<0x114, 0xf>(v);
+    v = dpp_umin<0x118, 0xf>(v);
+    v = dpp_umin<0x142, 0xa>(v);
+    v = dpp_umin<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ double wave_min_nonneg_d(double v) {
+    const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
+    const uint32_t mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xffffffffu);
+    return __hiloint2double((int)mh, (int)ml);
+}
+
 __device__ __forceinline__ double wave_max_d(double v) {
     WAVE_REDUCE_DPP(double, v, OP_MAX, dpp_d);
     return bcast_d(v, 63);
@@ -214,20 +241,24 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // Wave-wide sum the same way; a lane without a source contributes 0 (old = 0).  Used on packed
 // 16-bit counters too: partial sums never carry across fields as long as the totals fit.
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp0_u64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {       // (the adds take their DPP operand directly)
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Every caller packs counters that never carry across bit 32 (4 x 16-bit or 2 x 32-bit fields whose totals fit):
+// the two halves are summed on their own, without the carry chain of a 64-bit add.
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-    v += dpp0_u64<0x111, 0xf>(v);
-    v += dpp0_u64<0x112, 0xf>(v);
-    v += dpp0_u64<0x114, 0xf>(v);
-    v += dpp0_u64<0x118, 0xf>(v);
-    v += dpp0_u64<0x142, 0xa>(v);
-    v += dpp0_u64<0x143, 0xc>(v);
-    return bcast_u64(v, 63);
+    return ((uint64_t)wave_sum_u32((uint32_t)(v >> 32)) << 32) | wave_sum_u32((uint32_t)v);
 }
 
 // Wave-wide sum of doubles (same shifts; a lane without a source adds +0.0).  The order of the additions is this

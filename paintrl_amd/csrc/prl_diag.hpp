@@ -3,6 +3,10 @@
 // The product build defines none of the PRL_* diagnostic macros: STAMP / WCNT / PROF_* expand to nothing and the
 // kernels carry no instrumentation.  Diagnostic builds (tools/, tests/test_gpu_forced_paths.py) may define:
 //   PRL_PHASE_TIMING=<k>       s_memtime deltas of phase k summed over all waves (tools/phase_timing.py)
+//   PRL_WAVE_TRACE             per env and launch: start / end time and path counters of its wave (tools/wave_trace.py)
+//   PRL_CUT=<1|2|3>           instruction-count builds: no observation / nor painting / nor shots (wrong results;
+//                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
+//   PRL_NO_PRIO                no s_setprio by progress (A/B of the issue-priority scheme, prl_step.hpp)
 //   PRL_PAINT_ONE_ROW_PER_TRIP one sample-grid row per trip of the painter (multi-trip path)   } the general paths,
 //   PRL_FORCE_FULL_SCANS       whole-table scans instead of the ring searches                } run by the forced-
 //   PRL_FORCE_GENERAL_RAY      general two-stage ray search instead of the convex fast path  } path parity tests
@@ -13,7 +17,45 @@
 
 namespace {
 
+#ifdef PRL_WAVE_TRACE
+// Per wave: [start, end] in s_memrealtime ticks (100 MHz, one clock for the whole device) and eight 8-bit path
+// counters bumped where a slow path is entered (WCNT slots: 0 general ray search, 1 its second stage, 2 chunk
+// visits, 3 vertex-ring trips, 4 neighbourhood ray rounds, 5 paint trips, 6 straddle / f64 trips, 7 single-facet hits).
+#define PRL_TRACE_ENVS 8192
+__device__ unsigned long long g_wave_trace[4 * PRL_TRACE_ENVS];
+__shared__ unsigned long long g_wcnt[4];
+#define WCNT(slot, v)                                                                              \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) g_wcnt[threadIdx.x >> 6] += (unsigned long long)(v) << (8 * (slot)); \
+    } while (0)
+#define TRACE_BEGIN()                                                          \
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();      \
+    if ((threadIdx.x & 63) == 0) g_wcnt[threadIdx.x >> 6] = 0
+#define TRACE_END(env, dn)                                                     \
+    do {                                                                       \
+        if ((threadIdx.x & 63) == 0 && (env) < PRL_TRACE_ENVS) {               \
+            g_wave_trace[4 * (env)] = trace_t0;                                \
+            g_wave_trace[4 * (env) + 1] = __builtin_amdgcn_s_memrealtime();    \
+            g_wave_trace[4 * (env) + 2] = g_wcnt[threadIdx.x >> 6];            \
+            g_wave_trace[4 * (env) + 3] = (unsigned long long)((dn) != 0) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 1) | \
+                                          ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 40);   /* HW_ID, XCC_ID */ \
+        }                                                                      \
+    } while (0)
+#else
 #define WCNT(slot, v)
+#define TRACE_BEGIN() \
+    do {              \
+    } while (0)
+#define TRACE_END(env, dn) \
+    do {                   \
+    } while (0)
+#endif
+
+#ifdef PRL_NO_PRIO                       // A/B switch for the progress-based issue priority (prl_step.hpp)
+#define PRIO_BY_PROGRESS(p)
+#else
+#define PRIO_BY_PROGRESS(p) __builtin_amdgcn_s_setprio(p)
+#endif
 
 #ifdef PRL_PHASE_TIMING
 // (cdna_hip_programming.md "In-kernel stamps"): the stamps go to a buffer nothing else reads.  ONE phase is

@@ -137,32 +137,61 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
         smask[k] = __ballot(straddle);
     }
     // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
-    // { xs > x1 } a suffix of the word: a 7-probe lower bound by the owning lane, all rows at once.
+    // { xs > x1 } a suffix of the word.  The owning lane finds the prefix length in two round trips, all its rows at
+    // once: the word's eight pivots (samples 7, 15, .. 63) name the group of eight that holds the boundary, the
+    // group itself gives the position.
     // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
     {
         bool any = false;
 #pragma unroll
         for (int k = 0; k < KW; ++k) any = any || vline[k];
         if (__ballot(any)) {
-            int base[KW_MAX], pos[KW_MAX];
+            const f64x4 GAS *pv = reinterpret_cast<const f64x4 GAS *>(P.word_pivot);
+            const f64x4 GAS *sx4 = reinterpret_cast<const f64x4 GAS *>(sx);
+            int grp[KW_MAX];
+            {
+                f64x4 pa[KW_MAX], pb[KW_MAX];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                base[k] = vline[k] ? (lane + 64 * (slot0 + k)) << 6 : 0;      // other lanes probe word 0: harmless, in bounds
-                pos[k] = 0;
+                for (int k = 0; k < KW; ++k) {
+                    const int w = vline[k] ? lane + 64 * (slot0 + k) : 0;    // other lanes probe word 0: harmless, in bounds
+                    pa[k] = ldg(pv, 2 * w);
+                    pb[k] = ldg(pv, 2 * w + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+                    grp[k] = (pa[k].x < x1) + (pa[k].y < x1) + (pa[k].z < x1) + (pa[k].w < x1) + (pb[k].x < x1) + (pb[k].y < x1) +
+                             (pb[k].z < x1) + (pb[k].w < x1);
+            }
+            int pos[KW_MAX];
+            bool eq[KW_MAX];
+            {
+                f64x4 ga[KW_MAX], gb[KW_MAX];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int w = vline[k] ? lane + 64 * (slot0 + k) : 0;
+                    const int g8 = grp[k] < 8 ? grp[k] : 7;                  // grp = 8: the whole word lies left of x1
+                    ga[k] = ldg(sx4, 16 * w + 2 * g8);
+                    gb[k] = ldg(sx4, 16 * w + 2 * g8 + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int in = (ga[k].x < x1) + (ga[k].y < x1) + (ga[k].z < x1) + (ga[k].w < x1) + (gb[k].x < x1) + (gb[k].y < x1) +
+                                   (gb[k].z < x1) + (gb[k].w < x1);
+                    pos[k] = grp[k] < 8 ? 8 * grp[k] + in : 64;
+                    // the first sample not left of x1 lies in this group: it equals x1 iff some sample of the group does
+                    eq[k] = grp[k] < 8 && (ga[k].x == x1 || ga[k].y == x1 || ga[k].z == x1 || ga[k].w == x1 || gb[k].x == x1 ||
+                                           gb[k].y == x1 || gb[k].z == x1 || gb[k].w == x1);
+                }
             }
 #pragma unroll
-            for (int step = 32; step >= 0; step = step > 1 ? step >> 1 : step - 1) {   // 32 .. 1, then the closing probe
-                double probe[KW_MAX];
-#pragma unroll
-                for (int k = 0; k < KW; ++k) probe[k] = ldg(sx, base[k] + pos[k] + (step ? step - 1 : 0));
-                __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip per step
-#pragma unroll
-                for (int k = 0; k < KW; ++k) pos[k] += probe[k] < x1 ? (step ? step : 1) : 0;
-            }
-#pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const int at = base[k] + (pos[k] < 64 ? pos[k] : 63);
-                int ub = (pos[k] < 64 && ldg(sx, at) == x1) ? (int)ldg(P.samp_ub, at) : pos[k];
+                int ub = pos[k];
+                if (__ballot(eq[k] && vline[k])) {                  // a sample exactly on the line: the run of equals ends at samp_ub
+                    const int at = ((vline[k] ? lane + 64 * (slot0 + k) : 0) << 6) + (pos[k] < 64 ? pos[k] : 63);
+                    if (eq[k]) ub = (int)ldg(P.samp_ub, at);
+                }
                 if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
                 if (vline[k]) {
                     const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
@@ -176,26 +205,37 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
             }
         }
     }
+    // Pass 3: the words that straddle the tool on both axes or on x2 only, one sample per lane, four words per trip
+    // (their loads travel together).  32-bit work only: the uniform valid / painted words become lane predicates
+    // (inverse ballot) and the counters are four 8-bit fields (a lane sees at most 64 straddling words per call).
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         uint64_t sm = smask[k];
         while (sm) {                                // wave-uniform loop over the words that straddle the tool
             WCNT(6, 1);
-            const int L = __builtin_ctzll(sm);
-            sm &= sm - 1;
-            const int w2 = L + 64 * (slot0 + k);
-            const double xs = ldg(sx, (w2 << 6) + lane), ys = ldg(sy, (w2 << 6) + lane);
-            const uint64_t vs = P.word_valid[w2];
-            // one sample per lane, 32-bit work only: the uniform valid / painted words become lane
-            // predicates (inverse ballot) and the counters are four 8-bit fields (a lane sees at most
-            // 64 straddling words per call)
-            const uint64_t pw = bcast_u64(painted[k], L);
-            const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs) && !(xs == x1 && ys == x2);
-            const bool gy = ys > x2, lx = xs < x1;
-            const uint32_t sh = (xs > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys < x2) ? 16u : 24u));
-            const uint32_t one = cnt ? (1u << sh) : 0u;
-            tot_s += one;
-            und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
+            int L[4];
+            uint64_t vs[4];
+            double xs[4], ys[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool has = sm != 0;
+                L[q] = has ? __builtin_ctzll(sm) : 0;
+                sm &= sm - 1;                       // (0 stays 0)
+                const int w2 = L[q] + 64 * (slot0 + k);
+                xs[q] = ldg(sx, (w2 << 6) + lane);
+                ys[q] = ldg(sy, (w2 << 6) + lane);
+                vs[q] = has ? P.word_valid[w2] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t pw = bcast_u64(painted[k], L[q]);
+                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs[q]) && !(xs[q] == x1 && ys[q] == x2);
+                const bool gy = ys[q] > x2, lx = xs[q] < x1;
+                const uint32_t sh = (xs[q] > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys[q] < x2) ? 16u : 24u));
+                const uint32_t one = cnt ? (1u << sh) : 0u;
+                tot_s += one;
+                und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
+            }
         }
     }
     // widen the 8-bit straddle counters into the 16-bit fields

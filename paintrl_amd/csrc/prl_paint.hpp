@@ -95,20 +95,25 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     // the float64 centres are only needed for the cell ranges and by the rare float64 branch, which reads them
     // from LDS again: fifteen doubles held across the word loop would be thirty vector registers
     float cf[PAINT_PER_ACTION][3];
-    int cx_lo = 0x7fffffff, cx_hi = -0x7fffffff, cy_lo = 0x7fffffff, cy_hi = -0x7fffffff;
+    // cell ranges of the five centres: the cell coordinate is monotone in the position, so the range of the cells
+    // is the cells of the range (four conversions instead of ten)
+    double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
 #pragma unroll
     for (int k = 0; k < PAINT_PER_ACTION; ++k) {
         const double c0 = cen_lds[3 * k], c1 = cen_lds[3 * k + 1], c2 = cen_lds[3 * k + 2];
         cf[k][0] = (float)c0;
         cf[k][1] = (float)c1;
         cf[k][2] = (float)c2;
-        const int icx = cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx);
-        const int icy = cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny);
-        cx_lo = icx < cx_lo ? icx : cx_lo;
-        cx_hi = icx > cx_hi ? icx : cx_hi;
-        cy_lo = icy < cy_lo ? icy : cy_lo;
-        cy_hi = icy > cy_hi ? icy : cy_hi;
+        const double h1 = sel3(c0, c1, c2, P.a1), h2 = sel3(c0, c1, c2, P.a2);
+        lo1 = fmin(lo1, h1);
+        hi1 = fmax(hi1, h1);
+        lo2 = fmin(lo2, h2);
+        hi2 = fmax(hi2, h2);
     }
+    // (a NaN centre hits nothing and is ignored by fmin / fmax; five of them leave the inverted range: cell -2 as for a single NaN)
+    const bool none = !(lo1 <= hi1);
+    const int cx_lo = none ? -2 : cell_coord(lo1, P.sg_o1, P.sg_inv, P.sg_nx), cx_hi = none ? -2 : cell_coord(hi1, P.sg_o1, P.sg_inv, P.sg_nx);
+    const int cy_lo = none ? -2 : cell_coord(lo2, P.sg_o2, P.sg_inv, P.sg_ny), cy_hi = none ? -2 : cell_coord(hi2, P.sg_o2, P.sg_inv, P.sg_ny);
     double band = 16.0 * radius * 1.1920928955078125e-07 * (P.samp_absmax + radius) + 9.5367431640625e-07 * r2;
 #ifdef PRL_WIDE_PAINT_BAND
     band *= 4096.0;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], doub
 // Lane holding the wave's best (t, rank); -1 if no lane has a hit.
 __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
     if (__ballot(best_t < INFINITY) == 0) return -1;
-    tmin = wave_min_d(best_t);
+    tmin = wave_min_nonneg_d(best_t + 0.0);        // t >= 0 or +inf (no hit in this lane); + 0.0 turns a -0.0 into +0.0
     const uint64_t tie = __ballot(best_t == tmin);
     if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
     const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index

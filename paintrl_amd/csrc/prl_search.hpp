@@ -67,6 +67,56 @@ __device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const dou
     }
 }
 
+// The vertices of a (2k+1)-row cell block, rows as index ranges (lane 2r / 2r+1 of `bound` = begin / end of row r),
+// flattened into one candidate list and scanned two candidates per lane and trip.
+template <int NROWS>
+__device__ __forceinline__ void ring_block_scan(PartRef P, int bound, const double pt[3], int lane, double &best_d,
+                                                int &best_rank, int &best_idx) {
+    // per-row begin and exclusive prefix of counts, wave-uniform
+    int rbeg[NROWS], rpre[NROWS + 1];
+    rpre[0] = 0;
+#pragma unroll
+    for (int r = 0; r < NROWS; ++r) {
+        const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+        rbeg[r] = b0;
+        rpre[r + 1] = rpre[r] + (e0 - b0);
+    }
+    const int total = rpre[NROWS];
+    for (int c0 = 0; c0 < total; c0 += 128) {           // two candidates per lane and trip: one round trip
+        WCNT(3, 1);                                     // covers the 60-90 vertices of a typical 3 x 3 block
+        const int ca = c0 + lane, cb = ca + 64;
+        const bool ka = ca < total, kb = cb < total;
+        int va = rbeg[0] + ca, vb = rbeg[0] + cb;
+#pragma unroll
+        for (int r = 1; r < NROWS; ++r) {
+            if (ca >= rpre[r]) va = rbeg[r] + (ca - rpre[r]);
+            if (cb >= rpre[r]) vb = rbeg[r] + (cb - rpre[r]);
+        }
+        double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+        int ra = 0, rb = 0;
+        if (ka) load_vertex(P, va, ax, ay, az, ra);
+        if (kb) load_vertex(P, vb, bx, by, bz, rb);
+        if (ka) {
+            const double dx = ax - pt[0], dy = ay - pt[1], dz = az - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd < best_d || (dd == best_d && ra < best_rank)) {
+                best_d = dd;
+                best_rank = ra;
+                best_idx = va;
+            }
+        }
+        if (kb) {
+            const double dx = bx - pt[0], dy = by - pt[1], dz = bz - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd < best_d || (dd == best_d && rb < best_rank)) {
+                best_d = dd;
+                best_rank = rb;
+                best_idx = vb;
+            }
+        }
+    }
+}
+
 // Exact nearest neighbour by expanding rings: the (2k+1)^2 cell block around the query's cell is
 // scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
 // outside the block is at least k cells away in the principal plane, so the result is exact once the
@@ -83,40 +133,15 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         const int rcy = icy - ring + (lane >> 1);
         const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
         const int bound = okr ? ldg(P.vg_start, rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
-        // per-row begin and exclusive prefix of counts, wave-uniform (<= 7 rows)
-        int rbeg[7], rpre[8];
-        rpre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int b0 = __builtin_amdgcn_readlane(bound, 2 * r), e0 = __builtin_amdgcn_readlane(bound, 2 * r + 1);
-            rbeg[r] = b0;
-            rpre[r + 1] = rpre[r] + ((r < nrows) ? e0 - b0 : 0);
-        }
-        const int total = rpre[7];
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
-        for (int c0 = 0; c0 < total; c0 += 64) {
-            WCNT(3, 1);
-            const int c = c0 + lane;
-            if (c < total) {
-                int v = rbeg[0] + c;
-#pragma unroll
-                for (int r = 1; r < 7; ++r)
-                    if (c >= rpre[r]) v = rbeg[r] + (c - rpre[r]);
-                double vx, vy, vz;
-                int rk;
-                load_vertex(P, v, vx, vy, vz, rk);
-                const double dx = vx - pt[0], dy = vy - pt[1], dz = vz - pt[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                    best_d = dd;
-                    best_rank = rk;
-                    best_idx = v;
-                }
-            }
-        }
-        dmin = wave_min_d(best_d);
+        // (one copy of the scan per block height: the first ring -- nearly every query ends there -- then maps a
+        // candidate to its row with two selects instead of six)
+        if (ring == 1) ring_block_scan<3>(P, bound, pt, lane, best_d, best_rank, best_idx);
+        else if (ring == 2) ring_block_scan<5>(P, bound, pt, lane, best_d, best_rank, best_idx);
+        else ring_block_scan<7>(P, bound, pt, lane, best_d, best_rank, best_idx);
+        dmin = wave_min_nonneg_d(best_d);
         const double lim = ring * P.vg_accept;          // ring * 0.99 * cell
         exact = dmin <= lim * lim;
     }
@@ -128,7 +153,7 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         best_rank = 0x7fffffff;
         best_idx = -1;
         nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
-        dmin = wave_min_d(best_d);
+        dmin = wave_min_nonneg_d(best_d);
     }
     const uint64_t tie = __ballot(best_d == dmin);
     if (tie == 0) return -1;                                        // NaN query point
@@ -260,7 +285,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
                 }
             }
         }
-        dmin = wave_min_d(best_d);
+        dmin = wave_min_nonneg_d(best_d);
         const double lim = ring * (0.99 / P.sg_inv);        // ring * 0.99 * sample cell
         exact = dmin <= lim * lim;
     }
@@ -282,7 +307,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
                 best_idx = sidx;
             }
         }
-        dmin = wave_min_d(best_d);
+        dmin = wave_min_nonneg_d(best_d);
     }
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
     const uint64_t win = __ballot(best_d == dmin && best_rank == rmin && best_idx >= 0);
@@ -344,6 +369,8 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
         }
     }
     // the chosen triangle's normal, quaternion and centre offset: one wave-uniform read of its record's tail
+    // (measured: every candidate lane fetching its whole record and broadcasting the winner's tail saves the
+    // dependent read but costs more than it gains, 48.0 -> 48.8 us)
     const int tj = __builtin_amdgcn_readlane(ti, rfl(j));
     tri = tj;
     const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)tj * (TRI_REC / 2);

@@ -107,12 +107,24 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
     uint32_t n_succeeded_l = 0;
     double *cen = wl.cen;
+    // the guided point's offset from the pose (bpw:865-880: d1 along axis a1, d2 * lwr along a2) is the same for the
+    // five shots; the third component is -0.0, the one addend that leaves every double (either zero too) unchanged
+    const double delta_2 = d2 * P.lwr;
+    const double dvec[3] = {P.a1 == 0 ? d1 : (P.a2 == 0 ? delta_2 : -0.0), P.a1 == 1 ? d1 : (P.a2 == 1 ? delta_2 : -0.0),
+                            P.a1 == 2 ? d1 : (P.a2 == 2 ? delta_2 : -0.0)};
+#if defined(PRL_CUT) && PRL_CUT >= 3              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
+    for (int shot = 0; shot < 0; ++shot) {
+#else
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+#endif
+        // Issue priority by progress (s_setprio 3: shots 0-1, 2: shots 2-4, 1: painting, 0: observation).  The SIMD's
+        // arbiter serves its oldest wave first: of the four envs that share a SIMD the youngest then ends 14 us after
+        // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
+        // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
+        if (shot <= 1) PRIO_BY_PROGRESS(3);
+        else PRIO_BY_PROGRESS(2);
         // bpw:865-880 get_guided_point
-        double pt[3] = {cur_pose[0], cur_pose[1], cur_pose[2]};
-        const double delta_2 = d2 * P.lwr;
-        if (P.a1 == 0) pt[0] += d1; else if (P.a1 == 1) pt[1] += d1; else pt[2] += d1;
-        if (P.a2 == 0) pt[0] += delta_2; else if (P.a2 == 1) pt[1] += delta_2; else pt[2] += delta_2;
+        const double pt[3] = {cur_pose[0] + dvec[0], cur_pose[1] + dvec[1], cur_pose[2] + dvec[2]};
         const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
         double t, hit[3], pos[3], orn[3], quat[4];
         STAMP(PH_MATH);
@@ -192,6 +204,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     } else {
         pose_orn_quat(cur_norm, S.quat);
     }
+    PRIO_BY_PROGRESS(1);
     if constexpr (!NORMAL && !BIG) masks.template load<KW>(painted, last);
     STAMP(PH_LOAD);
     // bpw:568-577 fast_paint + _paint for the five shots
@@ -216,8 +229,10 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+#if !defined(PRL_CUT) || PRL_CUT < 2
             paint_shots_union(P, C.paint_radius, cen, lane, RegWords<KW>{painted, last, new_last, lane}, succeeded,
                               pixel_counter);
+#endif
 #pragma unroll
             for (int k = 0; k < KW; ++k) last[k] = new_last[k];
         }
@@ -252,10 +267,14 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     if (!dn) S.total_return += actual;
     STAMP(PH_APPLY);
 
+    PRIO_BY_PROGRESS(0);
     const bool do_reset = dn && C.auto_reset;
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
     double *obs_row = a.obs() + (size_t)env * od;
     double *term_row = do_reset ? (a.final_obs() ? a.final_obs() + (size_t)env * od : nullptr) : obs_row;
+#if defined(PRL_CUT) && PRL_CUT >= 1
+    term_row = nullptr;
+#endif
     if (term_row) {
         if constexpr (BIG) observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, term_row, wl.cnt);
         else observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row, wl.cnt);

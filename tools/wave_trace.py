@@ -1,0 +1,125 @@
+"""Diagnostic: how long each env's wave lives inside one step_kernel launch, and which slow paths it took.
+
+Built HERE beforehand (this script builds nothing and spawns nothing):
+
+    python tools/build_variant.py trace -DPRL_WAVE_TRACE
+    gpurun -- python tools/wave_trace.py
+
+The launch lasts as long as its slowest wave: the table shows what the waves in the tail have in common
+(prl_diag.hpp lists the counters).  Never used by the product or the tests.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from paintrl_amd import build as hb  # noqa: E402
+
+SLOTS = ['gen_ray', 'ray_stage2', 'chunks', 'ring_trips', 'nbr_rounds', 'paint_trips', 'straddle', 'facet_hits']
+
+
+def main():
+    import torch
+    from paintrl_amd import _lib, part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    hb.LIBRARY = os.path.join(REPO, 'tools', '_ab', 'trace.so')
+    os.environ['PAINTRL_LAX_SYMBOLS'] = '1'
+    _lib._lib = None
+    lib = _lib.load()
+    lib.prl_debug_wave_trace.argtypes = [C.c_void_p, C.c_int]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
+    dt = DeviceTables(tables)
+    n = int(os.environ.get('PRL_ENVS', '4096'))
+    steps = int(os.environ.get('PRL_TRACE_STEPS', '40'))
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234)
+    acts = torch.randint(0, 4, (200 + steps, n), generator=gen, device='cuda', dtype=torch.int32)
+    env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678)
+    env.reset()
+    for s in range(200):
+        env.step_raw(acts[s])
+    torch.cuda.synchronize()
+    rows = []
+    buf = np.zeros((n, 4), dtype=np.uint64)
+    for s in range(200, 200 + steps):
+        env.step_raw(acts[s])
+        torch.cuda.synchronize()
+        rc = lib.prl_debug_wave_trace(buf.ctypes.data, n)
+        assert rc == 0
+        rows.append(buf.copy())
+    env.close()
+    tr = np.stack(rows).astype(np.int64)                          # [steps, n, 4]
+    t0 = tr[:, :, 0].min(axis=1, keepdims=True)
+    start = (tr[:, :, 0] - t0) * 0.01                             # us
+    end = (tr[:, :, 1] - t0) * 0.01
+    life = end - start
+    cnt = np.stack([(tr[:, :, 2] >> (8 * k)) & 0xff for k in range(8)], axis=-1)
+    done = (tr[:, :, 3] & 1) != 0
+    hw = (tr[:, :, 3] >> 1) & 0xffffffff
+    xcc = (tr[:, :, 3] >> 40) & 15
+    simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    where = {'xcc': xcc, 'se': se, 'sh': sh, 'cu': cu, 'simd': simd, 'wave_slot': hw & 15}
+    span = end.max(axis=1)
+    print('launch span (first wave start -> last wave end): mean %.1f us, min %.1f, max %.1f' % (span.mean(), span.min(), span.max()))
+    print('wave start offset: mean %.2f us, 99%% %.2f, max %.2f' % (start.mean(), np.percentile(start, 99), start.max()))
+    q = [50, 75, 90, 99, 99.9, 100]
+    print('wave life us:  mean %.1f  ' % life.mean() + '  '.join('p%g %.1f' % (p, np.percentile(life, p)) for p in q))
+    print('wave end us:   mean %.1f  ' % end.mean() + '  '.join('p%g %.1f' % (p, np.percentile(end, p)) for p in q))
+    print('done waves: %.2f %%, life mean %.1f us (others %.1f)' % (100 * done.mean(), life[done].mean() if done.any() else 0, life[~done].mean()))
+    print('counters, mean per wave: ' + '  '.join('%s %.2f' % (nm, cnt[..., k].mean()) for k, nm in enumerate(SLOTS)))
+    # least squares: life ~ c0 + sum_k c_k * counter_k + c_done * done
+    X = np.concatenate([np.ones(life.size)[:, None], cnt.reshape(-1, 8).astype(float), done.reshape(-1, 1).astype(float)], axis=1)
+    coef, *_ = np.linalg.lstsq(X, life.reshape(-1), rcond=None)
+    print('least squares  life = %.1f' % coef[0] + ''.join(' %+.2f*%s' % (coef[1 + k], nm) for k, nm in enumerate(SLOTS)) + ' %+.2f*done' % coef[9])
+    # what the slowest 1 % have in common
+    thr = np.percentile(life, 99)
+    slow = life >= thr
+    print('slowest 1 %% (life >= %.1f us): ' % thr + '  '.join('%s %.2f' % (nm, cnt[slow][:, k].mean()) for k, nm in enumerate(SLOTS)) +
+          '  done %.2f' % done[slow].mean())
+    for k, nm in enumerate(SLOTS):
+        vals = np.unique(cnt[..., k])
+        if len(vals) > 12:
+            edges = np.percentile(cnt[..., k], [0, 25, 50, 75, 90, 99, 100])
+            vals = np.unique(edges.astype(int))
+        txt = []
+        for v in vals:
+            m = cnt[..., k] == v
+            if m.any():
+                txt.append('%d: %.1f us (%.1f %%)' % (v, life[m].mean(), 100 * m.mean()))
+        print('  life by %-11s ' % nm + '  '.join(txt))
+    for nm, arr in where.items():
+        txt = []
+        for v in np.unique(arr):
+            m = arr == v
+            txt.append('%d: %.1f (%.1f %%)' % (v, life[m].mean(), 100 * m.mean()))
+        print('  life by %-9s ' % nm + '  '.join(txt))
+    # waves sharing a SIMD within one launch
+    key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    per = []
+    for s in range(key.shape[0]):
+        u, c = np.unique(key[s], return_counts=True)
+        per.append(c)
+        if s == 0:
+            print('  launch 0: %d distinct SIMDs, waves per SIMD min %d max %d; distinct CUs %d' % (len(u), c.min(), c.max(), len(np.unique(key[s] // 4))))
+            cmap = dict(zip(u, c))
+            nshare = np.array([cmap[k] for k in key[s]])
+            for v in np.unique(nshare):
+                print('    waves on a SIMD with %d waves: life %.1f us (%.1f %%)' % (v, life[s][nshare == v].mean(), 100 * (nshare == v).mean()))
+            # per SIMD: spread of its waves' lives
+            order = np.argsort(key[s], kind='stable')
+            ks, ls = key[s][order], life[s][order]
+            grp = np.split(ls, np.nonzero(np.diff(ks))[0] + 1)
+            means = np.array([g.mean() for g in grp])
+            print('    per-SIMD mean life: p10 %.1f p50 %.1f p90 %.1f; mean within-SIMD spread (max-min) %.1f us' % (
+                np.percentile(means, 10), np.percentile(means, 50), np.percentile(means, 90), np.mean([g.max() - g.min() for g in grp])))
+    hist, edges = np.histogram(life, bins=24)
+    for h, e0, e1 in zip(hist, edges[:-1], edges[1:]):
+        print('  %5.1f-%5.1f us  %6.2f %%' % (e0, e1, 100.0 * h / life.size))
+
+
+if __name__ == '__main__':
+    main()
