@@ -247,8 +247,8 @@ def main():
                               seed=pdist.rank_seed(5678, rank), max_possible_point=[9148, 14350], **common)
         subs = [env]
     else:
-        if args.streams > 1 and (args.policy != 'random' or args.envs % args.streams):
-            raise SystemExit('--streams needs --policy random and a divisible --envs')
+        if args.streams > 1 and (args.policy not in ('random', 'mlp') or args.envs % args.streams):
+            raise SystemExit('--streams needs --policy random or mlp and a divisible --envs')
         n_sub = args.envs // args.streams
         subs = [BatchedPaintEnv(dt, n_sub, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=9148,
                                 **common) for g in range(args.streams)]
@@ -305,6 +305,7 @@ def main():
         if args.policy == 'mlp':
             from paintrl_amd.policy import FusedPolicy
             fused = FusedPolicy(torch_policy)
+            group_policies = [fused] + [FusedPolicy(torch_policy, seed=g) for g in range(1, len(subs))]
 
             class _Fused(object):                   # same call shape as MLPPolicy.act, float64 observations in
                 def act(self, obs32, generator=None):
@@ -357,6 +358,13 @@ def main():
                             e.step_raw(sub_actions[g][k])
                 elif policy is None:
                     env.step_raw(actions[k])
+                elif len(subs) > 1:
+                    # each env group alternates policy and env step on its own stream: one group's policy launch
+                    # (latency bound, a few us) runs under the other group's env step
+                    for g, e in enumerate(subs):
+                        with torch.cuda.stream(sub_streams[g]):
+                            act, _, _ = group_policies[g].act(e.obs)
+                            e.step_raw(act)
                 else:
                     act, _, _ = policy.act(obs_for_policy(), gen)
                     env.step_raw(act)

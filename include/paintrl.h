@@ -230,18 +230,30 @@ int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, co
                    float *logp /* or NULL */, float *value /* or NULL */, float *logits /* or NULL, [N][n_actions] */,
                    void *stream);
 
+/* Policy + env step in ONE launch: what a rollout worker does per step (paint_ppo.py:170-195: policy forward on the
+ * current observations, sample, env.step).  Sixteen envs per workgroup run the policy together, each wave then steps
+ * its env with the sampled action.  obs_in f64[N][obs_dim] is what the policy sees (the obs a previous step or
+ * reset wrote; it may be the same buffer as obs only if the caller no longer needs it: rows are read before they are
+ * written, by the same workgroup).  action i32[N], logp f32[N], value f32[N] out; the remaining arguments are
+ * prl_batch_step's.  Results are bit for bit those of prl_policy_act (in-kernel sampling stream: rng_count u32[N],
+ * rng_seed) followed by prl_batch_step.  The batch must have auto_reset, discrete actions, PAINT_METHOD 'fast'. */
+int prl_batch_act_step(PrlBatch *batch, const PrlPolicyWeights *weights, const double *obs_in, uint32_t *rng_count,
+                       uint64_t rng_seed, int32_t *action, float *logp, float *value, double *obs, double *reward,
+                       uint8_t *done, double *info, double *final_obs /* or NULL */, void *stream);
+
 /* A whole rollout fragment -- what one RLlib rollout worker does between two learner updates
- * (paint_ppo.py:170-195, sample_batch_size steps of policy forward + env.step) -- in ONE persistent launch:
- * sixteen envs per workgroup, policy and step alternate inside the kernel with workgroup barriers only, env state
- * in registers and coverage masks in LDS for the whole fragment.  The batch must have been created with auto_reset,
- * discrete actions and PAINT_METHOD 'fast'.  All buffers are device pointers, row-major [t][env]:
+ * (paint_ppo.py:170-195, sample_batch_size steps of policy forward + env.step) -- enqueued by ONE call, no host code of
+ * the caller between the steps.  The batch must have been created with auto_reset, discrete actions and
+ * PAINT_METHOD 'fast'.  All buffers are device pointers, row-major [t][env]:
  *   obs        f64[n_steps + 1][N][obs_dim]   row 0: observations before the first step (input), row t + 1: after step t
  *   final_obs  f64[n_steps][N][obs_dim] or NULL: terminal observation of envs that finished in step t
  *   reward f64[n_steps][N], done u8[n_steps][N], info f64[n_steps][N][2]
  *   action     i32[n_steps][N]: written when `weights` is given, otherwise READ (replay / scripted / random actions)
  *   logp, value f32[n_steps][N], last_value f32[N] (value estimate of row n_steps), rng_count u32[N]: policy only
- * With `weights` the rows are bit for bit what n_steps rounds of prl_policy_act (in-kernel sampling stream, same
- * rng_count / rng_seed) + prl_batch_step produce, followed by one more prl_policy_act for last_value. */
+ * Given actions (weights == NULL): ONE persistent launch, sixteen envs per workgroup, every wave walks its env through
+ * all n_steps on its own (no barrier, no launch boundary: a slow step delays nobody), coverage masks in LDS throughout.
+ * With `weights`: n_steps launches of prl_batch_act_step and one of prl_policy_act for last_value (its draw is
+ * discarded): the rows are bit for bit what n_steps rounds of prl_policy_act + prl_batch_step produce. */
 int prl_rollout_fragment(PrlBatch *batch, const PrlPolicyWeights *weights /* or NULL */, int n_steps, double *obs,
                          double *final_obs, double *reward, uint8_t *done, double *info, int32_t *action, float *logp,
                          float *value, float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream);

@@ -79,6 +79,8 @@ SYMBOLS = {
     'prl_batch_set_pose': (C.c_int, [_vp, C.c_int, _dp, _dp]),
     'prl_batch_observe': (C.c_int, [_vp, _vp, _vp]),
     'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    'prl_batch_act_step': (C.c_int, [_vp, C.POINTER(PrlPolicyWeights), _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp]),
     'prl_rollout_fragment': (C.c_int, [_vp, C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, C.c_uint64, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),

@@ -133,12 +133,26 @@ class BatchedPaintEnv(object):
                                            C.c_void_p(info.data_ptr()), C.c_void_p(final_obs.data_ptr()), None,
                                            self._stream()), 'prl_batch_step')
 
+    def act_step_into(self, weights, obs_in, rng_count, rng_seed, action, logp, value, obs, reward, done_u8, info,
+                      final_obs=None):
+        """Policy + env step in ONE launch (``prl_batch_act_step``): the policy (``weights``: a
+        ``_lib.PrlPolicyWeights`` of device pointers) reads ``obs_in``, the sampled ``action`` (int32 (N,)), ``logp``
+        and ``value`` (float32 (N,)) and the step's rows are written into the caller's tensors.  No checks, no
+        allocations: the rollout hot loop.  Needs auto_reset=True, discrete actions, fast paint."""
+        p = self._ptr
+        rc = self.lib.prl_batch_act_step(self._batch, C.byref(weights), p(obs_in), p(rng_count), C.c_uint64(int(rng_seed)),
+                                         p(action), p(logp), p(value), p(obs), p(reward), p(done_u8), p(info),
+                                         p(final_obs), self._stream())
+        if rc:
+            _lib.check(rc, 'prl_batch_act_step')
+
     def rollout_fragment(self, n_steps, obs, final_obs, reward, done_u8, info, action, weights=None, logp=None,
                          value=None, last_value=None, rng_count=None, rng_seed=0):
-        """``n_steps`` steps in ONE persistent launch (``prl_rollout_fragment``): with ``weights`` (a
-        ``_lib.PrlPolicyWeights`` holding device pointers) the kernel runs the policy itself and WRITES ``action``
-        (int32 (T, N)), ``logp`` / ``value`` (float32 (T, N)) and ``last_value`` (float32 (N,)); without, it READS
-        ``action``.  ``obs`` is float64 (T + 1, N, obs_dim) with row 0 = the current observations; ``final_obs``
+        """``n_steps`` steps enqueued by ONE call (``prl_rollout_fragment``).  Without ``weights`` the kernel READS
+        ``action`` (int32 (T, N)) and the whole fragment is one persistent launch; with ``weights`` (a
+        ``_lib.PrlPolicyWeights`` holding device pointers) every step is one policy-and-step launch that WRITES
+        ``action``, ``logp`` / ``value`` (float32 (T, N)), and ``last_value`` (float32 (N,)) comes from a final policy
+        pass.  ``obs`` is float64 (T + 1, N, obs_dim) with row 0 = the current observations; ``final_obs``
         float64 (T, N, obs_dim) or None, ``reward`` float64 (T, N), ``done_u8`` uint8 (T, N), ``info`` float64
         (T, N, 2).  Needs auto_reset=True, discrete actions, fast paint."""
         p = self._ptr

@@ -241,20 +241,28 @@ __global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
 // prl_batch_step write.  All workgroups must be resident together (4 per CU at 4096 envs): 23 KB of LDS each.
 struct FragmentArgs {
     StepArgs s;                    // batch-level fields; the per-step output rows come from FragmentRows
-    PrlPolicyWeights w;
-    int T, use_policy;
+    int T;
     double *obs;                   // [T + 1][N][od]: row 0 = the observations before the first step (input)
     double *final_obs;             // [T][N][od]
     double *reward, *info;         // [T][N], [T][N][2]
     uint8_t *done;                 // [T][N]
-    int32_t *action;               // [T][N]: written (policy) or read (given actions)
-    float *logp, *value;           // [T][N], policy only
-    float *last_value;             // [N]: value estimate of the observation after the last step, policy only
+    const int32_t *action;         // [T][N]: the actions to take
+};
+
+// One launch = policy + env step for every env (act_step_kernel below): the step kernel's arguments plus the policy's.
+struct ActStepArgs {
+    StepArgs s;                    // s.actions is unused: the actions come from the policy phase
+    PrlPolicyWeights w;
+    const double *obs_in;          // [N][od]: the observations the policy sees (what the previous step wrote)
+    int32_t *action;               // [N] out
+    float *logp, *value;           // [N] out
     uint32_t *rng_count;           // [N]
     uint64_t rng_seed;
 };
 
-constexpr int FRAG_WAVES = 4;      // envs (= waves) per workgroup = real rows of the policy tiles
+// Envs (= waves) per workgroup of the two kernels below = rows of the policy's MFMA tiles: one workgroup per CU at
+// 4 096 envs, four waves per SIMD.
+constexpr int FRAG_WAVES = POLICY_WAVES;
 
 // Output rows of step t of a fragment (see StepRows in prl_step.hpp).
 struct FragmentRows {
@@ -317,7 +325,6 @@ __device__ __forceinline__ int opaque_s(int v) {
 template <int KW>
 __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(FragmentArgs) {
     extern __shared__ float lds[];
-    __shared__ int s_act[FRAG_WAVES];
     const FragmentArgs CAS *f0 = (const FragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane0 = threadIdx.x & 63, wave0 = rfl((int)(threadIdx.x >> 6));
     const int lane = lane0, wave = wave0, env0 = blockIdx.x * FRAG_WAVES, env = env0 + wave;
@@ -334,46 +341,16 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             m.template store<KW>(p, l);
         }
     }
+    FRAG_DECL();
     for (int t = 0;; ++t) {
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
-        const int lane = opaque_v(lane0), wave = opaque_s(wave0), tid = 64 * wave + lane;
+        const int lane = opaque_v(lane0), wave = opaque_s(wave0);
         const int env0 = opaque_s((int)blockIdx.x) * FRAG_WAVES, env = env0 + wave;
         const int n_envs = a.n_envs, T = f.T;
         const size_t n = (size_t)n_envs;
-        float *pol = lds + (size_t)FRAG_WAVES * 4 * a.mask_stride;       // policy area behind the masks (2 floats per u64)
-        if (f.use_policy) {
-            PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
-            W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
-            W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
-            const PolicyLds L = policy_lds_layout(W, FRAG_WAVES);
-            float *X = pol, *H1 = X + FRAG_WAVES * L.xs, *H2 = H1 + FRAG_WAVES * L.s1, *O = pol + L.o_off;
-            const double *obs_t = f.obs + (size_t)t * n * W.in_dim;
-            for (int i = tid; i < FRAG_WAVES * L.in_pad; i += 64 * FRAG_WAVES) {
-                const int row = i / L.in_pad, k = i - row * L.in_pad, e = env0 + row;
-                X[row * L.xs + k] = (e < n_envs && k < W.in_dim) ? (float)obs_t[(size_t)e * W.in_dim + k] : 0.0f;
-            }
-            __syncthreads();
-            policy_layers<FRAG_WAVES, FRAG_WAVES>(W, X, H1, H2, O, L.xs, L.s1, L.s2, L.in_pad, wave, lane);
-            if (tid < FRAG_WAVES && env0 + tid < n_envs) {
-                const int e = env0 + tid, A = W.n_actions;
-                const float u = policy_uniform(f.rng_seed, e, f.rng_count[e]++);
-                float o[16], lse;
-                const int act = policy_sample_row<FRAG_WAVES>(W, O, tid, u, o, lse);
-                if (t < T) {
-                    s_act[tid] = act;
-                    f.action[(size_t)t * n + e] = act;
-                    f.logp[(size_t)t * n + e] = o[act] - lse;
-                    f.value[(size_t)t * n + e] = o[A];
-                } else {
-                    f.last_value[e] = o[A];                           // the bootstrap value; its draw is discarded
-                }
-            }
-        } else if (t < T && tid < FRAG_WAVES && env0 + tid < n_envs) {
-            s_act[tid] = f.action[(size_t)t * n + env0 + tid];
-        }
         if (t >= T) break;
-        __syncthreads();
+        FRAG_T(ft1);
         if (env < n_envs) {                                           // exactly the per-step kernel's body
             const int part_id = a.env_part ? a.env_part[env] : 0;
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
@@ -384,7 +361,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             EnvState S;
             load_state_motion(state_rec, S);
             double delta1, delta2, new_angle;
-            decode_discrete_action(C, s_act[wave], delta1, delta2, new_angle);
+            decode_discrete_action(C, f.action[(size_t)t * n + env], delta1, delta2, new_angle);
             const FragmentRows row{&f, t, n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
             __shared__ int s_cand[FRAG_WAVES][64];
             __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
@@ -394,8 +371,11 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
                                                             new_angle, row, wl PROF_PASS);
             store_state_live(state_rec, S, lane, dn != 0);
         }
-        __syncthreads();            // the observations of step t are written (workgroup-scope fences included)
+        FRAG_T(ft2);
+        FRAG_ACC(1, ft1, ft2);
+        FRAG_COUNT();
     }
+    FRAG_FLUSH();
     {   // coverage masks: LDS -> HBM
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
@@ -410,6 +390,66 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         }
     }
 }
+// ---------------------------------------------------------------- policy + env step in one launch
+// What a rollout worker does per step (paint_ppo.py:170-195: policy forward, sample, env.step) as ONE kernel: the
+// sixteen envs of a workgroup first run the policy on their observations together (prl_policy.hpp: three MFMA layers,
+// ~3 us, bound by the weight reads it issues up front), each wave then steps its own env with the sampled action.
+// No second launch and no ~2.5 us of dispatch gaps per step; rows as prl_policy_act + prl_batch_step write them.
+template <int KW>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs) {
+    extern __shared__ float lds[];
+    __shared__ int s_act[POLICY_WAVES];
+    __shared__ int s_cand[POLICY_WAVES][64];
+    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
+    const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const StepArgs CAS &a = f.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const int env0 = blockIdx.x * POLICY_WAVES, env = env0 + wave, n_envs = a.n_envs;
+    FRAG_DECL();
+    FRAG_T(ft0);
+    {
+        PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
+        W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
+        W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
+        const PolicyLds L = policy_lds_layout(W);
+        const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
+        SamplerPre sp;
+        policy_forward(W, f.obs_in + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, nullptr, f.rng_count, sp);
+        if (tid < rows_real) {
+            const int e = env0 + tid, A = W.n_actions;
+            const float u = policy_uniform(f.rng_seed, e, sp.count);
+            float lse;
+            float *Ow = lds + L.o_off;
+            const int act = policy_sample_row(A, lds + L.b3_off, Ow, tid, u, lse);
+            s_act[tid] = act;
+            POL_STAMP(7);
+            f.action[e] = act;
+            f.logp[e] = Ow[tid * 17 + act] - lse;
+            f.value[e] = Ow[tid * 17 + A];
+        }
+    }
+    __syncthreads();
+    FRAG_T(ft1);
+    FRAG_ACC(0, ft0, ft1);
+    FRAG_COUNT();
+    FRAG_FLUSH();
+    if (env >= n_envs) return;
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
+    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+    double delta1, delta2, new_angle;
+    decode_discrete_action(C, s_act[wave], delta1, delta2, new_angle);
+    const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, nullptr};
+    PROF_BEGIN();
+    const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                                  new_angle, StepRows{&a}, wl PROF_PASS);
+    store_state_live(state_rec, S, lane, dn != 0);
+}
+
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
 __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int n, const double *from,
                                                         const double *to, int *tri, double *frac, double *pos) {
@@ -479,6 +519,7 @@ struct PrlBatch {
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
+    int32_t *scratch_action = nullptr; // [n_envs]: the discarded draw of prl_rollout_fragment's bootstrap policy pass
     double *state = nullptr;
     int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
     long long launch_no = 0;
@@ -1012,6 +1053,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
     for (double *p : b->reset_obs) (void)hipFree(p);
+    (void)hipFree(b->scratch_action);
     (void)hipFree(b->state);
     delete b;
 }
@@ -1165,20 +1207,95 @@ int prl_ray_batch(PrlPart *p, int n, const double *from, const double *to, int32
     return PRL_OK;
 }
 
+// what both rollout entry points ask of the batch (the fast-path instantiation of the step: prl_step.hpp)
+static int check_rollout_batch(PrlBatch *b, const char *who) {
+    if (int rc = check_device(b)) return rc;
+    const PrlConfig &c = b->cfg;
+    if (!c.auto_reset) return fail(PRL_E_INVALID, "%s: the batch must be created with auto_reset", who);
+    if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "%s: parts of at most %d samples", who, 64 * 64 * KW_MAX);
+    if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "%s: COLOR_MODE 'RGB'", who);
+    if (b->kd) return fail(PRL_E_UNSUPPORTED, "%s: not for parts with the reference's stale vertex kd-tree", who);
+    if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
+        return fail(PRL_E_UNSUPPORTED, "%s: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for section / discrete observations", who);
+    return PRL_OK;
+}
+
+static int check_policy(const PrlBatch *b, const PrlPolicyWeights *w, const char *who) {
+    const PrlConfig &c = b->cfg;
+    if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3) return fail(PRL_E_INVALID, "%s: null weights", who);
+    if (w->in_dim != obs_dim_of(c.obs_mode, c.obs_grad))
+        return fail(PRL_E_INVALID, "%s: policy input %d, observation %d", who, w->in_dim, obs_dim_of(c.obs_mode, c.obs_grad));
+    if (w->h1 < 16 || w->h1 % 16 || w->h2 < 16 || w->h2 % 16 || w->n_actions != c.n_discrete || w->n_actions > 15)
+        return fail(PRL_E_UNSUPPORTED, "%s: hidden sizes multiples of 16, n_actions = n_discrete <= 15", who);
+    if (sizeof(float) * (size_t)policy_lds_layout(*w).floats > 120 * 1024)
+        return fail(PRL_E_UNSUPPORTED, "%s: layer sizes need more than 120 KB of LDS per 16 envs", who);
+    if (reinterpret_cast<uintptr_t>(w->w2) % 16) return fail(PRL_E_INVALID, "%s: w2 must be 16-byte aligned", who);
+    return PRL_OK;
+}
+
+int prl_batch_act_step(PrlBatch *b, const PrlPolicyWeights *w, const double *obs_in, uint32_t *rng_count, uint64_t rng_seed,
+                       int32_t *action, float *logp, float *value, double *obs, double *reward, uint8_t *done, double *info,
+                       double *final_obs, void *stream) {
+    if (!b || !w || !obs_in || !rng_count || !action || !logp || !value || !obs || !reward || !done || !info)
+        return fail(PRL_E_INVALID, "prl_batch_act_step: null argument");
+    if (int rc = check_rollout_batch(b, "prl_batch_act_step")) return rc;
+    if (int rc = check_policy(b, w, "prl_batch_act_step")) return rc;
+    ActStepArgs f{};
+    f.s = base_args(b);
+    f.s.obs = obs;
+    f.s.reward = reward;
+    f.s.done = done;
+    f.s.info = info;
+    f.s.final_obs = final_obs;
+    f.w = *w;
+    f.obs_in = obs_in;
+    f.action = action;
+    f.logp = logp;
+    f.value = value;
+    f.rng_count = rng_count;
+    f.rng_seed = rng_seed;
+    const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
+    void (*kernel)(ActStepArgs) = nullptr;
+    switch (b->kw) {
+    case 1: kernel = act_step_kernel<1>; break;
+    case 2: kernel = act_step_kernel<2>; break;
+    case 3: kernel = act_step_kernel<3>; break;
+    default: kernel = act_step_kernel<4>; break;
+    }
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((b->n_envs + POLICY_WAVES - 1) / POLICY_WAVES), block(64 * POLICY_WAVES);
+    hipLaunchKernelGGL(kernel, grid, block, lds, static_cast<hipStream_t>(stream), f);
+    HIP_TRY(hipGetLastError());
+    return PRL_OK;
+}
+
 int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, double *obs, double *final_obs,
                          double *reward, uint8_t *done, double *info, int32_t *action, float *logp, float *value,
                          float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream) {
     if (!b || !obs || !reward || !done || !info || !action || n_steps < 1)
         return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
-    if (int rc = check_device(b)) return rc;
-    const PrlConfig &c = b->cfg;
-    if (!c.auto_reset) return fail(PRL_E_INVALID, "prl_rollout_fragment: the batch must be created with auto_reset");
-    if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: parts of at most %d samples", 64 * 64 * KW_MAX);
-    if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: COLOR_MODE 'RGB'");
-    if (b->kd) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: not for parts with the reference's stale vertex kd-tree");
-    if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
-        return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for "
-                                       "section / discrete observations");
+    if (int rc = check_rollout_batch(b, "prl_rollout_fragment")) return rc;
+    const size_t n = (size_t)b->n_envs, od = (size_t)obs_dim_of(b->cfg.obs_mode, b->cfg.obs_grad);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (w) {
+        // policy: one act-and-step launch per step, enqueued back to back from here (no host code of the caller in
+        // between), then the policy once more for the bootstrap value of the last observation (its draw is discarded)
+        if (!logp || !value || !last_value || !rng_count)
+            return fail(PRL_E_INVALID, "prl_rollout_fragment: the policy needs logp, value, last_value and rng_count");
+        if (int rc = check_policy(b, w, "prl_rollout_fragment")) return rc;
+        for (int t = 0; t < n_steps; ++t) {
+            const int rc = prl_batch_act_step(b, w, obs + (size_t)t * n * od, rng_count, rng_seed, action + (size_t)t * n,
+                                              logp + (size_t)t * n, value + (size_t)t * n, obs + (size_t)(t + 1) * n * od,
+                                              reward + (size_t)t * n, done + (size_t)t * n, info + (size_t)t * n * 2,
+                                              final_obs ? final_obs + (size_t)t * n * od : nullptr, stream);
+            if (rc) return rc;
+        }
+        if (!b->scratch_action) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->scratch_action), sizeof(int32_t) * n));
+        return prl_policy_act(w, b->n_envs, obs + (size_t)n_steps * n * od, nullptr, rng_count, rng_seed, b->scratch_action,
+                              nullptr, last_value, nullptr, stream);
+    }
+    // given actions: ONE persistent launch, the waves never meet (rollout_fragment_kernel)
     FragmentArgs f{};
     f.s = base_args(b);
     f.T = n_steps;
@@ -1188,29 +1305,9 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     f.done = done;
     f.info = info;
     f.action = action;
-    size_t lds_floats = 0;
-    if (w) {
-        if (!logp || !value || !last_value || !rng_count)
-            return fail(PRL_E_INVALID, "prl_rollout_fragment: the policy needs logp, value, last_value and rng_count");
-        if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3) return fail(PRL_E_INVALID, "null weights");
-        if (w->in_dim != obs_dim_of(c.obs_mode, c.obs_grad))
-            return fail(PRL_E_INVALID, "prl_rollout_fragment: policy input %d, observation %d", w->in_dim,
-                        obs_dim_of(c.obs_mode, c.obs_grad));
-        if (w->h1 < 16 || w->h1 % 16 || w->h2 < 16 || w->h2 % 16 || w->n_actions != c.n_discrete || w->n_actions > 15)
-            return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: hidden sizes multiples of 16, n_actions = n_discrete <= 15");
-        f.w = *w;
-        f.use_policy = 1;
-        f.logp = logp;
-        f.value = value;
-        f.last_value = last_value;
-        f.rng_count = rng_count;
-        f.rng_seed = rng_seed;
-        lds_floats = (size_t)policy_lds_layout(*w, FRAG_WAVES).floats;
-    }
-    const size_t lds = lds_floats * sizeof(float) + (size_t)FRAG_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
-    if (lds > 64 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
+    const size_t lds = (size_t)FRAG_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
+    if (lds > 120 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
     const dim3 grid((b->n_envs + FRAG_WAVES - 1) / FRAG_WAVES), block(64 * FRAG_WAVES);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     void (*kernel)(FragmentArgs) = nullptr;
     switch (b->kw) {
     case 1: kernel = rollout_fragment_kernel<1>; break;
@@ -1218,6 +1315,8 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     case 3: kernel = rollout_fragment_kernel<3>; break;
     default: kernel = rollout_fragment_kernel<4>; break;
     }
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, f);
     HIP_TRY(hipGetLastError());
     return PRL_OK;
@@ -1231,6 +1330,17 @@ int prl_debug_phase_cycles(unsigned long long *out, int n) {
     for (int k = 0; k < n && k < 16; ++k) out[k] = host[k];
     unsigned long long zero[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
+    return PRL_OK;
+}
+#endif
+
+#ifdef PRL_FRAG_TIMING
+// diagnostic build only: read and clear the fragment kernel's phase sums
+int prl_debug_frag_ticks(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frag_ticks), sizeof(unsigned long long) * 4) != hipSuccess) return PRL_E_HIP;
+    if (hipMemcpyFromSymbol(out + 4, HIP_SYMBOL(g_pol_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PRL_E_HIP;
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_frag_ticks), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;
 }
 #endif

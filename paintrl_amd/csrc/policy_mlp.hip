@@ -3,21 +3,16 @@
 // The caller of the env step in BASELINE.json configs 3-4 is an RLlib rollout worker whose policy is
 // the fully connected net of paint_ppo.py:170-195 (fcnet_hiddens [256, 128], RLlib's default tanh,
 // a linear logits head and a linear value head).  In torch that is ~10 tiny launches per env step;
-// here it is ONE kernel on the env's stream: 16 envs per 256-thread workgroup (256 workgroups for
+// here it is ONE kernel on the env's stream: 16 envs per 1024-thread workgroup (256 workgroups for
 // 4 096 envs: every SIMD of the chip takes part), the three GEMMs on the f32-in / f32-accumulate matrix
-// instruction v_mfma_f32_16x16x4_f32 (exact f32: a k-ordered fmaf chain, cdna_hip_programming.md
-// "FP32-input MFMA"), activations staged through LDS, then softmax and an inverse-CDF draw.
+// instruction v_mfma_f32_16x16x4_f32 (exact f32 products and sums, cdna_hip_programming.md "FP32-input MFMA"),
+// activations staged through LDS, then softmax and an inverse-CDF draw.  prl_policy.hpp holds the layers.
 //
 //   X  [16][in]  = (float) obs                       LDS, K padded to a multiple of 4 with zeros
-//   H1 [16][h1]  = tanh(X  W1 + b1)   h1/16 column tiles, two per wave at a time     LDS
-//   H2 [16][h2]  = tanh(H1 W2 + b2)   h2/16 column tiles                             LDS
-//   O  [16][16]  = H2 W3 + b3         columns 0..A-1 logits, column A the value      LDS (K split over the waves)
-//
-// Operand maps of the 16x16x4 instruction: lane l supplies A[row l&15][k = l>>4] and B[k = l>>4][col l&15];
-// accumulator register g of lane l is C[row 4 (l>>4) + g][col l&15].  A wave always works on TWO column
-// tiles at once: two independent accumulators keep the matrix pipe issuing (a dependent 16x16x4 needs 40
-// cycles, the issue interval is 32) and the LDS operand is read once for both.  LDS rows are padded by
-// four floats so that the 16 rows x 4 k a wave reads per step spread over all 32 banks.
+//   H1 [16][h1]  = tanh(X  W1 + b1)   one 16-column tile per wave                              LDS
+//   H2 [16][h2]  = tanh(H1 W2 + b2)   (h2 / 16) x 2 items: a column tile over half of k        LDS
+//   O  [16][16]  = H2 W3 + b3         columns 0..A-1 logits, column A the value      LDS (k split over four waves)
+// LDS rows are padded by four floats so that the 16 rows x 4 k a wave reads per step spread over all 32 banks.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -30,32 +25,26 @@ extern "C" __attribute__((visibility("hidden"))) int prl_set_error_(int code, co
 
 namespace {
 
-__global__ __launch_bounds__(256) void policy_act_kernel(PolicyArgs a) {
+__global__ __launch_bounds__(64 * POLICY_WAVES) void policy_act_kernel(PolicyArgs a) {
     extern __shared__ float lds[];
     const PrlPolicyWeights &W = a.w;
     const PolicyLds L = policy_lds_layout(W);
-    float *X = lds, *H1 = X + ROWS * L.xs, *H2 = H1 + ROWS * L.s1, *O = lds + L.o_off;  // O: 4 x [16][17] partial head tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int env0 = blockIdx.x * ROWS;
-
-    for (int i = tid; i < ROWS * L.in_pad; i += 256) {
-        const int row = i / L.in_pad, k = i - row * L.in_pad, env = env0 + row;
-        X[row * L.xs + k] = (env < a.n && k < W.in_dim) ? (float)a.obs[(size_t)env * W.in_dim + k] : 0.0f;
-    }
-    __syncthreads();
-    policy_layers<4>(W, X, H1, H2, O, L.xs, L.s1, L.s2, L.in_pad, wave, lane);
-    if (tid < ROWS && env0 + tid < a.n) {           // one env per thread: softmax, inverse-CDF draw
+    const int rows_real = a.n - env0 < ROWS ? a.n - env0 : ROWS;
+    SamplerPre sp;
+    policy_forward(W, a.obs + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, a.uniform, a.rng_count, sp);
+    if (tid < rows_real) {                          // one env per thread: softmax, inverse-CDF draw
         const int env = env0 + tid, A = W.n_actions;
-        float u;
-        if (a.uniform) u = a.uniform[env];
-        else u = policy_uniform(a.rng_seed, env, a.rng_count[env]++);
-        float o[16], lse;
-        const int act = policy_sample_row<ROWS>(W, O, tid, u, o, lse);
+        const float u = a.uniform ? sp.u : policy_uniform(a.rng_seed, env, sp.count);
+        float lse;
+        float *Ow = lds + L.o_off;
+        const int act = policy_sample_row(A, lds + L.b3_off, Ow, tid, u, lse);
         a.action[env] = act;
-        if (a.logp) a.logp[env] = o[act] - lse;
-        if (a.value) a.value[env] = o[A];
+        if (a.logp) a.logp[env] = Ow[tid * 17 + act] - lse;
+        if (a.value) a.value[env] = Ow[tid * 17 + A];
         if (a.logits)
-            for (int j = 0; j < A; ++j) a.logits[(size_t)env * A + j] = o[j];
+            for (int j = 0; j < A; ++j) a.logits[(size_t)env * A + j] = Ow[tid * 17 + j];
     }
 }
 
@@ -71,7 +60,6 @@ extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *ob
     PolicyArgs a;
     a.w = *w;
     a.n = n;
-    a.o_off = 0;
     a.obs = obs;
     a.uniform = uniform;
     a.rng_count = rng_count;
@@ -81,8 +69,12 @@ extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *ob
     a.value = value;
     a.logits = logits;
     const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
-    if (lds > 64 * 1024) return prl_set_error_(PRL_E_UNSUPPORTED, "prl_policy_act: layer sizes need more than 64 KB of LDS per 16 envs");
-    hipLaunchKernelGGL(policy_act_kernel, dim3((n + ROWS - 1) / ROWS), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    if (lds > 120 * 1024) return prl_set_error_(PRL_E_UNSUPPORTED, "prl_policy_act: layer sizes need more than 120 KB of LDS per 16 envs");
+    if (reinterpret_cast<uintptr_t>(w->w2) % 16) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: w2 must be 16-byte aligned");
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return prl_set_error_(PRL_E_HIP, "prl_policy_act: hipFuncSetAttribute");
+    hipLaunchKernelGGL(policy_act_kernel, dim3((n + ROWS - 1) / ROWS), dim3(64 * POLICY_WAVES), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return prl_set_error_(PRL_E_HIP, hipGetErrorString(e));
     return PRL_OK;

@@ -4,9 +4,11 @@
 // kernels carry no instrumentation.  Diagnostic builds (tools/, tests/test_gpu_forced_paths.py) may define:
 //   PRL_PHASE_TIMING=<k>       s_memtime deltas of phase k summed over all waves (tools/phase_timing.py)
 //   PRL_WAVE_TRACE             per env and launch: start / end time and path counters of its wave (tools/wave_trace.py)
-//   PRL_CUT=<1|2|3>           instruction-count builds: no observation / nor painting / nor shots (wrong results;
+//   PRL_CUT=<1|2|4|5|6>       instruction-count builds: no observation / nor painting / nor hook point / nor ray / no
+//                              shots at all (wrong results;
 //                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
 //   PRL_NO_PRIO                no s_setprio by progress (A/B of the issue-priority scheme, prl_step.hpp)
+//   PRL_FRAG_TIMING            rollout-fragment kernel: time in policy / env step / barrier wait (tools/fragment_timing.py)
 //   PRL_PAINT_ONE_ROW_PER_TRIP one sample-grid row per trip of the painter (multi-trip path)   } the general paths,
 //   PRL_FORCE_FULL_SCANS       whole-table scans instead of the ring searches                } run by the forced-
 //   PRL_FORCE_GENERAL_RAY      general two-stage ray search instead of the convex fast path  } path parity tests
@@ -48,6 +50,47 @@ __shared__ unsigned long long g_wcnt[4];
     } while (0)
 #define TRACE_END(env, dn) \
     do {                   \
+    } while (0)
+#endif
+
+#ifdef PRL_FRAG_TIMING
+// Per wave of the rollout-fragment kernel, summed over waves and steps (s_memrealtime ticks, 10 ns): [0] policy
+// phase incl. its barriers, [1] env step, [2] wait at the barrier after the step, [3] wave-steps counted.
+__device__ unsigned long long g_frag_ticks[4];
+__device__ unsigned long long g_pol_stamps[8];          // policy_forward of workgroup 0: time at each barrier
+#define POL_STAMP(k)                                                                  \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_pol_stamps[k] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define FRAG_T(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define FRAG_DECL() unsigned long long frag_acc[3] = {0, 0, 0}, frag_n = 0
+#define FRAG_ACC(slot, t0, t1) frag_acc[slot] += (t1) - (t0)
+#define FRAG_COUNT() ++frag_n
+#define FRAG_FLUSH()                                                           \
+    do {                                                                       \
+        if ((threadIdx.x & 63) == 0) {                                         \
+            for (int k_ = 0; k_ < 3; ++k_) atomicAdd(&g_frag_ticks[k_], frag_acc[k_]); \
+            atomicAdd(&g_frag_ticks[3], frag_n);                               \
+        }                                                                      \
+    } while (0)
+#else
+#define POL_STAMP(k) \
+    do {            \
+    } while (0)
+#define FRAG_T(var) \
+    do {            \
+    } while (0)
+#define FRAG_ACC(slot, t0, t1) \
+    do {                       \
+    } while (0)
+#define FRAG_DECL() \
+    do {            \
+    } while (0)
+#define FRAG_COUNT() \
+    do {             \
+    } while (0)
+#define FRAG_FLUSH() \
+    do {             \
     } while (0)
 #endif
 

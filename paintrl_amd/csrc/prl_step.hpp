@@ -112,7 +112,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     const double delta_2 = d2 * P.lwr;
     const double dvec[3] = {P.a1 == 0 ? d1 : (P.a2 == 0 ? delta_2 : -0.0), P.a1 == 1 ? d1 : (P.a2 == 1 ? delta_2 : -0.0),
                             P.a1 == 2 ? d1 : (P.a2 == 2 ? delta_2 : -0.0)};
-#if defined(PRL_CUT) && PRL_CUT >= 3              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
+#if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
     for (int shot = 0; shot < 0; ++shot) {
 #else
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
@@ -128,10 +128,23 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
         double t, hit[3], pos[3], orn[3], quat[4];
         STAMP(PH_MATH);
+#if defined(PRL_CUT) && PRL_CUT >= 5
+        bool on = true;
+        t = 0;
+        hit[0] = end[0] * 0.1 + pt[0] * 0.9, hit[1] = end[1] * 0.1 + pt[1] * 0.9, hit[2] = end[2] * 0.1 + pt[2] * 0.9;
+#else
         bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint, wl.cand) >= 0;
+#endif
         STAMP(PH_RAY);
         double center[3];                                  // rob:277-278 shot centre
+#if defined(PRL_CUT) && PRL_CUT >= 4
+        if (on) {
+            for (int k = 0; k < 3; ++k) pos[k] = hit[k] - 0.1 * cur_norm[k], orn[k] = cur_norm[k], center[k] = hit[k];
+            quat[0] = quat[1] = quat[2] = 0, quat[3] = 1;
+        }
+#else
         if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, last_tri, wl.kd_heap PROF_PASS);
+#endif
         if (!on) {
             last_tri = -1;
             orn[0] = cur_norm[0];

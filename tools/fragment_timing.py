@@ -5,7 +5,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402
-from paintrl_amd import part_tables, synth_parts  # noqa: E402
+from paintrl_amd import _lib, part_tables, synth_parts  # noqa: E402
 from paintrl_amd.batched_env import BatchedPaintEnv  # noqa: E402
 from paintrl_amd.device_tables import DeviceTables  # noqa: E402
 from paintrl_amd.rollout import FragmentRunner, MLPPolicy  # noqa: E402
@@ -46,6 +46,19 @@ def main():
     print('fragment kernel, given actions      : %.1f us/step' % (1e3 * timed(given) / T))
     runner.run(T)
     print('fragment kernel, fused policy       : %.1f us/step' % (1e3 * timed(lambda: runner.run(T)) / T))
+    lib = _lib.load()
+    if hasattr(lib, 'prl_debug_frag_ticks'):             # a -DPRL_FRAG_TIMING build (PAINTRL_LIB=tools/_ab/fragt.so)
+        import ctypes as C
+        buf = (C.c_ulonglong * 12)()
+        lib.prl_debug_frag_ticks(buf)
+        runner.run(T)
+        torch.cuda.synchronize()
+        lib.prl_debug_frag_ticks(buf)
+        ws = max(1, buf[3])
+        print('  per wave-step: policy phase %.2f us, env step %.2f us, wait after step %.2f us' % (
+            buf[0] * 0.01 / ws, buf[1] * 0.01 / ws, buf[2] * 0.01 / ws))
+        st = [buf[4 + k] for k in range(8)]
+        print('  workgroup 0, last launch, us since its first stamp: ' + '  '.join('%.2f' % ((v - st[0]) * 0.01) for v in st[1:]))
     for steps in (1, 10):
         print('fragment kernel, policy, %3d steps   : %.1f us/step' % (steps, 1e3 * timed(lambda: runner.run(steps)) / steps))
 
