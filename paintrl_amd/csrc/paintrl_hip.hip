@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC, KD>();
+    const WaveLds wl = wave_lds<GENSEC, KD, NORMAL>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
@@ -779,6 +779,50 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         UP(samp_ub, ub.data(), ub.size());
         UP(word_pivot, pivot.data(), pivot.size());
     }
+    {   // fine grid over the real samples for the lane-parallel nearest-sample query (prl_cone.hpp): ~4 samples a cell
+        const double *x1 = t->sample_xyz[d.a1], *x2 = t->sample_xyz[d.a2];
+        double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
+        std::vector<int> real;
+        for (int i = 0; i < t->n_samples_pad; ++i)
+            if ((t->word_valid[i >> 6] >> (i & 63)) & 1) {
+                real.push_back(i);
+                lo1 = std::fmin(lo1, x1[i]);
+                hi1 = std::fmax(hi1, x1[i]);
+                lo2 = std::fmin(lo2, x2[i]);
+                hi2 = std::fmax(hi2, x2[i]);
+            }
+        if ((int)real.size() != t->n_samples) return fail(PRL_E_INVALID, "word_valid marks %zu samples, n_samples is %d", real.size(), t->n_samples);
+        double cell = 2.0 * std::sqrt(std::fmax((hi1 - lo1) * (hi2 - lo2), 1e-12) / (double)real.size());
+        cell = std::fmax(cell, 1e-6);
+        while (((hi1 - lo1) / cell + 1) * ((hi2 - lo2) / cell + 1) > 4.0e6) cell *= 2;
+        const double inv = 1.0 / cell;
+        const int nx = (int)std::floor((hi1 - lo1) * inv) + 1, ny = (int)std::floor((hi2 - lo2) * inv) + 1;
+        std::vector<int> cell_of(real.size()), start((size_t)nx * ny + 1, 0);
+        for (size_t j = 0; j < real.size(); ++j) {
+            int cx = (int)std::floor((x1[real[j]] - lo1) * inv), cy = (int)std::floor((x2[real[j]] - lo2) * inv);
+            cx = cx < 0 ? 0 : (cx > nx - 1 ? nx - 1 : cx);
+            cy = cy < 0 ? 0 : (cy > ny - 1 ? ny - 1 : cy);
+            cell_of[j] = cy * nx + cx;
+            ++start[(size_t)cell_of[j] + 1];
+        }
+        for (size_t c = 0; c < (size_t)nx * ny; ++c) start[c + 1] += start[c];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        std::vector<double> rec(real.size() * 4);
+        for (size_t j = 0; j < real.size(); ++j) {
+            const int i = real[j], slot = fill[cell_of[j]]++;
+            for (int k = 0; k < 3; ++k) rec[(size_t)slot * 4 + k] = t->sample_xyz[k][i];
+            const int32_t pair[2] = {t->sample_rank[i], (int32_t)i};
+            std::memcpy(&rec[(size_t)slot * 4 + 3], pair, sizeof pair);
+        }
+        d.fg_o1 = lo1;
+        d.fg_o2 = lo2;
+        d.fg_inv = inv;
+        d.fg_accept = 0.99 * cell;
+        d.fg_nx = nx;
+        d.fg_ny = ny;
+        UP(fg_start, start.data(), start.size());
+        UP(fg_rec, rec.data(), rec.size());
+    }
     d.n_start = t->n_start;
     if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
     UP(start_pos, t->start_pos, (size_t)d.n_start * 3);
@@ -1350,6 +1394,11 @@ int prl_debug_frag_ticks(unsigned long long *out) {
 int prl_debug_wave_trace(unsigned long long *out, int n_envs) {
     if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
+    return PRL_OK;
+}
+int prl_debug_wave_trace16(unsigned long long *out, int n_envs) {
+    if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace16), sizeof(unsigned long long) * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;
 }
 #endif

@@ -12,12 +12,16 @@
 //     on upload).  A facet that is ENTERED at a point clear of its edges ends the walk with the exact closest hit of
 //     the whole set -- the criterion of ray_closest_wave's single-facet path, same arithmetic.  Lanes that do not
 //     get there in a few steps (edge and vertex hits, misses, rays leaving the hull) take the wave-wide search.
-//   * nearest samples: see nearest_samples_lanes below.
+//   * nearest samples: nearest_sample_lane below, one hit point per lane; the hit bits meet in the wave's LDS mask row.
 #pragma once
 
 namespace {
 
-constexpr int CONE_WALK_STEPS = 6;
+#ifndef PRL_WALK_STEPS
+#define PRL_WALK_STEPS 8
+#endif
+constexpr int CONE_WALK_STEPS = PRL_WALK_STEPS;
+#define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
 
 // One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0): Moller-Trumbore on
 // the facet record, arithmetic as in mt_rec.  Returns 1 = entered at an interior point (t, exact closest hit),
@@ -45,10 +49,24 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, const double o[3
     const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
     const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
     const bool entering = orient * det > 0 && det * det >= FACET_MIN_COS2 * dd * nn;
-    if (!entering || !(t >= 0.0)) return -1;               // leaving through this facet, grazing, or behind the origin
+    if (!entering) {
+        // The walk has gone over the hull's horizon (or grazes).  The hull lies on the inner side of this facet's
+        // plane: if both ends of the beam are clear of the plane on the OUTER side, by more than any tolerance of the
+        // triangle tests, the beam misses the whole set -- no search needed.  (Most beams that miss pass beside the
+        // part; the walk ends on a rim facet whose plane separates them.)
+        const double n0 = e11 * e22 - e12 * e21, n1 = e12 * e20 - e10 * e22, n2 = e10 * e21 - e11 * e20;   // e1 x e2
+        const double so = ((s0 * n0 + s1 * n1) + s2 * n2) * orient;                     // origin, outward if > 0
+        const double se = so + ((d0 * n0 + d1 * n1) + d2 * n2) * orient;                // end point
+        const double clear = CONE_MISS_MARGIN * CONE_MISS_MARGIN * nn;                  // (distance margin)^2 |n|^2
+        if (so > 0 && se > 0 && so * so > clear && se * se > clear) return 2;
+        return -1;
+    }
+    if (!(t >= 0.0)) return -1;                              // behind the origin
     if (u >= m && v >= m && (u + v) <= 1.0 - m) {
-        if (!(t <= 1.0)) return -1;                          // the facet lies beyond the beam's end point: a miss, let
-        t_out = t;                                           // the general search confirm it
+        // entered at an interior point: the closest hit of the whole set (ray_closest_wave's single-facet criterion);
+        // beyond the beam's end point it means the beam stops short of the part: a miss
+        if (!(t <= 1.0)) return 2;
+        t_out = t;
         rank_out = ldg(P.col_rank, i);
         return 1;
     }
@@ -59,9 +77,55 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, const double o[3
     return 0;
 }
 
+// The general closest-hit search for up to 64 rays at once, one per lane (`need`), all from the same origin o: what
+// ray_closest_wave's general search returns for each of them -- the closest two-sided hit over ALL collision triangles,
+// equal t resolved to the lowest reference index.  The triangle loop is wave-uniform (every lane looks at the same
+// triangle, read once for the wave), culled twice with the float boxes: a chunk of 64 is visited if ANY lane's segment
+// box meets the chunk's box, a triangle is tested by the lanes whose segment box meets its box.  No candidate lists,
+// no reductions: a lane keeps its own best.  (The wave-wide search costs ~3 us per ray; a shot of an env that has
+// wandered off the part has ~130 rays that all miss -- 2 ms per step, and the launch waits for that env.)
+__device__ __forceinline__ float bcast_f(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+__device__ void rays_general_lanes(PartRef P, const double o[3], const double dst[3], bool need, double &t_out, int &tri_out) {
+    const double d0 = dst[0] - o[0], d1 = dst[1] - o[1], d2 = dst[2] - o[2];
+    double best_t = INFINITY, best_det = 0;
+    int best_r = 0x7fffffff, best_i = -1;
+    const double o3[3] = {sel3(o[0], o[1], o[2], P.a1), sel3(o[0], o[1], o[2], P.a2), sel3(o[0], o[1], o[2], P.a0)};
+    const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
+    const SegBox sb = seg_box(o3, d3, 1.0);
+    const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
+    const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
+    // The boxes are read 64 at a time, one per lane, and handed round by lane broadcasts: a read per loop trip at a
+    // wave-uniform address would put a memory round trip into every one of the ~64 x chunks trips.
+    const int lane = threadIdx.x & 63;
+    for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {                 // (table padded to 64 with empty boxes)
+        const f32x4 cla = ldg(chunk_boxes, 2 * (cbase + lane)), clb = ldg(chunk_boxes, 2 * (cbase + lane) + 1);
+        const int nc = P.n_col_chunks - cbase < 64 ? P.n_col_chunks - cbase : 64;
+        for (int cl = 0; cl < nc; ++cl) {
+            const f32x4 ca = {bcast_f(cla.x, cl), bcast_f(cla.y, cl), bcast_f(cla.z, cl), bcast_f(cla.w, cl)};
+            const f32x4 cb = {bcast_f(clb.x, cl), bcast_f(clb.y, cl), 0.0f, 0.0f};
+            const bool ov = need && box_overlap(sb, ca, cb);
+            if (__ballot(ov) == 0) continue;
+            const int i0 = (cbase + cl) << 6;
+            const f32x4 tla = ldg(boxes, 2 * (i0 + lane)), tlb = ldg(boxes, 2 * (i0 + lane) + 1);
+            for (int tl = 0; tl < 64; ++tl) {
+                const f32x4 ba = {bcast_f(tla.x, tl), bcast_f(tla.y, tl), bcast_f(tla.z, tl), bcast_f(tla.w, tl)};
+                const f32x4 bb = {bcast_f(tlb.x, tl), bcast_f(tlb.y, tl), 0.0f, 0.0f};
+                const bool pass = ov && box_overlap(sb, ba, bb);
+                if (__ballot(pass) == 0) continue;
+                mt_one(P, pass ? i0 + tl : -1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
+            }
+        }
+    }
+    t_out = best_t;
+    tri_out = best_i;
+}
+
 // The rays of beams b0 + lane: hit[3] / t of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray.
 __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                int *cand_lds, double hit[3]) {
+                                int *cand_lds, double hit[3] PROF_ARG) {
     const int bm = b0 + lane;
     const bool have = bm < P.n_beams;
     double dst[3] = {pos[0], pos[1], pos[2]};
@@ -69,6 +133,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
     const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
     double t = INFINITY;
+    STAMP(PH_RAY);
     int state = have ? 0 : 2;                       // 0 walking, 1 hit, 2 finished without a hit (no beam), 3 -> wave-wide search
     if (P.col_convex && hint >= 0) {
         int f = hint, rk = 0;
@@ -78,6 +143,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
                 int next;
                 const int r = cone_walk_step(P, f, pos, d0, d1, d2, dd, t, rk, next);
                 if (r == 1) state = 1;
+                else if (r == 2) state = 2;
                 else if (r < 0 || next < 0) state = 3;
                 else f = next;
             }
@@ -89,26 +155,85 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 #ifdef PRL_FORCE_GENERAL_RAY
     if (have) state = 3;
 #endif
+    STAMP(PH_VERTEX);                               // (stamped builds: the walk counts as 'vertex', the search as 'bary')
     hit[0] = pos[0] + t * d0;
     hit[1] = pos[1] + t * d1;
     hit[2] = pos[2] + t * d2;
-    // the stragglers, one wave-wide search each
-    uint64_t todo = __ballot(state == 3);
-    int wide_hint = hint;
-    while (todo) {
-        const int L = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const double e3[3] = {bcast_d(dst[0], L), bcast_d(dst[1], L), bcast_d(dst[2], L)};
-        double tw, hw[3];
-        const int idx = ray_closest_wave(P, pos, e3, lane, tw, hw, wide_hint, cand_lds);
-        if (lane == L) {
-            state = idx >= 0 ? 1 : 2;
-            hit[0] = hw[0];
-            hit[1] = hw[1];
-            hit[2] = hw[2];
+    // the stragglers (edge and vertex hits, and every miss), together
+    const uint64_t todo = __ballot(state == 3);
+    WCNT16(0, __popcll(todo));
+    if (todo) {
+        double tw;
+        int tri;
+        rays_general_lanes(P, pos, dst, state == 3, tw, tri);
+        if (state == 3) {
+            state = tri >= 0 ? 1 : 2;
+            hit[0] = pos[0] + tw * d0;
+            hit[1] = pos[1] + tw * d1;
+            hit[2] = pos[2] + tw * d2;
         }
     }
+    STAMP(PH_BARY);
     return state == 1;
+}
+
+// ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1), one hit point per lane
+// The nearest sample of this lane's point `pt` (if `want`), exact, equal distances resolved to the lowest reference
+// index -- as nearest_sample_wave, but 64 queries at once: each lane scans the (2k+1)^2 block of FINE grid cells around
+// its point (PartDev::fg_*: ~4 samples a cell, so a 3 x 3 block holds ~36 candidates where the painter's own sample
+// grid holds ~1 350), rows as contiguous record ranges, four records per trip so that their reads travel together.
+// A sample outside the block is more than k cells away in the principal plane: the best of the block is the answer
+// once it lies within k * 0.99 * cell.  Returns the device position of the sample, -1 if not `want`, or -2 if three
+// rings did not settle it (a hit point centimetres off the sampled surface): the caller asks nearest_sample_wave.
+__device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
+    const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
+    int result = want ? -2 : -1;
+    bool open = want;
+    for (int ring = 1; ring <= 3; ++ring) {
+        if (__ballot(open) == 0) break;
+        double best_d = INFINITY;
+        int best_rank = 0x7fffffff, best_pos = -1;
+        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.fg_nx - 1 ? P.fg_nx - 1 : icx + ring;
+        for (int dy = -ring; dy <= ring; ++dy) {                    // wave-uniform trip count, per-lane ranges
+            const int cy = icy + dy;
+            const bool row_ok = open && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
+            const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
+            const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
+            for (int i0 = b; __ballot(i0 < e) != 0; i0 += 4) {
+                f64x2 ra[4], rb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + q < e ? i0 + q : (e > b ? e - 1 : 0);     // (in range: the fold repeats a record)
+                    ra[q] = ldg(rec, 2 * i);
+                    rb[q] = ldg(rec, 2 * i + 1);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + q < e) {
+                        const double dx = ra[q].x - pt[0], dy2 = ra[q].y - pt[1], dz = rb[q].x - pt[2];
+                        const double dd = (dx * dx + dy2 * dy2) + dz * dz;
+                        const int rk = __double2loint(rb[q].y);
+                        if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                            best_d = dd;
+                            best_rank = rk;
+                            best_pos = __double2hiint(rb[q].y);
+                        }
+                    }
+                }
+            }
+        }
+        const double lim = ring * P.fg_accept;
+        if (open && best_pos >= 0 && best_d <= lim * lim) {
+            result = best_pos;
+            open = false;
+        }
+    }
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the wave-wide search
+    if (want) result = -2;
+#endif
+    return result;
 }
 
 }  // namespace

@@ -47,6 +47,12 @@ struct PartDev {
     gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
+    // fine sample grid for the cone-beam painter's nearest-sample queries, one query per lane (prl_cone.hpp; derived
+    // in part_fill): cells of ~4 samples, fg_rec = the samples sorted by cell as (x, y, z, {i32 rank, i32 device pos})
+    double fg_o1, fg_o2, fg_inv, fg_accept;       // fg_accept = 0.99 * cell edge
+    int fg_nx, fg_ny;
+    gint_p fg_start;              // [fg_nx * fg_ny + 1]
+    gdouble_p fg_rec;             // [n_samples][4]
     gfloat_p samp_f32;            // [n_samples_pad][4]: x y z 0 rounded to float (derived): the paint pre-filter
     double samp_absmax;           // largest |coordinate| of a real sample: bounds the pre-filter's rounding error
     double sg_o1, sg_o2, sg_inv;
@@ -141,15 +147,25 @@ struct WaveLds {
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
     int *cnt;           // [128], only with the atan2-sector observation
     double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
+    uint64_t *mask;     // [4][64 * KW_MAX], only in the cone-beam kernels: a shot's hit bits (zero between shots), then
+                        // the env's painted / last-shot / union-of-valid masks while the shots run (prl_step.hpp)
 };
-template <bool GENSEC, bool KD = false>
+template <bool GENSEC, bool KD = false, bool CONE = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[MAX_WAVES_PER_WG][64];
     __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
     __shared__ double s_kd[KD ? MAX_WAVES_PER_WG : 1][KD ? KD_HEAP * 5 : 1];
+    __shared__ uint64_t s_mask[CONE ? MAX_WAVES_PER_WG : 1][CONE ? 4 * 64 * KW_MAX : 1];
     const int w = rfl((int)(threadIdx.x >> 6));
-    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0]};
+    if constexpr (CONE) {
+#pragma unroll
+        for (int k = 0; k < KW_MAX; ++k) s_mask[w][(threadIdx.x & 63) + 64 * k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], s_mask[CONE ? w : 0]};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

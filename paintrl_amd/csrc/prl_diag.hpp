@@ -25,26 +25,33 @@ namespace {
 // visits, 3 vertex-ring trips, 4 neighbourhood ray rounds, 5 paint trips, 6 straddle / f64 trips, 7 single-facet hits).
 #define PRL_TRACE_ENVS 8192
 __device__ unsigned long long g_wave_trace[4 * PRL_TRACE_ENVS];
-__shared__ unsigned long long g_wcnt[4];
+__shared__ unsigned long long g_wcnt[4], g_wcnt16[4];
+__device__ unsigned long long g_wave_trace16[PRL_TRACE_ENVS];      // four 16-bit counters of the cone-beam painter
+#define WCNT16(slot, v)                                                                            \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) g_wcnt16[threadIdx.x >> 6] += (unsigned long long)(v) << (16 * (slot)); \
+    } while (0)
 #define WCNT(slot, v)                                                                              \
     do {                                                                                           \
         if ((threadIdx.x & 63) == 0) g_wcnt[threadIdx.x >> 6] += (unsigned long long)(v) << (8 * (slot)); \
     } while (0)
 #define TRACE_BEGIN()                                                          \
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();      \
-    if ((threadIdx.x & 63) == 0) g_wcnt[threadIdx.x >> 6] = 0
+    if ((threadIdx.x & 63) == 0) g_wcnt[threadIdx.x >> 6] = g_wcnt16[threadIdx.x >> 6] = 0
 #define TRACE_END(env, dn)                                                     \
     do {                                                                       \
         if ((threadIdx.x & 63) == 0 && (env) < PRL_TRACE_ENVS) {               \
             g_wave_trace[4 * (env)] = trace_t0;                                \
             g_wave_trace[4 * (env) + 1] = __builtin_amdgcn_s_memrealtime();    \
             g_wave_trace[4 * (env) + 2] = g_wcnt[threadIdx.x >> 6];            \
+            g_wave_trace16[env] = g_wcnt16[threadIdx.x >> 6];                  \
             g_wave_trace[4 * (env) + 3] = (unsigned long long)((dn) != 0) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 1) | \
                                           ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 40);   /* HW_ID, XCC_ID */ \
         }                                                                      \
     } while (0)
 #else
 #define WCNT(slot, v)
+#define WCNT16(slot, v)
 #define TRACE_BEGIN() \
     do {              \
     } while (0)

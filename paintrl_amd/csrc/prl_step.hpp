@@ -84,10 +84,21 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
     // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
     constexpr bool BIG = KW == 0;
-    static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in registers: small parts only");
+    static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in 64-word-per-slot LDS rows: small parts only");
     static_assert(!(HSI && (BIG || NORMAL)), "thickness mode is built for ball-query painting of small parts");
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    if constexpr (NORMAL || BIG) masks.template load<KW>(painted, last);
+    if constexpr (BIG) masks.template load<KW>(painted, last);
+    if constexpr (NORMAL) {
+        // cone-beam painting updates the masks shot by shot: they wait in this wave's LDS rows (wl.mask + 256 painted,
+        // + 512 last shot, + 768 union of the shots' valid sets), not in 24 vector registers held through the rays
+        masks.template load<KW>(painted, last);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            wl.mask[256 + lane + 64 * k] = painted[k];
+            wl.mask[512 + lane + 64 * k] = last[k];
+            wl.mask[768 + lane + 64 * k] = 0;
+        }
+    }
     const int counter_before = S.terminate_counter;
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
@@ -104,7 +115,6 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     // shots (eight vector registers): after the last one it is read from the record of the triangle that shot
     // hooked to, or recomputed from the normal after a miss -- the same arithmetic either way.
     int last_tri = -1;
-    uint64_t n_uni[KW_MAX] = {0, 0, 0, 0};      // NORMAL only: union of valid samples over the five shots
     uint32_t n_succeeded_l = 0;
     double *cen = wl.cen;
     // the guided point's offset from the pose (bpw:865-880: d1 along axis a1, d2 * lwr along a2) is the same for the
@@ -177,28 +187,44 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             // rob:251-258, 280-285: one ray per cone beam from the tool to the beam's end point on the
             // plane 0.2 ahead; bpw:562-566: every hit paints the sample nearest to it.  No hit at all:
             // the reference returns early and leaves the last-shot set untouched.
-            uint64_t cur[KW_MAX] = {0, 0, 0, 0};
             int beam_hits = 0;
             for (int b0 = 0; b0 < P.n_beams; b0 += 64) {          // 64 beams per trip, one per lane (prl_cone.hpp)
                 double bh[3];
-                const bool hit = cone_rays_lanes(P, pos, quat, b0, facet_hint, lane, wl.cand, bh);
-                uint64_t hm = __ballot(hit);
+                const bool hit = cone_rays_lanes(P, pos, quat, b0, facet_hint, lane, wl.cand, bh PROF_PASS);
+                STAMP(PH_RAY);                                    // (stamped builds: the cone's rays count as 'ray',
+                uint64_t hm = __ballot(hit);                       //  its nearest-sample queries as 'paint', fallbacks as 'apply')
                 beam_hits += __popcll(hm);
-                while (hm) {                                      // nearest sample of every hit point
-                    const int L = __builtin_ctzll(hm);
-                    hm &= hm - 1;
+                // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle
+                // go through the wave-wide search.  Bits are collected in this wave's LDS mask row.
+                int sidx = nearest_sample_lane(P, bh, hit);
+                STAMP(PH_BALL);
+                uint64_t rest = __ballot(sidx == -2);
+                WCNT16(1, __popcll(rest));
+                WCNT16(3, __popcll(hm));
+                while (rest) {
+                    const int L = __builtin_ctzll(rest);
+                    rest &= rest - 1;
                     const double h3[3] = {bcast_d(bh[0], L), bcast_d(bh[1], L), bcast_d(bh[2], L)};
-                    const int sidx = nearest_sample_wave(P, h3, lane);
-                    if (sidx >= 0) set_word<KW>(cur, sidx >> 6, (uint64_t)1 << (sidx & 63), lane);
+                    const int s2 = nearest_sample_wave(P, h3, lane);
+                    if (lane == L) sidx = s2;
                 }
+                if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&wl.mask[sidx >> 6]), 1ull << (sidx & 63));
+                STAMP(PH_APPLY);
             }
-            if (beam_hits > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    n_succeeded_l += __popcll(cur[k] & ~painted[k]);
-                    painted[k] |= cur[k];
-                    n_uni[k] |= cur[k] & ~last[k];
-                    last[k] = cur[k];
+            for (int k = 0; k < KW; ++k) {
+                const int w = lane + 64 * k;
+                const uint64_t c = wl.mask[w];
+                wl.mask[w] = 0;                                // (clean for the next shot)
+                if (beam_hits > 0) {
+                    const uint64_t pw = wl.mask[256 + w], lw = wl.mask[512 + w];
+                    n_succeeded_l += __popcll(c & ~pw);
+                    wl.mask[256 + w] = pw | c;
+                    wl.mask[768 + w] |= c & ~lw;
+                    wl.mask[512 + w] = c;
                 }
             }
         }
@@ -229,7 +255,11 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     } else if constexpr (NORMAL) {
         uint32_t pix_l = 0;
 #pragma unroll
-        for (int k = 0; k < KW; ++k) pix_l += __popcll(n_uni[k]);
+        for (int k = 0; k < KW; ++k) {
+            painted[k] = wl.mask[256 + lane + 64 * k];
+            last[k] = wl.mask[512 + lane + 64 * k];
+            pix_l += __popcll(wl.mask[768 + lane + 64 * k]);
+        }
         const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
         succeeded = (int)(sums >> 32);
         pixel_counter = (int)(sums & 0xffffffffu);

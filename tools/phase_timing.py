@@ -30,7 +30,9 @@ def main():
     n = int(os.environ.get('PRL_ENVS', '4096'))
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
-    acts = torch.randint(0, 4, (400, n), generator=gen, device='cuda', dtype=torch.int32)
+    total = int(os.environ.get('PRL_PHASE_STEPS', '400'))
+    warm = total // 4
+    acts = torch.randint(0, 4, (total, n), generator=gen, device='cuda', dtype=torch.int32)
     rows = []
     for k, name in enumerate(NAMES):
         path = os.path.join(REPO, 'tools', '_ab', 'phase%d.so' % k)
@@ -40,21 +42,21 @@ def main():
         _lib._lib = None
         lib = _lib.load()
         lib.prl_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678)
+        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, paint_method=os.environ.get('PRL_PAINT_METHOD', 'fast'))
         env.reset()
-        for s in range(100):
+        for s in range(warm):
             env.step_raw(acts[s])
         torch.cuda.synchronize()
         buf = (C.c_ulonglong * 16)()
         lib.prl_debug_phase_cycles(buf, 16)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for s in range(100, 400):
+        for s in range(warm, total):
             env.step_raw(acts[s])
         e1.record()
         torch.cuda.synchronize()
         lib.prl_debug_phase_cycles(buf, 16)
-        rows.append((name, buf[0] / (300.0 * n), buf[1] / (300.0 * n), 1e3 * e0.elapsed_time(e1) / 300))
+        rows.append((name, buf[0] / (float(total - warm) * n), buf[1] / (float(total - warm) * n), 1e3 * e0.elapsed_time(e1) / (total - warm)))
         env.close()
     for name, cyc, life, us in rows:
         print('%-8s %8.0f cycles per env-step  (%4.1f %% of the %6.0f-cycle wave lifetime; stamped build %.1f us/step)'

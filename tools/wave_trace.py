@@ -38,19 +38,25 @@ def main():
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (200 + steps, n), generator=gen, device='cuda', dtype=torch.int32)
-    env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678)
+    method = os.environ.get('PRL_PAINT_METHOD', 'fast')
+    env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, paint_method=method)
     env.reset()
-    for s in range(200):
+    warm = 200 if method == 'fast' else 20
+    for s in range(warm):
         env.step_raw(acts[s])
     torch.cuda.synchronize()
-    rows = []
+    rows, rows16 = [], []
     buf = np.zeros((n, 4), dtype=np.uint64)
-    for s in range(200, 200 + steps):
+    buf16 = np.zeros(n, dtype=np.uint64)
+    lib.prl_debug_wave_trace16.argtypes = [C.c_void_p, C.c_int]
+    for s in range(warm, warm + steps):
         env.step_raw(acts[s])
         torch.cuda.synchronize()
         rc = lib.prl_debug_wave_trace(buf.ctypes.data, n)
         assert rc == 0
         rows.append(buf.copy())
+        lib.prl_debug_wave_trace16(buf16.ctypes.data, n)
+        rows16.append(buf16.copy())
     env.close()
     tr = np.stack(rows).astype(np.int64)                          # [steps, n, 4]
     t0 = tr[:, :, 0].min(axis=1, keepdims=True)
@@ -63,6 +69,10 @@ def main():
     xcc = (tr[:, :, 3] >> 40) & 15
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
     where = {'xcc': xcc, 'se': se, 'sh': sh, 'cu': cu, 'simd': simd, 'wave_slot': hw & 15}
+    c16 = np.stack(rows16).astype(np.int64)
+    if method == 'normal':
+        names16 = ['wave-wide straggler rays', 'wave-wide nearest-sample fallbacks', 'lanes past ring 1', 'beam hits']
+        print('cone-beam painter, mean per env-step: ' + '  '.join('%s %.1f' % (nm, ((c16 >> (16 * k)) & 0xffff).mean()) for k, nm in enumerate(names16)))
     span = end.max(axis=1)
     print('launch span (first wave start -> last wave end): mean %.1f us, min %.1f, max %.1f' % (span.mean(), span.min(), span.max()))
     print('wave start offset: mean %.2f us, 99%% %.2f, max %.2f' % (start.mean(), np.percentile(start, 99), start.max()))
