@@ -11,7 +11,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def counters(d, kernel='step_kernel'):
     acc, waves = {}, None
-    for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+    files = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                             # the newest run only
         for r in csv.DictReader(open(f)):
             if kernel in r['Kernel_Name']:
                 acc.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
@@ -32,8 +33,9 @@ def main():
     # kernel trace stats
     for name, sub in (('kernel_stats', 'trace'), ('kernel_stats_grid', 'trace_grid')):
         hits = glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True)
+        hits.sort(key=os.path.getmtime)                 # (gpurun merges new files next to older ones: newest wins)
         if hits:
-            shutil.copy(hits[0], os.path.join(dst, '%s_%s.csv' % (tag, name)))
+            shutil.copy(hits[-1], os.path.join(dst, '%s_%s.csv' % (tag, name)))
     # SQ counters -> json (what bench.py's valu_issue bound reads) + a text table
     sq, text = {}, []
     for mode in ('section', 'grid'):

@@ -73,6 +73,14 @@ def main():
     if method == 'normal':
         names16 = ['wave-wide straggler rays', 'wave-wide nearest-sample fallbacks', 'lanes past ring 1', 'beam hits']
         print('cone-beam painter, mean per env-step: ' + '  '.join('%s %.1f' % (nm, ((c16 >> (16 * k)) & 0xffff).mean()) for k, nm in enumerate(names16)))
+    if method == 'normal':
+        flat_life = (end - start).reshape(-1)
+        top = np.argsort(flat_life)[-12:][::-1]
+        c8 = np.stack([(tr[:, :, 2] >> (8 * k)) & 0xff for k in range(8)], axis=-1).reshape(-1, 8)
+        c16f = np.stack([(c16 >> (16 * k)) & 0xffff for k in range(4)], axis=-1).reshape(-1, 4)
+        print('slowest waves: life us | 8-bit counters %s | 16-bit (stragglers, nearest fallbacks, past ring 1, hits)' % SLOTS)
+        for i in top:
+            print('   %7.1f | %s | %s' % (flat_life[i], c8[i].tolist(), c16f[i].tolist()))
     span = end.max(axis=1)
     print('launch span (first wave start -> last wave end): mean %.1f us, min %.1f, max %.1f' % (span.mean(), span.min(), span.max()))
     print('wave start offset: mean %.2f us, 99%% %.2f, max %.2f' % (start.mean(), np.percentile(start, 99), start.max()))
