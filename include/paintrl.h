@@ -250,10 +250,11 @@ int prl_batch_act_step(PrlBatch *batch, const PrlPolicyWeights *weights, const d
  *   reward f64[n_steps][N], done u8[n_steps][N], info f64[n_steps][N][2]
  *   action     i32[n_steps][N]: written when `weights` is given, otherwise READ (replay / scripted / random actions)
  *   logp, value f32[n_steps][N], last_value f32[N] (value estimate of row n_steps), rng_count u32[N]: policy only
- * Given actions (weights == NULL): ONE persistent launch, sixteen envs per workgroup, every wave walks its env through
- * all n_steps on its own (no barrier, no launch boundary: a slow step delays nobody), coverage masks in LDS throughout.
- * With `weights`: n_steps launches of prl_batch_act_step and one of prl_policy_act for last_value (its draw is
- * discarded): the rows are bit for bit what n_steps rounds of prl_policy_act + prl_batch_step produce. */
+ * ONE persistent launch either way, sixteen envs per workgroup.  Given actions (weights == NULL): every wave walks its
+ * env through all n_steps on its own (no barrier, no launch boundary: a slow step delays nobody), coverage masks in LDS
+ * throughout.  With `weights`: the sixteen waves of a workgroup alternate the policy (together) and the step (each its
+ * env) and meet only at the policy's barriers; after the last step the policy runs once more for last_value (its draw
+ * is discarded).  The rows are bit for bit what n_steps rounds of prl_policy_act + prl_batch_step produce. */
 int prl_rollout_fragment(PrlBatch *batch, const PrlPolicyWeights *weights /* or NULL */, int n_steps, double *obs,
                          double *final_obs, double *reward, uint8_t *done, double *info, int32_t *action, float *logp,
                          float *value, float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream);

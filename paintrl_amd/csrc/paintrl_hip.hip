@@ -33,6 +33,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -123,13 +124,13 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
 }
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
-// One launch = one batched step: one wavefront per env, four envs per workgroup (prl_step.hpp holds the step).
+// One launch = one batched step: one wavefront per env, STEP_WAVES envs per workgroup (prl_step.hpp holds the step).
 template <int KW, bool NORMAL, bool GENSEC, bool HSI = false, bool KD = false>
-__global__ __launch_bounds__(256, 4) void step_kernel(StepArgs) {
+__global__ __launch_bounds__(64 * (NORMAL ? CONE_WAVES : STEP_WAVES), 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int env = rfl(blockIdx.x * (NORMAL ? CONE_WAVES : STEP_WAVES) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     const WaveLds wl = wave_lds<GENSEC, KD, NORMAL>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
@@ -390,50 +391,13 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         }
     }
 }
-// ---------------------------------------------------------------- policy + env step in one launch
-// What a rollout worker does per step (paint_ppo.py:170-195: policy forward, sample, env.step) as ONE kernel: the
-// sixteen envs of a workgroup first run the policy on their observations together (prl_policy.hpp: three MFMA layers,
-// ~3 us, bound by the weight reads it issues up front), each wave then steps its own env with the sampled action.
-// No second launch and no ~2.5 us of dispatch gaps per step; rows as prl_policy_act + prl_batch_step write them.
+// The env step of act_step_kernel: everything is derived afresh from laundered lane / wave numbers and from the
+// kernel-argument segment, so that nothing of the policy phase is still held in registers (the step is at its ceiling).
 template <int KW>
-__global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs) {
-    extern __shared__ float lds[];
-    __shared__ int s_act[POLICY_WAVES];
-    __shared__ int s_cand[POLICY_WAVES][64];
-    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
+__device__ __forceinline__ void act_step_env(int env, int lane, int wave, int act, int (*s_cand)[64],
+                                             double (*s_centres)[PAINT_PER_ACTION * 3 + 1]) {
     const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const StepArgs CAS &a = f.s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
-    const int env0 = blockIdx.x * POLICY_WAVES, env = env0 + wave, n_envs = a.n_envs;
-    FRAG_DECL();
-    FRAG_T(ft0);
-    {
-        PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
-        W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
-        W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
-        const PolicyLds L = policy_lds_layout(W);
-        const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
-        SamplerPre sp;
-        policy_forward(W, f.obs_in + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, nullptr, f.rng_count, sp);
-        if (tid < rows_real) {
-            const int e = env0 + tid, A = W.n_actions;
-            const float u = policy_uniform(f.rng_seed, e, sp.count);
-            float lse;
-            float *Ow = lds + L.o_off;
-            const int act = policy_sample_row(A, lds + L.b3_off, Ow, tid, u, lse);
-            s_act[tid] = act;
-            POL_STAMP(7);
-            f.action[e] = act;
-            f.logp[e] = Ow[tid * 17 + act] - lse;
-            f.value[e] = Ow[tid * 17 + A];
-        }
-    }
-    __syncthreads();
-    FRAG_T(ft1);
-    FRAG_ACC(0, ft0, ft1);
-    FRAG_COUNT();
-    FRAG_FLUSH();
-    if (env >= n_envs) return;
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
@@ -442,12 +406,141 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs
     load_state_motion(state_rec, S);
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;
-    decode_discrete_action(C, s_act[wave], delta1, delta2, new_angle);
+    decode_discrete_action(C, act, delta1, delta2, new_angle);
     const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, nullptr};
     PROF_BEGIN();
     const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                                   new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
+}
+
+// ---------------------------------------------------------------- policy + env step in one launch
+// What a rollout worker does per step (paint_ppo.py:170-195: policy forward, sample, env.step) as ONE kernel: the
+// sixteen envs of a workgroup first run the policy on their observations together (prl_policy.hpp: three MFMA layers,
+// ~3 us, bound by the weight reads it issues up front), each wave then steps its own env with the sampled action.
+// No second launch and no ~2.5 us of dispatch gaps per step; rows as prl_policy_act + prl_batch_step write them.
+template <int KW>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs) {
+    extern __shared__ float lds[];
+    __shared__ int s_cand[POLICY_WAVES][64];
+    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
+    const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const StepArgs CAS &a = f.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const int env0 = blockIdx.x * POLICY_WAVES, env = env0 + wave, n_envs = a.n_envs;
+    FRAG_DECL();
+    FRAG_T(ft0);
+    int act = 0;
+    {
+        PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
+        W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
+        W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
+        const PolicyLds L = policy_lds_layout(W);
+        const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
+        SamplerPre sp;
+        policy_forward(W, f.obs_in + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, nullptr, f.rng_count, sp);
+        if (lane == 0 && wave < rows_real) {                      // every wave draws for its own env: no barrier after it
+            const int e = env0 + wave, A = W.n_actions;
+            const float u = policy_uniform(f.rng_seed, e, sp.count);
+            float lse;
+            float *Ow = lds + L.o_off;
+            act = policy_sample_row(A, lds + L.b3_off, Ow, wave, u, lse);
+            POL_STAMP(7);
+            f.action[e] = act;
+            f.logp[e] = Ow[wave * 17 + act] - lse;
+            f.value[e] = Ow[wave * 17 + A];
+        }
+    }
+    act = rfl(act);
+    FRAG_T(ft1);
+    FRAG_ACC(0, ft0, ft1);
+    FRAG_COUNT();
+    FRAG_FLUSH();
+    if (env >= n_envs) return;
+    act_step_env<KW>(opaque_s((int)blockIdx.x) * POLICY_WAVES + opaque_s(wave), opaque_v((int)(threadIdx.x & 63)), opaque_s(wave), act,
+                     s_cand, s_centres);
+}
+
+// ---------------------------------------------------------------- a whole fragment WITH the policy in one persistent launch
+// (prl_rollout_fragment with weights) -- the loop of act_step_kernel's two phases: the sixteen waves of a workgroup meet
+// at the policy's barriers, workgroups never wait for each other, nothing is launched in between.  Each phase starts
+// from laundered pointers and lane / wave numbers, so that neither holds the other's registers (5 spilled VGPRs, none in
+// a loop; the round's first version of this kernel spilled 954).  47.1 us per step against 50.4 for T launches of
+// act_step_kernel: no dispatch ramp, and only sixteen envs wait for their slowest.
+struct PolicyFragmentArgs {
+    FragmentArgs f;                // f.action is written here
+    PrlPolicyWeights w;
+    float *logp, *value, *last_value;
+    uint32_t *rng_count;
+    uint64_t rng_seed;
+};
+__device__ __forceinline__ const PolicyFragmentArgs CAS *opaque(const PolicyFragmentArgs CAS *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <int KW>
+__global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(PolicyFragmentArgs) {
+    extern __shared__ float lds[];
+    __shared__ int s_cand[POLICY_WAVES][64];
+    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
+    const PolicyFragmentArgs CAS *g0 = (const PolicyFragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int wave0 = rfl((int)(threadIdx.x >> 6));
+    for (int t = 0;; ++t) {
+        const PolicyFragmentArgs CAS &g = *opaque(g0);
+        const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0), tid = 64 * wave + lane;
+        const int env0 = opaque_s((int)blockIdx.x) * POLICY_WAVES, env = env0 + wave;
+        const int n_envs = g.f.s.n_envs, T = g.f.T;
+        const size_t n = (size_t)n_envs;
+        int act = 0;
+        {
+            PrlPolicyWeights W;
+            W.in_dim = g.w.in_dim; W.h1 = g.w.h1; W.h2 = g.w.h2; W.n_actions = g.w.n_actions;
+            W.w1 = g.w.w1; W.b1 = g.w.b1; W.w2 = g.w.w2; W.b2 = g.w.b2; W.w3 = g.w.w3; W.b3 = g.w.b3;
+            const PolicyLds L = policy_lds_layout(W);
+            const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
+            SamplerPre sp;
+            policy_forward(W, g.f.obs + ((size_t)t * n + env0) * W.in_dim, rows_real, lds, L, tid, env0, nullptr, g.rng_count, sp);
+            if (lane == 0 && wave < rows_real) {
+                const int e = env0 + wave, A = W.n_actions;
+                const float u = policy_uniform(g.rng_seed, e, sp.count);
+                float lse;
+                float *Ow = lds + L.o_off;
+                act = policy_sample_row(A, lds + L.b3_off, Ow, wave, u, lse);
+                if (t < T) {
+                    const_cast<int32_t *>(g.f.action)[(size_t)t * n + e] = act;
+                    g.logp[(size_t)t * n + e] = Ow[wave * 17 + act] - lse;
+                    g.value[(size_t)t * n + e] = Ow[wave * 17 + A];
+                } else {
+                    g.last_value[e] = Ow[wave * 17 + A];          // the bootstrap value; its draw is discarded
+                }
+            }
+        }
+        if (t >= T) break;
+        act = rfl(act);
+        if (env < n_envs) {
+            const PolicyFragmentArgs CAS &h = *opaque(g0);
+            const StepArgs CAS &a = h.f.s;
+            const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0);
+            const int env = opaque_s((int)blockIdx.x) * POLICY_WAVES + wave;
+            const int part_id = a.env_part ? a.env_part[env] : 0;
+            PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+            CfgRef C = *(const PrlConfig CAS *)a.cfg;
+            double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+            EnvState S;
+            load_state_motion(state_rec, S);
+            const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            double delta1, delta2, new_angle;
+            decode_discrete_action(C, act, delta1, delta2, new_angle);
+            const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
+            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, nullptr};
+            PROF_BEGIN();
+            const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                                          new_angle, row, wl PROF_PASS);
+            store_state_live(state_rec, S, lane, dn != 0);
+        }
+        __syncthreads();            // the observations of step t are written (workgroup-scope fences included)
+    }
 }
 
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
@@ -519,7 +612,6 @@ struct PrlBatch {
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
-    int32_t *scratch_action = nullptr; // [n_envs]: the discarded draw of prl_rollout_fragment's bootstrap policy pass
     double *state = nullptr;
     int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
     long long launch_no = 0;
@@ -857,7 +949,8 @@ int check_config(const PrlConfig *c) {
 
 template <int KW>
 void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, bool kd, hipStream_t s) {
-    const dim3 grid((a.n_envs + 3) / 4), block(256);
+    const int waves = normal ? CONE_WAVES : STEP_WAVES;
+    const dim3 grid((a.n_envs + waves - 1) / waves), block(64 * waves);
     if (kd && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, true>), grid, block, 0, s, a);
     else if (kd) hipLaunchKernelGGL((step_kernel<KW, false, false, false, true>), grid, block, 0, s, a);
     else if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true>), grid, block, 0, s, a);
@@ -1097,7 +1190,6 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
     for (double *p : b->reset_obs) (void)hipFree(p);
-    (void)hipFree(b->scratch_action);
     (void)hipFree(b->state);
     delete b;
 }
@@ -1320,24 +1412,43 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     if (!b || !obs || !reward || !done || !info || !action || n_steps < 1)
         return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
     if (int rc = check_rollout_batch(b, "prl_rollout_fragment")) return rc;
-    const size_t n = (size_t)b->n_envs, od = (size_t)obs_dim_of(b->cfg.obs_mode, b->cfg.obs_grad);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (w) {
-        // policy: one act-and-step launch per step, enqueued back to back from here (no host code of the caller in
-        // between), then the policy once more for the bootstrap value of the last observation (its draw is discarded)
+        // policy: ONE persistent launch too (rollout_policy_kernel): the sixteen envs of a workgroup alternate policy and
+        // step; after the last step the policy runs once more for the bootstrap value (its draw is discarded)
         if (!logp || !value || !last_value || !rng_count)
             return fail(PRL_E_INVALID, "prl_rollout_fragment: the policy needs logp, value, last_value and rng_count");
         if (int rc = check_policy(b, w, "prl_rollout_fragment")) return rc;
-        for (int t = 0; t < n_steps; ++t) {
-            const int rc = prl_batch_act_step(b, w, obs + (size_t)t * n * od, rng_count, rng_seed, action + (size_t)t * n,
-                                              logp + (size_t)t * n, value + (size_t)t * n, obs + (size_t)(t + 1) * n * od,
-                                              reward + (size_t)t * n, done + (size_t)t * n, info + (size_t)t * n * 2,
-                                              final_obs ? final_obs + (size_t)t * n * od : nullptr, stream);
-            if (rc) return rc;
+        {
+            PolicyFragmentArgs g{};
+            g.f.s = base_args(b);
+            g.f.T = n_steps;
+            g.f.obs = obs;
+            g.f.final_obs = final_obs;
+            g.f.reward = reward;
+            g.f.done = done;
+            g.f.info = info;
+            g.f.action = action;
+            g.w = *w;
+            g.logp = logp;
+            g.value = value;
+            g.last_value = last_value;
+            g.rng_count = rng_count;
+            g.rng_seed = rng_seed;
+            const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
+            void (*kernel)(PolicyFragmentArgs) = nullptr;
+            switch (b->kw) {
+            case 1: kernel = rollout_policy_kernel<1>; break;
+            case 2: kernel = rollout_policy_kernel<2>; break;
+            case 3: kernel = rollout_policy_kernel<3>; break;
+            default: kernel = rollout_policy_kernel<4>; break;
+            }
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kernel, dim3((b->n_envs + POLICY_WAVES - 1) / POLICY_WAVES), dim3(64 * POLICY_WAVES), lds, s, g);
+            HIP_TRY(hipGetLastError());
+            return PRL_OK;
         }
-        if (!b->scratch_action) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->scratch_action), sizeof(int32_t) * n));
-        return prl_policy_act(w, b->n_envs, obs + (size_t)n_steps * n * od, nullptr, rng_count, rng_seed, b->scratch_action,
-                              nullptr, last_value, nullptr, stream);
     }
     // given actions: ONE persistent launch, the waves never meet (rollout_fragment_kernel)
     FragmentArgs f{};

@@ -34,17 +34,18 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void policy_act_kernel(PolicyArg
     const int rows_real = a.n - env0 < ROWS ? a.n - env0 : ROWS;
     SamplerPre sp;
     policy_forward(W, a.obs + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, a.uniform, a.rng_count, sp);
-    if (tid < rows_real) {                          // one env per thread: softmax, inverse-CDF draw
-        const int env = env0 + tid, A = W.n_actions;
+    const int row = tid >> 6;
+    if ((tid & 63) == 0 && row < rows_real) {       // lane 0 of wave R: softmax and inverse-CDF draw for env row R
+        const int env = env0 + row, A = W.n_actions;
         const float u = a.uniform ? sp.u : policy_uniform(a.rng_seed, env, sp.count);
         float lse;
         float *Ow = lds + L.o_off;
-        const int act = policy_sample_row(A, lds + L.b3_off, Ow, tid, u, lse);
+        const int act = policy_sample_row(A, lds + L.b3_off, Ow, row, u, lse);
         a.action[env] = act;
-        if (a.logp) a.logp[env] = Ow[tid * 17 + act] - lse;
-        if (a.value) a.value[env] = Ow[tid * 17 + A];
+        if (a.logp) a.logp[env] = Ow[row * 17 + act] - lse;
+        if (a.value) a.value[env] = Ow[row * 17 + A];
         if (a.logits)
-            for (int j = 0; j < A; ++j) a.logits[(size_t)env * A + j] = Ow[tid * 17 + j];
+            for (int j = 0; j < A; ++j) a.logits[(size_t)env * A + j] = Ow[row * 17 + j];
     }
 }
 

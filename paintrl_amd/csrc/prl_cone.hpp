@@ -107,14 +107,14 @@ __device__ void rays_general_lanes(PartRef P, const double o[3], const double ds
             const f32x4 ca = {bcast_f(cla.x, cl), bcast_f(cla.y, cl), bcast_f(cla.z, cl), bcast_f(cla.w, cl)};
             const f32x4 cb = {bcast_f(clb.x, cl), bcast_f(clb.y, cl), 0.0f, 0.0f};
             const bool ov = need && box_overlap(sb, ca, cb);
-            if (__ballot(ov) == 0) continue;
+            if (ballot64(ov) == 0) continue;
             const int i0 = (cbase + cl) << 6;
             const f32x4 tla = ldg(boxes, 2 * (i0 + lane)), tlb = ldg(boxes, 2 * (i0 + lane) + 1);
             for (int tl = 0; tl < 64; ++tl) {
                 const f32x4 ba = {bcast_f(tla.x, tl), bcast_f(tla.y, tl), bcast_f(tla.z, tl), bcast_f(tla.w, tl)};
                 const f32x4 bb = {bcast_f(tlb.x, tl), bcast_f(tlb.y, tl), 0.0f, 0.0f};
                 const bool pass = ov && box_overlap(sb, ba, bb);
-                if (__ballot(pass) == 0) continue;
+                if (ballot64(pass) == 0) continue;
                 mt_one(P, pass ? i0 + tl : -1, o, d0, d1, d2, 1.0, best_t, best_r, best_i, best_det);
             }
         }
@@ -138,7 +138,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     if (P.col_convex && hint >= 0) {
         int f = hint, rk = 0;
         for (int step = 0; step < CONE_WALK_STEPS; ++step) {
-            if (__ballot(state == 0) == 0) break;
+            if (ballot64(state == 0) == 0) break;
             if (state == 0) {
                 int next;
                 const int r = cone_walk_step(P, f, pos, d0, d1, d2, dd, t, rk, next);
@@ -160,7 +160,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     hit[1] = pos[1] + t * d1;
     hit[2] = pos[2] + t * d2;
     // the stragglers (edge and vertex hits, and every miss), together
-    const uint64_t todo = __ballot(state == 3);
+    const uint64_t todo = ballot64(state == 3);
     WCNT16(0, __popcll(todo));
     if (todo) {
         double tw;
@@ -192,7 +192,7 @@ __device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
     int result = want ? -2 : -1;
     bool open = want;
     for (int ring = 1; ring <= 3; ++ring) {
-        if (__ballot(open) == 0) break;
+        if (ballot64(open) == 0) break;
         double best_d = INFINITY;
         int best_rank = 0x7fffffff, best_pos = -1;
         const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.fg_nx - 1 ? P.fg_nx - 1 : icx + ring;
@@ -201,7 +201,7 @@ __device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
             const bool row_ok = open && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
             const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
             const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
-            for (int i0 = b; __ballot(i0 < e) != 0; i0 += 4) {
+            for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4) {
                 f64x2 ra[4], rb[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -6,7 +6,13 @@
 namespace {
 
 
-constexpr int MAX_WAVES_PER_WG = 4;              // per-wave LDS scratch rows: every kernel here runs four waves per workgroup
+#ifndef PRL_STEP_WAVES
+#define PRL_STEP_WAVES 8                         // envs (= waves) per workgroup of step_kernel: 4 / 8 / 16 measured
+                                                 // 41.8 / 41.05 / 41.0 us (fewer workgroups to dispatch); cone beams: 4
+#endif
+constexpr int STEP_WAVES = PRL_STEP_WAVES;
+constexpr int CONE_WAVES = 4;                    // ... of its cone-beam instantiations (8 KB of LDS mask rows per wave)
+constexpr int MAX_WAVES_PER_WG = STEP_WAVES > 4 ? STEP_WAVES : 4;   // per-wave LDS scratch rows
 constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples in registers
 constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3 copies x 4 waves x 1600 x 8 B = 150 KB of 160 KB
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
@@ -134,6 +140,14 @@ __device__ __forceinline__ T ldg(const T GAS *p, int i) {
 }
 
 // ---------------------------------------------------------------- wave helpers
+// HIP's __ballot(int) compares its argument with zero again (a v_cndmask + a v_cmp per call on top of the compare that
+// produced the predicate); the builtin takes the predicate's own lane mask.  Same result: bit l = predicate of active lane l.
+#ifdef PRL_OLD_BALLOT                    // (A/B switch)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+#else
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Per-wave LDS scratch of a workgroup (MAX_WAVES_PER_WG waves): the ray's candidate list, the five shot centres of
@@ -156,7 +170,7 @@ __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
     __shared__ double s_kd[KD ? MAX_WAVES_PER_WG : 1][KD ? KD_HEAP * 5 : 1];
-    __shared__ uint64_t s_mask[CONE ? MAX_WAVES_PER_WG : 1][CONE ? 4 * 64 * KW_MAX : 1];
+    __shared__ uint64_t s_mask[CONE ? CONE_WAVES : 1][CONE ? 4 * 64 * KW_MAX : 1];     // (32 KB at four waves)
     const int w = rfl((int)(threadIdx.x >> 6));
     if constexpr (CONE) {
 #pragma unroll

@@ -134,7 +134,7 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
                 straddle = !vline[k];
             }
         }
-        smask[k] = __ballot(straddle);
+        smask[k] = ballot64(straddle);
     }
     // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
     // { xs > x1 } a suffix of the word.  The owning lane finds the prefix length in two round trips, all its rows at
@@ -145,7 +145,7 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
         bool any = false;
 #pragma unroll
         for (int k = 0; k < KW; ++k) any = any || vline[k];
-        if (__ballot(any)) {
+        if (ballot64(any)) {
             const f64x4 GAS *pv = reinterpret_cast<const f64x4 GAS *>(P.word_pivot);
             const f64x4 GAS *sx4 = reinterpret_cast<const f64x4 GAS *>(sx);
             int grp[KW_MAX];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 int ub = pos[k];
-                if (__ballot(eq[k] && vline[k])) {                  // a sample exactly on the line: the run of equals ends at samp_ub
+                if (ballot64(eq[k] && vline[k])) {                  // a sample exactly on the line: the run of equals ends at samp_ub
                     const int at = ((vline[k] ? lane + 64 * (slot0 + k) : 0) << 6) + (pos[k] < 64 ? pos[k] : 63);
                     if (eq[k]) ub = (int)ldg(P.samp_ub, at);
                 }

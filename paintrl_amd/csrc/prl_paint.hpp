@@ -156,8 +156,8 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
             for (int k = 0; k < PAINT_PER_ACTION; ++k) {
                 const float dx = pf.x - cf[k][0], dy = pf.y - cf[k][1], dz = pf.z - cf[k][2];
                 const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                b[k] = __ballot(in && dd <= r2_in);
-                unsure |= b[k] ^ __ballot(in && dd <= r2_out);
+                b[k] = ballot64(in && dd <= r2_in);
+                unsure |= b[k] ^ ballot64(in && dd <= r2_out);
                 any |= b[k];
             }
 #ifdef PRL_FORCE_F64_PAINT
@@ -171,7 +171,7 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
                 for (int k = 0; k < PAINT_PER_ACTION; ++k) {
                     const double dx = x - cen_lds[3 * k], dy = y - cen_lds[3 * k + 1], dz = z - cen_lds[3 * k + 2];
                     const double dd = (dx * dx + dy * dy) + dz * dz;
-                    b[k] = __ballot(in && dd <= r2);
+                    b[k] = ballot64(in && dd <= r2);
                     any |= b[k];
                 }
             }
@@ -233,7 +233,7 @@ __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds,
                         if (hit) dmax_l = dd > dmax_l ? dd : dmax_l;
                         continue;
                     }
-                    const uint64_t b = __ballot(hit);
+                    const uint64_t b = ballot64(hit);
                     if (b == 0) continue;
                     uint8_t v = thick[s];
                     if (hit) {
@@ -245,7 +245,7 @@ __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds,
                             thick[s] = v;
                         }
                     }
-                    const uint64_t stat = __ballot(hit && v == 255);
+                    const uint64_t stat = ballot64(hit && v == 255);
                     const int owner = w & 63, slot = w >> 6;
 #pragma unroll
                     for (int k = 0; k < KW; ++k)

@@ -49,9 +49,10 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {          // splitmix64 f
 //     "column-interleaved" tiles (tile q = columns c0 + 4 r + q, r = 0..15), so the float4 at row k, column
 //     c0 + 4 r is lane r's B operand of the four tiles at once, and a read instruction covers whole 128-byte lines.
 //   layer 1: one 16-column tile of H1 per wave (h1 / 16 items), k = the observation
-//   layer 2: ceil(h2 / 64) x L2_KS items: a 64-column group over one of L2_KS = 8 slices of k; the eight partial
-//            sums of an output are added in LDS in slice order, then bias and tanh
-//   head   : four waves take a quarter of k each (<= 16 columns), summed by the sampler
+//   layer 2: ceil(h2 / 64) x L2_KS items: a 64-column group over one of L2_KS = 8 slices of k, partial sums to LDS
+//   head   : sixteen waves take a sixteenth of k each (<= 16 columns); a wave forms the H2 values of its slice itself
+//            (the eight partial sums in slice order, + bias, tanh) -- no separate reduction pass, no barrier for it;
+//            the sixteen partial head tiles are summed by the sampler
 // Within a layer-1 / head item k ascends in two interleaved chains (even / odd MFMA steps: a dependent 16x16x4 waits
 // 40 cycles, the issue interval is 32) that are added at the end; a layer-2 item has its four tiles to interleave.
 // This IS the arithmetic of the policy, for both kernels.
@@ -169,9 +170,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __frcp_rn(e + 1.0f);
 }
 
-// LDS layout of a workgroup (floats): X | H1 | P (L2_KS partial sums of layer 2) | H2 | O | the head's biases | W3
+// LDS layout of a workgroup (floats): X | H1 | P (L2_KS partial sums of layer 2) | O (HEAD_KS partial head tiles) |
+// the head's biases | W3 | b2
+constexpr int HEAD_KS = 16;           // k-slices of the head = waves: each adds the layer-2 partial sums of its slice itself
 struct PolicyLds {
-    int in_pad, xs, s1, s2, h1_off, p_off, h2_off, o_off, b3_off, w3_off, floats;
+    int in_pad, xs, s1, s2, h1_off, p_off, o_off, b3_off, w3_off, b2_off, floats;
 };
 __host__ __device__ inline PolicyLds policy_lds_layout(const PrlPolicyWeights &w) {
     PolicyLds L;
@@ -181,11 +184,11 @@ __host__ __device__ inline PolicyLds policy_lds_layout(const PrlPolicyWeights &w
     L.s2 = w.h2 + PAD;
     L.h1_off = ROWS * L.xs;
     L.p_off = L.h1_off + ROWS * L.s1;
-    L.h2_off = L.p_off + L2_KS * ROWS * L.s2;
-    L.o_off = L.h2_off + ROWS * L.s2;
-    L.b3_off = L.o_off + 4 * ROWS * 17;
+    L.o_off = L.p_off + L2_KS * ROWS * L.s2;
+    L.b3_off = L.o_off + HEAD_KS * ROWS * 17;
     L.w3_off = L.b3_off + 16;
-    L.floats = L.w3_off + w.h2 * (w.n_actions + 1);
+    L.b2_off = L.w3_off + w.h2 * (w.n_actions + 1);
+    L.floats = L.b2_off + w.h2;
     return L;
 }
 
@@ -196,8 +199,8 @@ struct SamplerPre {
 };
 
 // obs: the observation rows of this workgroup's envs (f64, row stride in_dim), rows_real of them (the rest read as
-// zero rows).  Called by all 64 * POLICY_WAVES threads; ends with a __syncthreads(): the four partial head tiles
-// O[q][16][17] at lds + L.o_off are complete on return.  Threads tid < rows_real also return what their env's
+// zero rows).  Called by all 64 * POLICY_WAVES threads; ends with a __syncthreads(): the HEAD_KS partial head tiles
+// O[q][16][17] at lds + L.o_off are complete on return.  Lane 0 of the waves < rows_real also returns what its env's
 // sampler needs: the uniform number (uniform[env]) or the counter to draw it from (seed, env, rng_count[env]; the
 // counter is advanced here); the head's biases go to lds + L.b3_off.
 __device__ __forceinline__ void policy_forward(const PrlPolicyWeights &W, const double *obs, int rows_real, float *lds,
@@ -205,9 +208,9 @@ __device__ __forceinline__ void policy_forward(const PrlPolicyWeights &W, const 
                                                uint32_t *rng_count, SamplerPre &sp) {
     constexpr int NT = 64 * POLICY_WAVES, NS1 = 4;
     const int wave = tid >> 6, lane = tid & 63, r = lane & 15, hq = lane >> 4, n_out = W.n_actions + 1;
-    float *X = lds, *H1 = lds + L.h1_off, *P = lds + L.p_off, *H2 = lds + L.h2_off, *O = lds + L.o_off;
+    float *X = lds, *H1 = lds + L.h1_off, *P = lds + L.p_off, *O = lds + L.o_off;
     const int n1 = W.h1 / 16, n_grp = (W.h2 + 63) / 64, n2 = n_grp * L2_KS;
-    const int kslice = ((W.h1 + L2_KS - 1) / L2_KS + 3) & ~3, kq = ((W.h2 / 4) + 3) & ~3;
+    const int kslice = ((W.h1 + L2_KS - 1) / L2_KS + 3) & ~3, kh = ((W.h2 + HEAD_KS - 1) / HEAD_KS + 3) & ~3;
     POL_STAMP(0);
     // ---- every read that does not depend on an activation, before the first barrier
     const int xrow = tid / L.in_pad, xk = tid - xrow * L.in_pad;           // (in_pad <= 64: one element per thread)
@@ -225,17 +228,20 @@ __device__ __forceinline__ void policy_forward(const PrlPolicyWeights &W, const 
         const int kb = (w2 % L2_KS) * kslice, ke = kb + kslice < W.h1 ? kb + kslice : W.h1;
         load_b4(W.w2, W.h2, (w2 / L2_KS) * 64, W.h2, kb, ke, lane, pre2);
     }
-    const int col2 = tid % W.h2;                                           // this thread's column in the reduction below
-    const float bias2 = wld<float>(W.b2, (uint32_t)col2);                  // (NT % h2 == 0 or one pass: see there)
-    const int srow = tid < rows_real ? tid : 0;                            // sampler threads; the others read row 0's
+    const float b2v = wld<float>(W.b2, (uint32_t)(tid < W.h2 ? tid : 0));  // layer-2 biases go to LDS too
+    // the sampler of env row R is lane 0 of wave R (every wave samples for its own env: no barrier after the draw)
+    const bool sampler = (tid & 63) == 0 && (tid >> 6) < rows_real;
+    const int srow = sampler ? tid >> 6 : 0;                               // (the other threads read row 0's words)
     const float b3v = wld<float>(W.b3, (uint32_t)(tid < n_out ? tid : 0));
     sp.u = *(uniform ? uniform + env0 + srow : W.b3);                     // (whichever is absent reads a harmless word)
     sp.count = *(uniform ? reinterpret_cast<const uint32_t *>(W.b3) : rng_count + env0 + srow);
     __builtin_amdgcn_sched_barrier(0);      // every read above is issued before the first result is waited for
     if (tid < 16) lds[L.b3_off + tid] = tid < n_out ? b3v : 0.0f;
     if (tid < n_w3) lds[L.w3_off + tid] = w3v;
+    if (tid < W.h2) lds[L.b2_off + tid] = b2v;
+    for (int i = tid + NT; i < W.h2; i += NT) lds[L.b2_off + i] = wld<float>(W.b2, (uint32_t)i);
     for (int i = tid + NT; i < n_w3; i += NT) lds[L.w3_off + i] = wld<float>(W.w3, (uint32_t)i);
-    if (!uniform && tid < rows_real) rng_count[env0 + tid] = sp.count + 1;
+    if (!uniform && sampler) rng_count[env0 + srow] = sp.count + 1;
     if (tid < ROWS * L.in_pad) X[xrow * L.xs + xk] = x_ok ? (float)xraw : 0.0f;
     for (int i = tid + NT; i < ROWS * L.in_pad; i += NT) {                 // (wider inputs: the rest of X)
         const int row = i / L.in_pad, k = i - row * L.in_pad;
@@ -283,27 +289,22 @@ __device__ __forceinline__ void policy_forward(const PrlPolicyWeights &W, const 
     }
     __syncthreads();
     POL_STAMP(3);
-    for (int i = tid; i < ROWS * W.h2; i += NT) {                          // H2 = tanh(sum of the slices, in order, + b2)
-        const int row = i / W.h2, col = i - row * W.h2;
-        float v = P[row * L.s2 + col];
+    {                                                                      // ---- head: a sixteenth of k per wave
+        const int kb = wave * kh, ke = kb + kh < W.h2 ? kb + kh : W.h2;
+        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float *W3 = lds + L.w3_off, *B2 = lds + L.b2_off;
+        for (int k0 = kb; k0 < ke; k0 += 4) {
+            const int k = k0 + hq;
+            float a = 0.0f, bw = 0.0f;
+            if (k < ke) {
+                float v = P[r * L.s2 + k];                                 // H2[r][k] = tanh(slices in order + b2)
 #pragma unroll
-        for (int sl = 1; sl < L2_KS; ++sl) v += P[sl * (ROWS * L.s2) + row * L.s2 + col];
-        H2[row * L.s2 + col] = fast_tanh(v + (col == col2 ? bias2 : W.b2[col]));
-    }
-    __syncthreads();
-    POL_STAMP(4);
-    if (wave < 4) {                                                        // ---- head: a quarter of k per wave
-        const int kb = wave * kq, ke = kb + kq < W.h2 ? kb + kq : W.h2;
-        f32x4 c0 = {0.0f, 0.0f, 0.0f, 0.0f}, c1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float *W3 = lds + L.w3_off;
-        for (int k0 = kb; k0 < ke; k0 += 8) {                              // two steps per trip, both operands from LDS
-            const int ka = k0 + hq, kc = k0 + 4 + hq;
-            const float a0 = ka < ke ? H2[r * L.s2 + ka] : 0.0f, a1 = kc < ke ? H2[r * L.s2 + kc] : 0.0f;
-            const float b0 = (ka < ke && r < n_out) ? W3[ka * n_out + r] : 0.0f, b1 = (kc < ke && r < n_out) ? W3[kc * n_out + r] : 0.0f;
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c1, 0, 0, 0);
+                for (int sl = 1; sl < L2_KS; ++sl) v += P[sl * (ROWS * L.s2) + r * L.s2 + k];
+                a = fast_tanh(v + B2[k]);
+                bw = r < n_out ? W3[k * n_out + r] : 0.0f;
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, c, 0, 0, 0);
         }
-        const f32x4 c = c0 + c1;
         float *Ow = O + wave * (ROWS * 17);
 #pragma unroll
         for (int g = 0; g < 4; ++g) Ow[(4 * hq + g) * 17 + r] = c[g];
@@ -312,15 +313,19 @@ __device__ __forceinline__ void policy_forward(const PrlPolicyWeights &W, const 
     POL_STAMP(5);
 }
 
-// One env (row `row` of the workgroup's tiles): logits + value from the four partial head tiles, softmax, and the
+// One env (row `row` of the workgroup's tiles): logits + value from the HEAD_KS partial head tiles, softmax, and the
 // inverse-CDF draw for the uniform number u.  Returns the action; the row's final outputs (A logits, then the value)
 // replace its partial sums in the first head tile, O[row * 17 + j], where the caller reads what it needs (an array
 // in registers read at a run-time index ends up in scratch memory); lse = the log-sum-exp of the logits.
+// (Tried: the sixteen partial sums of a row added by sixteen lanes with DPP row shifts -- 1.8 us instead of 1.3.)
 __device__ __forceinline__ int policy_sample_row(int A, const float *b3 /* LDS */, float *O, int row, float u, float &lse) {
     float *o = O + row * 17;
     float m = -INFINITY;
     for (int j = 0; j <= A; ++j) {
-        const float v = (((o[j] + O[ROWS * 17 + row * 17 + j]) + O[2 * ROWS * 17 + row * 17 + j]) + O[3 * ROWS * 17 + row * 17 + j]) + b3[j];
+        float v = o[j];
+#pragma unroll
+        for (int q = 1; q < HEAD_KS; ++q) v += O[q * (ROWS * 17) + row * 17 + j];
+        v += b3[j];
         o[j] = v;
         if (j < A) m = fmaxf(m, v);
     }

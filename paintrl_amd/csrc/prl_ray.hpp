@@ -113,12 +113,12 @@ __device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], doub
 
 // Lane holding the wave's best (t, rank); -1 if no lane has a hit.
 __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
-    if (__ballot(best_t < INFINITY) == 0) return -1;
+    if (ballot64(best_t < INFINITY) == 0) return -1;
     tmin = wave_min_nonneg_d(best_t + 0.0);        // t >= 0 or +inf (no hit in this lane); + 0.0 turns a -0.0 into +0.0
-    const uint64_t tie = __ballot(best_t == tmin);
+    const uint64_t tie = ballot64(best_t == tmin);
     if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
     const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
-    return __builtin_ctzll(__ballot(best_t == tmin && best_r == rmin));
+    return __builtin_ctzll(ballot64(best_t == tmin && best_r == rmin));
 }
 
 // `hint` (in/out): collision-set position of the facet hit by the previous ray of this env, or -1.
@@ -184,7 +184,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         const int i1 = lane < P.nbr_width ? ldg(P.col_nbr, hint * P.nbr_width + lane) : -1;
         bool interior;
         mt_rec(P, i1, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
-        const uint64_t im = __ballot(interior);
+        const uint64_t im = ballot64(interior);
         if (im) {
             win = __builtin_ctzll(im);
             tmin = bcast_d(best_t, win);
@@ -197,7 +197,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
                 const double fdet = bcast_d(best_det, win);
                 const int i2 = lane < P.nbr_width ? ldg(P.col_nbr, f * P.nbr_width + lane) : -1;
                 const bool entering = (double)P.col_orient[f] * fdet > 0;
-                if (entering && __ballot(i2 >= 0) != 0) {
+                if (entering && ballot64(i2 >= 0) != 0) {
                     if (f != hint) {
                         WCNT(4, 16);
                         mt_rec(P, i2, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
@@ -227,14 +227,14 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
             int n_cand = 0;
             for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
                 const f32x4 ca = ldg(chunk_boxes, 2 * (cbase + lane)), cb = ldg(chunk_boxes, 2 * (cbase + lane) + 1);
-                uint64_t cm = __ballot(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
+                uint64_t cm = ballot64(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
                 while (cm) {
                     WCNT(2, 1);
                     const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
                     cm &= cm - 1;
                     const f32x4 ba = ldg(boxes, 2 * i), bb = ldg(boxes, 2 * i + 1);
                     const bool pass = box_overlap(sb, ba, bb);
-                    const uint64_t pm = __ballot(pass);
+                    const uint64_t pm = ballot64(pass);
                     if (pm == 0) continue;
                     const int np = __popcll(pm);
                     if (n_cand + np > 64) {                        // list full: test what is queued first
@@ -254,7 +254,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
                 mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
                 __builtin_amdgcn_wave_barrier();
             }
-            if (__ballot(best_t < INFINITY)) break;
+            if (ballot64(best_t < INFINITY)) break;
         }
         win = ray_winner_lane(best_t, best_r, tmin);
     }

@@ -155,11 +155,11 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         nv_scan(P, 0, P.n_vertices, pt, lane, best_d, best_rank, best_idx);
         dmin = wave_min_nonneg_d(best_d);
     }
-    const uint64_t tie = __ballot(best_d == dmin);
+    const uint64_t tie = ballot64(best_d == dmin);
     if (tie == 0) return -1;                                        // NaN query point
     if ((tie & (tie - 1)) == 0) return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(tie)));
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
-    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin);
+    const uint64_t win = ballot64(best_d == dmin && best_rank == rmin);
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
 
@@ -202,14 +202,14 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
                 const double dmin = wave_min_d(d);
                 if (dmin < dub) {                                   // the first point (tree order) reaching the minimum
                     dub = dmin;
-                    best = __builtin_amdgcn_readlane(v, rfl(__builtin_ctzll(__ballot(d == dmin))));
+                    best = __builtin_amdgcn_readlane(v, rfl(__builtin_ctzll(ballot64(d == dmin))));
                 }
             }
             if (n_heap == 0) break;
             // pop the nearest queued cell: lane l looks at entry l
             const double key = lane < n_heap ? heap[5 * lane] : INFINITY;
             const double kmin = wave_min_d(key);
-            const int m = rfl(__builtin_ctzll(__ballot(key == kmin)));
+            const int m = rfl(__builtin_ctzll(ballot64(key == kmin)));
             mind = heap[5 * m];
             side0 = heap[5 * m + 1];
             side1 = heap[5 * m + 2];
@@ -310,7 +310,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
         dmin = wave_min_nonneg_d(best_d);
     }
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
-    const uint64_t win = __ballot(best_d == dmin && best_rank == rmin && best_idx >= 0);
+    const uint64_t win = ballot64(best_d == dmin && best_rank == rmin && best_idx >= 0);
     if (win == 0) return -1;
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
@@ -329,7 +329,7 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;
     const int ti = lane < P.adj_width ? ldg(P.vadj, vidx * P.adj_width + lane) : -1;   // file order, -1 = pad
-    if (__ballot(ti >= 0) == 0) return false;
+    if (ballot64(ti >= 0) == 0) return false;
     bool inside = false, ok = false;
     double m = -INFINITY, n0, n1, n2;
     if (ti >= 0) {
@@ -356,16 +356,16 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
         ok = m >= -1.0;
     }
     int j;
-    const uint64_t in_mask = __ballot(inside);
+    const uint64_t in_mask = ballot64(inside);
     if (in_mask) {
         j = __builtin_ctzll(in_mask);                               // first triangle containing the point
     } else {
-        const uint64_t ok_mask = __ballot(ok);
+        const uint64_t ok_mask = ballot64(ok);
         if (ok_mask == 0) {
             j = 0;                                                   // nothing beat -1: the first candidate stays
         } else {
             const double mx = wave_max_d(ok ? m : -INFINITY);
-            j = 63 - __builtin_clzll(__ballot(ok && m == mx));       // last one reaching the maximum
+            j = 63 - __builtin_clzll(ballot64(ok && m == mx));       // last one reaching the maximum
         }
     }
     // the chosen triangle's normal, quaternion and centre offset: one wave-uniform read of its record's tail

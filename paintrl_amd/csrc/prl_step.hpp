@@ -119,9 +119,11 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     double *cen = wl.cen;
     // the guided point's offset from the pose (bpw:865-880: d1 along axis a1, d2 * lwr along a2) is the same for the
     // five shots; the third component is -0.0, the one addend that leaves every double (either zero too) unchanged
+    // (held in scalar registers: as three vector-register pairs it was what the act-and-step kernel spilled to scratch
+    // and fetched back in every shot)
     const double delta_2 = d2 * P.lwr;
-    const double dvec[3] = {P.a1 == 0 ? d1 : (P.a2 == 0 ? delta_2 : -0.0), P.a1 == 1 ? d1 : (P.a2 == 1 ? delta_2 : -0.0),
-                            P.a1 == 2 ? d1 : (P.a2 == 2 ? delta_2 : -0.0)};
+    const double dvec[3] = {uni_d(P.a1 == 0 ? d1 : (P.a2 == 0 ? delta_2 : -0.0)), uni_d(P.a1 == 1 ? d1 : (P.a2 == 1 ? delta_2 : -0.0)),
+                            uni_d(P.a1 == 2 ? d1 : (P.a2 == 2 ? delta_2 : -0.0))};
 #if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
     for (int shot = 0; shot < 0; ++shot) {
 #else
@@ -192,13 +194,13 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
                 double bh[3];
                 const bool hit = cone_rays_lanes(P, pos, quat, b0, facet_hint, lane, wl.cand, bh PROF_PASS);
                 STAMP(PH_RAY);                                    // (stamped builds: the cone's rays count as 'ray',
-                uint64_t hm = __ballot(hit);                       //  its nearest-sample queries as 'paint', fallbacks as 'apply')
+                uint64_t hm = ballot64(hit);                       //  its nearest-sample queries as 'paint', fallbacks as 'apply')
                 beam_hits += __popcll(hm);
                 // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle
                 // go through the wave-wide search.  Bits are collected in this wave's LDS mask row.
                 int sidx = nearest_sample_lane(P, bh, hit);
                 STAMP(PH_BALL);
-                uint64_t rest = __ballot(sidx == -2);
+                uint64_t rest = ballot64(sidx == -2);
                 WCNT16(1, __popcll(rest));
                 WCNT16(3, __popcll(hm));
                 while (rest) {

@@ -50,12 +50,13 @@ class RolloutWorker(object):
     observations, rewards, done flags, info and terminal observations into theirs.  The float32 views RLlib
     expects are made once per fragment."""
 
-    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True, persistent=False):
+    def __init__(self, env, policy, fragment=FRAGMENT, seed=0, fused=True, persistent=False, act_step=False):
         """``persistent=True`` (with the fused policy): a whole fragment is ONE launch of the persistent rollout
-        kernel (``prl_rollout_fragment``) instead of 2 T launches; the buffers receive the same bits."""
-        self.persistent = bool(persistent)
-        if self.persistent and not fused:
-            raise ValueError('persistent=True needs the fused policy')
+        kernel (``prl_rollout_fragment``) instead of 2 T launches; ``act_step=True``: T launches, policy and env
+        step in one (``prl_batch_act_step``).  The buffers receive the same bits either way."""
+        self.persistent, self.act_step = bool(persistent), bool(act_step)
+        if (self.persistent or self.act_step) and not fused:
+            raise ValueError('persistent / act_step need the fused policy')
         if not env.cfg.auto_reset:
             raise ValueError('RolloutWorker needs BatchedPaintEnv(auto_reset=True)')
         self.env, self.policy, self.T = env, policy, int(fragment)
@@ -104,6 +105,15 @@ class RolloutWorker(object):
             env.rollout_fragment(T, raw['obs'], raw['final_obs'], raw['rewards'], raw['dones'], raw['infos'], b['actions'],
                                  weights=fp._w, logp=b['action_logp'], value=b['vf_preds'], last_value=self._last_value,
                                  rng_count=fp._rng_count, rng_seed=fp.seed)
+        elif self.act_step:
+            fp = self.fused
+            if fp._rng_count is None or fp._rng_count.shape[0] != env.n_envs:
+                fp._rng_count = torch.zeros(env.n_envs, dtype=torch.int32, device=env.device)
+            for t in range(T):
+                env.act_step_into(fp._w, raw['obs'][t], fp._rng_count, fp.seed, b['actions'][t], b['action_logp'][t],
+                                  b['vf_preds'][t], raw['obs'][t + 1], raw['rewards'][t], raw['dones'][t], raw['infos'][t],
+                                  raw['final_obs'][t])
+            self.fused.act_into(raw['obs'][T], self._scratch_action, self._scratch_logp, self._last_value)
         elif self.fused is not None:
             for t in range(T):
                 self.fused.act_into(raw['obs'][t], b['actions'][t], b['action_logp'][t], b['vf_preds'][t])
@@ -133,8 +143,8 @@ class RolloutWorker(object):
 
 
 class FragmentRunner(object):
-    """bench.py --policy fragment: policy + env for up to ``fragment`` steps per launch, rows into a ring of
-    trajectory buffers (what RolloutWorker(persistent=True) does, without the float32 SampleBatch views)."""
+    """bench.py --policy fragment: policy + env for up to ``fragment`` steps in one persistent launch, rows into a ring
+    of trajectory buffers (what RolloutWorker(persistent=True) does, without the float32 SampleBatch views)."""
 
     def __init__(self, env, policy, fragment=FRAGMENT, seed=0, given_actions=None):
         """``given_actions``: int32 (steps, N) device tensor; the kernel then reads its action rows from it (in order,

@@ -168,3 +168,31 @@ def test_persistent_fragment_with_policy_equals_two_launches_per_step():
     assert torch.equal(envs[0].painted_words(), envs[1].painted_words())
     for e in envs:
         e.close()
+
+
+def test_act_step_launch_equals_policy_launch_plus_step_launch():
+    """prl_batch_act_step -- policy and env step of one worker iteration in ONE launch -- writes exactly the rows of
+    prl_policy_act followed by prl_batch_step, over two fragments (150 envs: a ragged last workgroup)."""
+    import torch
+    from conftest import synthetic_tables
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    tables = synthetic_tables('door_test')
+    n, T = 150, 30
+    envs = [BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=12) for _ in range(2)]
+    torch.manual_seed(4)
+    policy = MLPPolicy(envs[0].obs_dim, 4).to(envs[0].device)
+    workers = [RolloutWorker(envs[0], policy, fragment=T, seed=6), RolloutWorker(envs[1], policy, fragment=T, seed=6, act_step=True)]
+    for frag in range(2):
+        out = [w.collect() for w in workers]
+        torch.cuda.synchronize()
+        (b0, v0, r0), (b1, v1, r1) = out
+        for k in b0:
+            assert torch.equal(b0[k], b1[k]), (frag, k)
+        assert torch.equal(v0, v1) and torch.equal(r0, r1)
+        for k in workers[0].raw:
+            assert torch.equal(workers[0].raw[k], workers[1].raw[k]), (frag, k)
+    assert torch.equal(envs[0].painted_words(), envs[1].painted_words())
+    for e in envs:
+        e.close()
