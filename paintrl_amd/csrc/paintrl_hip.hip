@@ -915,6 +915,58 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         UP(fg_start, start.data(), start.size());
         UP(fg_rec, rec.data(), rec.size());
     }
+    {   // outline of the collision set in the principal plane (Andrew's monotone chain over the projected corners)
+        std::vector<std::pair<double, double>> pts;
+        double zlo = INFINITY, zhi = -INFINITY;
+        for (int i = 0; i < t->n_collision_pad; ++i) {
+            if (t->col_rank[i] == 0x7fffffff) continue;                 // pad
+            for (int c = 0; c < 3; ++c) {
+                double v[3];
+                for (int k = 0; k < 3; ++k)
+                    v[k] = t->col_v0e1e2[k][i] + (c == 1 ? t->col_v0e1e2[3 + k][i] : (c == 2 ? t->col_v0e1e2[6 + k][i] : 0.0));
+                pts.emplace_back(v[d.a1], v[d.a2]);
+                zlo = std::fmin(zlo, v[d.a0]);
+                zhi = std::fmax(zhi, v[d.a0]);
+            }
+        }
+        std::sort(pts.begin(), pts.end());
+        pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+        std::vector<std::pair<double, double>> hull(2 * pts.size() + 2);
+        size_t k = 0;
+        auto cross = [](const std::pair<double, double> &o, const std::pair<double, double> &a, const std::pair<double, double> &b) {
+            return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
+        };
+        for (size_t i = 0; i < pts.size(); ++i) {
+            while (k >= 2 && cross(hull[k - 2], hull[k - 1], pts[i]) <= 0) --k;
+            hull[k++] = pts[i];
+        }
+        for (size_t i = pts.size() - 1, lower = k + 1; i-- > 0;) {
+            while (k >= lower && cross(hull[k - 2], hull[k - 1], pts[i]) <= 0) --k;
+            hull[k++] = pts[i];
+        }
+        const size_t nh = k > 1 ? k - 1 : 0;                            // counter-clockwise, closed
+        std::vector<double> out;
+        int n_edges = 0;
+        if (nh >= 3 && nh <= 1024) {
+            for (size_t i = 0; i < nh; ++i) {
+                const auto &p0 = hull[i], &p1 = hull[(i + 1) % nh];
+                const double ex = p1.first - p0.first, ey = p1.second - p0.second, len = std::sqrt(ex * ex + ey * ey);
+                if (!(len > 0)) continue;
+                out.insert(out.end(), {p0.first, p0.second, ey / len, -ex / len});      // outward of a CCW polygon
+                ++n_edges;
+            }
+            // every projected corner must lie on the inner side (the test below trusts that)
+            for (const auto &q : pts)
+                for (int e = 0; e < n_edges; ++e)
+                    if (out[4 * e + 2] * (q.first - out[4 * e]) + out[4 * e + 3] * (q.second - out[4 * e + 1]) > 1e-9) n_edges = -1 - n_edges;
+            if (n_edges < 0) n_edges = 0;
+        }
+        d.n_outline = n_edges;
+        d.slab_lo = zlo;
+        d.slab_hi = zhi;
+        out.resize((size_t)((n_edges + 63) / 64 + 1) * 64 * 4, 0.0);    // pads: zero normal, never separating
+        UP(outline, out.data(), out.size());
+    }
     d.n_start = t->n_start;
     if (d.n_start <= 0) return fail(PRL_E_INVALID, "part has no start points");
     UP(start_pos, t->start_pos, (size_t)d.n_start * 3);

@@ -21,6 +21,14 @@ namespace {
 #define PRL_WALK_STEPS 8
 #endif
 constexpr int CONE_WALK_STEPS = PRL_WALK_STEPS;
+#ifndef PRL_CONE_JOINT_FROM
+#define PRL_CONE_JOINT_FROM 5
+#endif
+constexpr int CONE_JOINT_FROM = PRL_CONE_JOINT_FROM;
+#ifndef PRL_CONE_FAR_K0
+#define PRL_CONE_FAR_K0 4
+#endif
+constexpr int CONE_FAR_K0 = PRL_CONE_FAR_K0;             // first widening (fine cells) of the shared far scan     // more stragglers than this in a trip: searched together
 #define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
 
 // One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0): Moller-Trumbore on
@@ -159,10 +167,41 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     hit[0] = pos[0] + t * d0;
     hit[1] = pos[1] + t * d1;
     hit[2] = pos[2] + t * d2;
+    // Beams beside the part.  The collision set lies inside the slab [slab_lo, slab_hi] of the third axis and, projected
+    // to the principal plane, inside its outline polygon: if the stretch of the beam inside the slab (widened by the
+    // margin) lies, projected, more than the margin outside one edge of the outline, the beam misses every triangle.
+    if (P.n_outline > 0 && ballot64(state == 3) != 0) {
+        const double oz = sel3(pos[0], pos[1], pos[2], P.a0), dz = sel3(d0, d1, d2, P.a0);
+        const double lo = P.slab_lo - CONE_MISS_MARGIN, hi = P.slab_hi + CONE_MISS_MARGIN;
+        double ta = 0.0, tb = 1.0;
+        bool clear = false;                                   // never inside the slab
+        if (dz != 0.0) {
+            const double t0 = (lo - oz) / dz, t1 = (hi - oz) / dz;
+            ta = fmax(0.0, fmin(t0, t1) - 1e-9);
+            tb = fmin(1.0, fmax(t0, t1) + 1e-9);
+            clear = ta > tb;
+        } else {
+            clear = oz < lo || oz > hi;
+        }
+        const double o1 = sel3(pos[0], pos[1], pos[2], P.a1), o2 = sel3(pos[0], pos[1], pos[2], P.a2);
+        const double e1 = sel3(d0, d1, d2, P.a1), e2 = sel3(d0, d1, d2, P.a2);
+        const double ax = o1 + ta * e1, ay = o2 + ta * e2, bx = o1 + tb * e1, by = o2 + tb * e2;
+        const f64x2 GAS *ol = reinterpret_cast<const f64x2 GAS *>(P.outline);
+        for (int base = 0; base < P.n_outline && ballot64(state == 3 && !clear) != 0; base += 64) {
+            const f64x2 pq = ldg(ol, 2 * (base + lane)), nq = ldg(ol, 2 * (base + lane) + 1);
+            const int ne = P.n_outline - base < 64 ? P.n_outline - base : 64;
+            for (int j = 0; j < ne; ++j) {
+                const double px = bcast_d(pq.x, j), py = bcast_d(pq.y, j), nx = bcast_d(nq.x, j), ny = bcast_d(nq.y, j);
+                const double sa = nx * (ax - px) + ny * (ay - py), sb = nx * (bx - px) + ny * (by - py);
+                clear = clear || (sa > CONE_MISS_MARGIN && sb > CONE_MISS_MARGIN);
+            }
+        }
+        if (state == 3 && clear) state = 2;
+    }
     // the stragglers (edge and vertex hits, and every miss), together
     const uint64_t todo = ballot64(state == 3);
     WCNT16(0, __popcll(todo));
-    if (todo) {
+    if (__popcll(todo) > CONE_JOINT_FROM) {
         double tw;
         int tri;
         rays_general_lanes(P, pos, dst, state == 3, tw, tri);
@@ -171,6 +210,22 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
             hit[0] = pos[0] + tw * d0;
             hit[1] = pos[1] + tw * d1;
             hit[2] = pos[2] + tw * d2;
+        }
+    } else {                                        // a few: one wave-wide search each is cheaper than the joint loop
+        uint64_t left = todo;
+        int wide_hint = hint;
+        while (left) {
+            const int L = __builtin_ctzll(left);
+            left &= left - 1;
+            const double e3[3] = {bcast_d(dst[0], L), bcast_d(dst[1], L), bcast_d(dst[2], L)};
+            double tw, hw[3];
+            const int idx = ray_closest_wave(P, pos, e3, lane, tw, hw, wide_hint, cand_lds);
+            if (lane == L) {
+                state = idx >= 0 ? 1 : 2;
+                hit[0] = hw[0];
+                hit[1] = hw[1];
+                hit[2] = hw[2];
+            }
         }
     }
     STAMP(PH_BARY);
@@ -234,6 +289,65 @@ __device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
     if (want) result = -2;
 #endif
     return result;
+}
+
+// ---------------------------------------------------------------- nearest samples of points FAR from the sampled surface
+// Where the collision hull spans a recess of the part, every hit of a shot lies centimetres above the samples: three
+// rings of the fine grid do not settle any of them, and a wave-wide search per hit (4 us each, ~520 a step) made such
+// an env five times slower than the rest -- and the launch waits for it.  Here the needy lanes share one scan: the block
+// of fine cells around ALL their points, widened by `k` cells, is read once (64 records at a time, one per lane, handed
+// round by lane broadcast) and every needy lane measures every record against its own point.  A lane whose cell is at
+// least r cells inside the block (a block side on the grid's own border counts as infinitely far) has seen every sample
+// closer than r cells: its best is exact once within r * 0.99 * cell.  k = 4, 8, 16 (measured: 664 steps/s; from 8: 641; from 6: 340), then the wave-wide search.
+// (Tried: a small first block whose best distance sizes the second -- slower, 468 vs 696 steps/s: over a hole in the
+// part the bound is loose and the sized block larger than the one doubling reaches.)
+__device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, const double pt[3], int lane, int &sidx) {
+    const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
+    const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
+    const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
+    for (int k = CONE_FAR_K0; k <= 4 * CONE_FAR_K0; k *= 2) {
+        const bool need = sidx == -2;
+        if (ballot64(need) == 0) return;
+        const int ccx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), ccy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
+        int bx0 = wave_min_i(need ? ccx : 0x7fffffff) - k, bx1 = -wave_min_i(need ? -ccx : 0x7fffffff) + k;
+        int by0 = wave_min_i(need ? ccy : 0x7fffffff) - k, by1 = -wave_min_i(need ? -ccy : 0x7fffffff) + k;
+        const bool open_x0 = bx0 <= 0, open_x1 = bx1 >= P.fg_nx - 1, open_y0 = by0 <= 0, open_y1 = by1 >= P.fg_ny - 1;
+        bx0 = bx0 < 0 ? 0 : bx0;
+        by0 = by0 < 0 ? 0 : by0;
+        bx1 = bx1 > P.fg_nx - 1 ? P.fg_nx - 1 : bx1;
+        by1 = by1 > P.fg_ny - 1 ? P.fg_ny - 1 : by1;
+        double best_d = INFINITY;
+        int best_rank = 0x7fffffff, best_pos = -1;
+        for (int cy = by0; cy <= by1; ++cy) {                                   // wave-uniform loops
+            const int b = P.fg_start[cy * P.fg_nx + bx0], e = P.fg_start[cy * P.fg_nx + bx1 + 1];
+            for (int i0 = b; i0 < e; i0 += 64) {
+                const int i = i0 + lane < e ? i0 + lane : e - 1;
+                const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
+                const int n = e - i0 < 64 ? e - i0 : 64;
+                for (int j = 0; j < n; ++j) {
+                    const double x = bcast_d(ra.x, j), y = bcast_d(ra.y, j), z = bcast_d(rb.x, j);
+                    const int rk = __builtin_amdgcn_readlane(__double2loint(rb.y), j);
+                    const int ps = __builtin_amdgcn_readlane(__double2hiint(rb.y), j);
+                    const double dx = x - pt[0], dy = y - pt[1], dz = z - pt[2];
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        best_d = dd;
+                        best_rank = rk;
+                        best_pos = ps;
+                    }
+                }
+            }
+        }
+        // cells between this lane's (clamped) cell and the nearest CLOSED side of the block
+        int r = 0x7fffffff;
+        if (!open_x0) r = ccx - bx0 < r ? ccx - bx0 : r;
+        if (!open_x1) r = bx1 - ccx < r ? bx1 - ccx : r;
+        if (!open_y0) r = ccy - by0 < r ? ccy - by0 : r;
+        if (!open_y1) r = by1 - ccy < r ? by1 - ccy : r;
+        // (a point outside the grid is farther from every sample beyond the block than its clamped cell is)
+        const double lim = (r == 0x7fffffff ? 1.0e30 : (double)r * P.fg_accept);
+        if (need && best_pos >= 0 && best_d <= lim * lim) sidx = best_pos;
+    }
 }
 
 }  // namespace

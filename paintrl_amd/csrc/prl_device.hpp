@@ -59,6 +59,11 @@ struct PartDev {
     int fg_nx, fg_ny;
     gint_p fg_start;              // [fg_nx * fg_ny + 1]
     gdouble_p fg_rec;             // [n_samples][4]
+    // outline of the collision set in the principal plane (convex polygon, derived in part_fill) and its extent along
+    // the third axis: a beam whose stretch inside that slab projects outside the outline misses the part (prl_cone.hpp)
+    int n_outline;                // edges, 0 = no test; the table is padded to a multiple of 64 rows
+    gdouble_p outline;            // [n_outline_pad][4]: a point of the edge (axis a1, a2), its outward unit normal
+    double slab_lo, slab_hi;      // collision vertices' range on axis a0
     gfloat_p samp_f32;            // [n_samples_pad][4]: x y z 0 rounded to float (derived): the paint pre-filter
     double samp_absmax;           // largest |coordinate| of a real sample: bounds the pre-filter's rounding error
     double sg_o1, sg_o2, sg_inv;

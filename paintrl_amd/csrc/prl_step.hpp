@@ -200,6 +200,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
                 // go through the wave-wide search.  Bits are collected in this wave's LDS mask row.
                 int sidx = nearest_sample_lane(P, bh, hit);
                 STAMP(PH_BALL);
+                if (__popcll(ballot64(sidx == -2)) > 3) nearest_samples_shared(P, bh, lane, sidx);   // (a recess: prl_cone.hpp)
                 uint64_t rest = ballot64(sidx == -2);
                 WCNT16(1, __popcll(rest));
                 WCNT16(3, __popcll(hm));

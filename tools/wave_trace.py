@@ -81,6 +81,13 @@ def main():
         print('slowest waves: life us | 8-bit counters %s | 16-bit (stragglers, nearest fallbacks, past ring 1, hits)' % SLOTS)
         for i in top:
             print('   %7.1f | %s | %s' % (flat_life[i], c8[i].tolist(), c16f[i].tolist()))
+        X2 = np.concatenate([np.ones((flat_life.size, 1)), c16f.astype(float), c8[:, 3:4].astype(float)], axis=1)
+        cf, *_ = np.linalg.lstsq(X2, flat_life, rcond=None)
+        print('least squares: life = %.1f %+.2f*stragglers %+.2f*fallbacks %+.2f*ring>1 %+.2f*hits %+.2f*vertex_ring_trips' % tuple(cf))
+        for lo, hi in ((0, 1), (1, 200), (200, 400), (400, 519), (519, 521)):
+            m = (c16f[:, 3] >= lo) & (c16f[:, 3] < hi)
+            if m.any():
+                print('   hits in [%d, %d): %.1f %% of the waves, life mean %.1f us, p99 %.1f' % (lo, hi, 100 * m.mean(), flat_life[m].mean(), np.percentile(flat_life[m], 99)))
     span = end.max(axis=1)
     print('launch span (first wave start -> last wave end): mean %.1f us, min %.1f, max %.1f' % (span.mean(), span.min(), span.max()))
     print('wave start offset: mean %.2f us, 99%% %.2f, max %.2f' % (start.mean(), np.percentile(start, 99), start.max()))
