@@ -125,12 +125,13 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // One launch = one batched step: one wavefront per env, STEP_WAVES envs per workgroup (prl_step.hpp holds the step).
-template <int KW, bool NORMAL, bool GENSEC, bool HSI = false, bool KD = false>
-__global__ __launch_bounds__(64 * (NORMAL ? CONE_WAVES : STEP_WAVES), 4) void step_kernel(StepArgs) {
+template <int KW, bool NORMAL, bool GENSEC, bool HSI = false, bool KD = false, int WAVES = STEP_WAVES_NARROW>
+__global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * (NORMAL ? CONE_WAVES : STEP_WAVES) + (threadIdx.x >> 6));
+    static_assert(!NORMAL || WAVES == CONE_WAVES, "cone beams: four waves per workgroup (LDS mask rows)");
+    const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     const WaveLds wl = wave_lds<GENSEC, KD, NORMAL>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
@@ -612,6 +613,7 @@ struct PrlBatch {
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
+    int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
     int timing_every = 0;          // 0 = off; k = HIP events around every k-th step launch
     long long launch_no = 0;
@@ -999,18 +1001,28 @@ int check_config(const PrlConfig *c) {
     return PRL_OK;
 }
 
+template <int KW, int WAVES>
+void launch_step_w(const StepArgs &a, bool gensec, bool hsi, bool kd, hipStream_t s) {
+    const dim3 grid((a.n_envs + WAVES - 1) / WAVES), block(64 * WAVES);
+    if (kd && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, true, WAVES>), grid, block, 0, s, a);
+    else if (kd) hipLaunchKernelGGL((step_kernel<KW, false, false, false, true, WAVES>), grid, block, 0, s, a);
+    else if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true, false, WAVES>), grid, block, 0, s, a);
+    else if (hsi) hipLaunchKernelGGL((step_kernel<KW, false, false, true, false, WAVES>), grid, block, 0, s, a);
+    else if (gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, false, WAVES>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<KW, false, false, false, false, WAVES>), grid, block, 0, s, a);
+}
+
 template <int KW>
-void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, bool kd, hipStream_t s) {
-    const int waves = normal ? CONE_WAVES : STEP_WAVES;
-    const dim3 grid((a.n_envs + waves - 1) / waves), block(64 * waves);
-    if (kd && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, true>), grid, block, 0, s, a);
-    else if (kd) hipLaunchKernelGGL((step_kernel<KW, false, false, false, true>), grid, block, 0, s, a);
-    else if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true>), grid, block, 0, s, a);
-    else if (hsi) hipLaunchKernelGGL((step_kernel<KW, false, false, true>), grid, block, 0, s, a);
-    else if (normal && gensec) hipLaunchKernelGGL((step_kernel<KW, true, true>), grid, block, 0, s, a);
-    else if (normal) hipLaunchKernelGGL((step_kernel<KW, true, false>), grid, block, 0, s, a);
-    else if (gensec) hipLaunchKernelGGL((step_kernel<KW, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<KW, false, false>), grid, block, 0, s, a);
+void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, bool kd, bool wide, hipStream_t s) {
+    if (normal) {
+        const dim3 grid((a.n_envs + CONE_WAVES - 1) / CONE_WAVES), block(64 * CONE_WAVES);
+        if (gensec) hipLaunchKernelGGL((step_kernel<KW, true, true, false, false, CONE_WAVES>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((step_kernel<KW, true, false, false, false, CONE_WAVES>), grid, block, 0, s, a);
+    } else if (wide) {
+        launch_step_w<KW, STEP_WAVES_WIDE>(a, gensec, hsi, kd, s);
+    } else {
+        launch_step_w<KW, STEP_WAVES_NARROW>(a, gensec, hsi, kd, s);
+    }
 }
 
 template <int KW>
@@ -1168,6 +1180,10 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
                     64 * 64 * KW_MAX, words);
     }
     hipError_t e = hipSetDevice(b->device);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device) == hipSuccess) b->resident_envs = 16 * cus;
+    }
     std::vector<PartDev> pd(n_parts);
     const int od = obs_dim_of(cfg->obs_mode, cfg->obs_grad);
     b->reset_obs.assign(n_parts, nullptr);
@@ -1315,11 +1331,12 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         }
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
+    const bool wide = b->n_envs <= b->resident_envs;
     switch (b->kw) {
-    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
-    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
-    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
-    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, b->kd, s); break;
+    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
+    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
+    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
+    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
     default: {                                     // a part with more than 16 384 samples: masks in LDS
         const bool gs = general_section(b->cfg);
         const int rc = launch_big(b->kd ? (gs ? step_kernel_big<true, true> : step_kernel_big<false, true>)

@@ -6,13 +6,12 @@
 namespace {
 
 
-#ifndef PRL_STEP_WAVES
-#define PRL_STEP_WAVES 8                         // envs (= waves) per workgroup of step_kernel: 4 / 8 / 16 measured
-                                                 // 41.8 / 41.05 / 41.0 us (fewer workgroups to dispatch); cone beams: 4
-#endif
-constexpr int STEP_WAVES = PRL_STEP_WAVES;
+// Envs (= waves) per workgroup of step_kernel: 8 while every workgroup of the launch is resident at once (N <= 16 waves x
+// CUs: fewer workgroups to dispatch, 41.8 -> 41.05 us at 4 096 envs), 4 beyond that (a finishing 4-wave workgroup is
+// backfilled sooner: at 8 192 envs 80.2 vs 90.2 us, at 32 768 298 vs 319); cone beams: 4.
+constexpr int STEP_WAVES_WIDE = 8, STEP_WAVES_NARROW = 4;
+constexpr int MAX_WAVES_PER_WG = STEP_WAVES_WIDE;   // per-wave LDS scratch rows
 constexpr int CONE_WAVES = 4;                    // ... of its cone-beam instantiations (8 KB of LDS mask rows per wave)
-constexpr int MAX_WAVES_PER_WG = STEP_WAVES > 4 ? STEP_WAVES : 4;   // per-wave LDS scratch rows
 constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples in registers
 constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3 copies x 4 waves x 1600 x 8 B = 150 KB of 160 KB
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
