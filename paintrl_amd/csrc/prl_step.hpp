@@ -84,6 +84,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
     // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
     constexpr bool BIG = KW == 0;
+    PRIO_YOUNG_DECL();
     static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in 64-word-per-slot LDS rows: small parts only");
     static_assert(!(HSI && (BIG || NORMAL)), "thickness mode is built for ball-query painting of small parts");
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
@@ -129,12 +130,13 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
 #else
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
 #endif
-        // Issue priority by progress (s_setprio 3: shots 0-1, 2: shots 2-4, 1: painting, 0: observation).  The SIMD's
+        // Issue priority by progress (s_setprio 3: shots 0-1, 2: shots 2-4, 1: painting, 0: observation; the two youngest
+        // waves of a SIMD one level higher from shot 2 on).  The SIMD's
         // arbiter serves its oldest wave first: of the four envs that share a SIMD the youngest then ends 14 us after
         // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
         // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
         if (shot <= 1) PRIO_BY_PROGRESS(3);
-        else PRIO_BY_PROGRESS(2);
+        else PRIO_YOUNG_OLD(3, 2);
         // bpw:865-880 get_guided_point
         const double pt[3] = {cur_pose[0] + dvec[0], cur_pose[1] + dvec[1], cur_pose[2] + dvec[2]};
         const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
@@ -246,7 +248,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     } else {
         pose_orn_quat(cur_norm, S.quat);
     }
-    PRIO_BY_PROGRESS(1);
+    PRIO_YOUNG_OLD(2, 1);
     if constexpr (!NORMAL && !BIG) masks.template load<KW>(painted, last);
     STAMP(PH_LOAD);
     // bpw:568-577 fast_paint + _paint for the five shots
@@ -313,7 +315,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     if (!dn) S.total_return += actual;
     STAMP(PH_APPLY);
 
-    PRIO_BY_PROGRESS(0);
+    PRIO_YOUNG_OLD(1, 0);
     const bool do_reset = dn && C.auto_reset;
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
     double *obs_row = a.obs() + (size_t)env * od;
