@@ -7,8 +7,10 @@
 //   PRL_CUT=<1|2|4|5|6>       instruction-count builds: no observation / nor painting / nor hook point / nor ray / no
 //                              shots at all (wrong results;
 //                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
-//   PRL_NO_PRIO                no s_setprio by progress (A/B of the issue-priority scheme, prl_step.hpp)
-//   PRL_FRAG_TIMING            rollout-fragment kernel: time in policy / env step / barrier wait (tools/fragment_timing.py)
+//   PRL_NO_PRIO, PRL_PRIO_SLOT=<s>  no s_setprio by progress / youngest-wave bias from hardware slot s (prl_step.hpp)
+//   PRL_OLD_BALLOT             HIP's __ballot instead of the builtin (prl_device.hpp)
+//   PRL_WALK_STEPS, PRL_CONE_JOINT_FROM, PRL_CONE_FAR_K0   tuning constants of the cone-beam painter (prl_cone.hpp)
+//   PRL_FRAG_TIMING            policy phase of act_step_kernel per barrier, rollout kernels' phases (tools/fragment_timing.py)
 //   PRL_PAINT_ONE_ROW_PER_TRIP one sample-grid row per trip of the painter (multi-trip path)   } the general paths,
 //   PRL_FORCE_FULL_SCANS       whole-table scans instead of the ring searches                } run by the forced-
 //   PRL_FORCE_GENERAL_RAY      general two-stage ray search instead of the convex fast path  } path parity tests
