@@ -28,7 +28,8 @@ constexpr int CONE_JOINT_FROM = PRL_CONE_JOINT_FROM;
 #ifndef PRL_CONE_FAR_K0
 #define PRL_CONE_FAR_K0 4
 #endif
-constexpr int CONE_FAR_K0 = PRL_CONE_FAR_K0;             // first widening (fine cells) of the shared far scan     // more stragglers than this in a trip: searched together
+constexpr int CONE_FAR_K0 = PRL_CONE_FAR_K0;
+#define FAR_BAND 4.0e-6f              // m^2, see nearest_samples_shared             // first widening (fine cells) of the shared far scan     // more stragglers than this in a trip: searched together
 #define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
 
 // One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0): Moller-Trumbore on
@@ -318,13 +319,23 @@ __device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, cons
         by1 = by1 > P.fg_ny - 1 ? P.fg_ny - 1 : by1;
         double best_d = INFINITY;
         int best_rank = 0x7fffffff, best_pos = -1;
+        // float pre-test: a record is measured in float64 only if, in float, it comes within FAR_BAND of some needy lane's
+        // best so far.  Coordinates are below 2 m and differences below 1 m here, so a float squared distance is within
+        // 1e-6 m^2 of the exact one (rounding the six coordinates: 6 x 1.2e-7 x 2 x 1; the arithmetic: 1e-7): a record
+        // the test drops is farther than the lane's best and could neither replace nor tie it.
+        const float pfx = (float)pt[0], pfy = (float)pt[1], pfz = (float)pt[2];
+        float bestf = INFINITY;                                                  // >= best_d
         for (int cy = by0; cy <= by1; ++cy) {                                   // wave-uniform loops
             const int b = P.fg_start[cy * P.fg_nx + bx0], e = P.fg_start[cy * P.fg_nx + bx1 + 1];
             for (int i0 = b; i0 < e; i0 += 64) {
                 const int i = i0 + lane < e ? i0 + lane : e - 1;
                 const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
+                const float fx = (float)ra.x, fy = (float)ra.y, fz = (float)rb.x;
                 const int n = e - i0 < 64 ? e - i0 : 64;
                 for (int j = 0; j < n; ++j) {
+                    const float ex = bcast_f(fx, j) - pfx, ey = bcast_f(fy, j) - pfy, ez = bcast_f(fz, j) - pfz;
+                    const float ddf = ex * ex + ey * ey + ez * ez;
+                    if (ballot64(need && ddf <= bestf + FAR_BAND) == 0) continue;
                     const double x = bcast_d(ra.x, j), y = bcast_d(ra.y, j), z = bcast_d(rb.x, j);
                     const int rk = __builtin_amdgcn_readlane(__double2loint(rb.y), j);
                     const int ps = __builtin_amdgcn_readlane(__double2hiint(rb.y), j);
@@ -334,6 +345,7 @@ __device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, cons
                         best_d = dd;
                         best_rank = rk;
                         best_pos = ps;
+                        bestf = nextafterf((float)dd, INFINITY);
                     }
                 }
             }
