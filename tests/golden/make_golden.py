@@ -60,8 +60,12 @@ class RefDriver(object):
         self.part_no = part_no
 
     def configure(self, obs_mode='section', obs_grad=4, start_mode='anchor', overlap=False, turning=False,
-                  termination='late', paint_method='fast', action=('discrete', 1, 4), max_len=245, rollout=False):
+                  termination='late', paint_method='fast', action=('discrete', 1, 4), max_len=245, rollout=False,
+                  max_points=None):
         env, part, bpw = self.env, self.part, self.bpw
+        if not hasattr(self, 'part_max_points'):
+            self.part_max_points = env._max_possible_point           # Part_Dict constant (rge:106-117)
+        env._max_possible_point = self.part_max_points if max_points is None else max_points
         cls = self.rge.PaintGymEnv
         cls.OBS_MODE, cls.OBS_GRAD = obs_mode, obs_grad
         mode, shape, gran = action
@@ -266,6 +270,41 @@ def param_test_golden(pte):
     return out
 
 
+def main_termination():
+    """Episodes that end through each branch of _termination (rge:289-304) the other fixtures never reach: the step
+    limit (``_step_counter > EPISODE_MAX_LENGTH - 1``) and ``finished`` (``_total_reward * 100 >= _max_possible_point``).
+    Written to episodes_door_term.npz / episodes_sheet_term.npz; nothing else is touched."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    ref_import.load_reference('hull')
+    door = RefDriver(root, 0)
+    eps = {}
+    door.configure('section', 4, 'anchor', max_len=30)
+    eps['t1_max_len30'] = door.episode(7, zigzag_policy_grid(), max_steps=100, want_idx=0)
+    door.configure('grid', 4, 'anchor', overlap=True, max_len=17)
+    eps['t1_max_len17_grid'] = door.episode(8, zigzag_policy_grid(), max_steps=100, want_idx=0)
+    door.configure('section', 4, 'anchor', max_points=600)
+    eps['t2_finished600'] = door.episode(9, zigzag_policy_grid(), max_steps=245, want_idx=0)
+    door.configure('grid', 4, 'anchor', overlap=True, turning=True, max_points=3000)
+    eps['t2_finished3000_grid'] = door.episode(10, zigzag_policy_grid(), max_steps=245, want_idx=0)
+    door.configure('section', 4, 'anchor', termination='hybrid', max_points=1500)
+    eps['t2_finished1500_hybrid'] = door.episode(11, zigzag_policy_grid(), max_steps=245, want_idx=0)
+    save_episodes('door_term', eps)
+    for name, ep in eps.items():
+        assert bool(ep['done'][-1]), name
+    assert len(eps['t1_max_len30']['actions']) == 30 and len(eps['t1_max_len17_grid']['actions']) == 17
+    door.env.close()
+    sheet = RefDriver(root, 1)
+    eps = {}
+    sheet.configure('simple', 4, 'fixed', rollout=True)
+    eps['t3_full245'] = sheet.episode(0, zigzag_policy(1, 1), max_steps=300)      # one column per pass: 245 steps
+    sheet.configure('section', 4, 'fixed', max_points=9000)
+    eps['t2_finished9000'] = sheet.episode(0, zigzag_policy(-1, 2), max_steps=300)
+    save_episodes('sheet_term', eps)
+    assert len(eps['t3_full245']['actions']) == 245 and bool(eps['t3_full245']['done'][-1])
+    assert bool(eps['t2_finished9000']['done'][-1]) and len(eps['t2_finished9000']['actions']) < 245
+
+
 def main():
     root = os.path.join(HERE, '_synth_root')
     synth_parts.write_synthetic_parts(root)
@@ -369,4 +408,7 @@ def save_episodes(tag, eps):
 
 
 if __name__ == '__main__':
-    main()
+    if '--termination' in sys.argv:
+        main_termination()
+    else:
+        main()

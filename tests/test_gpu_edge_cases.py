@@ -179,6 +179,82 @@ def test_full_size_round_trip_properties():
     env2.close()
 
 
+def test_config4_total_size_in_one_launch():
+    """32 768 envs (BASELINE config 4's total) as ONE launch on one GPU -- the four-envs-per-workgroup shape
+    prl_batch_step picks beyond 16 waves per CU: the size-independent properties at full size, a 4 096-env slice
+    against the oracle on every output and painted bit, and the rest of the batch against that slice (env e and
+    env e mod 4 096 share start and actions)."""
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n, m, steps = 32768, 4096, 4
+    env = _env(tables, n, sp)
+    orc = oracle.Oracle(tables, m, start_points=sp, threads=8)
+    rng = np.random.RandomState(99)
+    start = rng.randint(0, len(sp), size=m)
+    obs = env.reset(start_idx=np.tile(start, n // m)).cpu().numpy()
+    assert np.array_equal(obs[:m], orc.reset(start))
+    cov = np.zeros(n, dtype=np.int64)
+    for k in range(steps):
+        a = rng.randint(0, 4, size=m)
+        o, r, d, i = env.step(np.tile(a, n // m))
+        o, r, d, i = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), i.cpu().numpy()
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o[:m], oo) and np.array_equal(r[:m], rr), 'step %d' % k
+        assert np.array_equal(d[:m], dd) and np.array_equal(i[:m], ii), 'step %d' % k
+        for blk in range(1, n // m):                       # every other 4 096-env block repeats the first
+            sl = slice(blk * m, (blk + 1) * m)
+            assert np.array_equal(o[sl], o[:m]) and np.array_equal(r[sl], r[:m]) and np.array_equal(d[sl], d[:m])
+        words = env.painted_words().cpu().numpy().view(np.uint64)
+        new_cov = np.unpackbits(words.view(np.uint8), axis=1).sum(1)
+        assert (new_cov >= cov).all()
+        assert np.array_equal(np.rint(i[:, 0] * 100).astype(np.int64), new_cov - cov)
+        assert np.array_equal(r, i[:, 0] - i[:, 1]) and (i[:, 1] == 0.2).all()
+        cov = new_cov
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = env.parts[0].mask_to_canonical(words[:m])
+    assert np.array_equal(bits, np.stack([orc.painted_bits(e) for e in range(m)]))
+    assert np.array_equal(words.reshape(n // m, m, -1), np.broadcast_to(words[:m], (n // m, m, words.shape[1])))
+    env.close()
+
+
+def test_vector_env_names():
+    """RLlib VectorEnv-style entry points: vector_reset / reset_at / vector_step against the oracle."""
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'anchor')
+    n = 37
+    env = _env(tables, n, sp)
+    orc = oracle.Oracle(tables, n, start_points=sp)
+    obs = env.vector_reset().cpu().numpy().copy()
+    cand = [orc.reset(np.full(n, s, dtype=np.int32))[0] for s in range(len(sp))]
+    start = np.array([next(s for s in range(len(sp)) if np.array_equal(cand[s], obs[e])) for e in range(n)])
+    assert np.array_equal(orc.reset(start), obs)          # the library's own draws, identified by their observations
+    rng = np.random.RandomState(3)
+    for k in range(6):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.vector_step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr)
+        assert np.array_equal(d.cpu().numpy(), dd) and np.array_equal(i.cpu().numpy(), ii)
+    # reset_at: one env back to a chosen start point, every other env untouched
+    before = env.painted_words().cpu().numpy().copy()
+    st_before = env.state()
+    row = env.reset_at(5, start_idx=2).cpu().numpy()
+    mask = np.zeros(n, dtype=bool)
+    mask[5] = True
+    want = orc.reset(np.full(n, 2, dtype=np.int32), mask=mask)
+    assert np.array_equal(row, want[5])
+    after = env.painted_words().cpu().numpy()
+    assert not after[5].any() and np.array_equal(np.delete(after, 5, 0), np.delete(before, 5, 0))
+    st = env.state()
+    assert st['step_counter'][5] == 0 and np.array_equal(np.delete(st['step_counter'], 5), np.delete(st_before['step_counter'], 5))
+    for k in range(4):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.vector_step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr) and np.array_equal(d.cpu().numpy(), dd)
+    env.close()
+
+
 def test_full_size_batch_equals_oracle():
     """The BASELINE batch (4096 envs, 'all' start points) against the oracle for a few steps: every
     observation, reward, done flag and painted bit."""

@@ -41,10 +41,13 @@ def test_rollout_fragment_and_ppo_step():
     env.close()
 
 
-def test_rollout_buffers_replay_through_the_oracle():
+@pytest.mark.parametrize('mode,n,T', [('two_launches', 96, 25), ('persistent', 4096, 24), ('act_step', 4096, 20)])
+def test_rollout_buffers_replay_through_the_oracle(mode, n, T):
     """The kernels write straight into rows of the worker's trajectory buffers; replaying the recorded actions
     through the CPU oracle must give the recorded observations, rewards, done flags and info, row by row, until
-    an env's first episode end (after it the env restarts from a start point drawn by the library's RNG)."""
+    an env's first episode end (after it the env restarts from a start point drawn by the library's RNG).
+    'persistent' / 'act_step' at 4096 envs: BASELINE config 4's per-GPU share -- the policy-driven fragment as ONE
+    launch (prl_rollout_fragment with weights) and as one launch per step (prl_batch_act_step)."""
     import torch
     import oracle
     from conftest import synthetic_tables
@@ -52,11 +55,10 @@ def test_rollout_buffers_replay_through_the_oracle():
     from paintrl_amd.device_tables import DeviceTables
     from paintrl_amd.rollout import MLPPolicy, RolloutWorker
     tables = synthetic_tables('door_test')
-    n, T = 96, 25
     env = BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=11)
     torch.manual_seed(3)
     policy = MLPPolicy(env.obs_dim, 4).to(env.device)
-    worker = RolloutWorker(env, policy, fragment=T, seed=5)
+    worker = RolloutWorker(env, policy, fragment=T, seed=5, persistent=mode == 'persistent', act_step=mode == 'act_step')
     start_obs = worker.raw['obs'][0].cpu().numpy().copy()
     batch, _, _ = worker.collect()
     torch.cuda.synchronize()
@@ -64,7 +66,7 @@ def test_rollout_buffers_replay_through_the_oracle():
     raw = {k: v.cpu().numpy() for k, v in worker.raw.items()}
     raw['obs'] = np.concatenate([start_obs[None], raw['obs'][1:]])     # row 0 already holds the next fragment's start
     # which start point did the library draw for each env?  (reset observations identify it)
-    orc = oracle.Oracle(tables, n)
+    orc = oracle.Oracle(tables, n, threads=8)
     n_start = orc.n_start
     cand = [orc.reset(np.full(n, s, dtype=np.int32))[0] for s in range(n_start)]
     start = np.array([next(s for s in range(n_start) if np.array_equal(cand[s], start_obs[e])) for e in range(n)])
