@@ -1,21 +1,34 @@
 """Builds the HIP shared library in-tree (paintrl_amd/libpaintrl_hip.so) with hipcc for gfx950.
 
--ffp-contract=off is part of the numerical contract: the only fused multiply-adds
-are the explicit ones that restate numpy.dot (see csrc/paintrl_hip.hip header).
+The library is several translation units compiled side by side (csrc/prl_launch.hpp): the host side of the C ABI,
+the policy, the large-part kernels, and three kernel units compiled once per mask width (-DPRL_KW=1..4).  Objects go
+to paintrl_amd/_obj/<build name>/ and are rebuilt when a file they include changed (hipcc -MD dependency files).
+
+-ffp-contract=off is part of the numerical contract: the only fused multiply-adds are the explicit ones that restate
+numpy.dot (see csrc/prl_all.hpp).
 """
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
-CSRC = os.path.join(_HERE, 'csrc')                      # paintrl_hip.hip + the prl_*.hpp it includes
-SOURCE = os.path.join(CSRC, 'paintrl_hip.hip')
-POLICY_SOURCE = os.path.join(CSRC, 'policy_mlp.hip')    # rollout policy (prl_policy_act), same library
+CSRC = os.path.join(_HERE, 'csrc')                      # *.hip units + the prl_*.hpp device headers they include
+SOURCE = os.path.join(CSRC, 'paintrl_hip.hip')          # host side of the C ABI
+POLICY_SOURCE = os.path.join(CSRC, 'policy_mlp.hip')    # rollout policy (prl_policy_act)
 HEADER = os.path.join(_REPO, 'include', 'paintrl.h')
 # PAINTRL_LIB points the binding at another build of the same source (diagnostic builds of tools/)
 LIBRARY = os.environ.get('PAINTRL_LIB') or os.path.join(_HERE, 'libpaintrl_hip.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-shared', '-std=c++17']
+CFLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17']
+FLAGS = CFLAGS + ['-shared']
+JOBS = int(os.environ.get('PAINTRL_BUILD_JOBS', '0')) or min(8, os.cpu_count() or 1)
+
+# (object name, source file, extra flags)
+UNITS = [('host', 'paintrl_hip.hip', []), ('policy', 'policy_mlp.hip', []), ('k_big', 'k_big.hip', [])]
+for _kw in (1, 2, 3, 4):
+    UNITS += [('k_step%d' % _kw, 'k_step.hip', ['-DPRL_KW=%d' % _kw]), ('k_cone%d' % _kw, 'k_cone.hip', ['-DPRL_KW=%d' % _kw]),
+              ('k_rollout%d' % _kw, 'k_rollout.hip', ['-DPRL_KW=%d' % _kw])]
 
 
 def hipcc():
@@ -25,23 +38,93 @@ def hipcc():
     return exe
 
 
+def _deps(depfile):
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    out = []
+    for tok in text.replace('\\\n', ' ').split():
+        if not tok.endswith(':') and (tok.startswith(CSRC) or tok.startswith(os.path.join(_REPO, 'include'))):
+            out.append(tok)
+    return out
+
+
+def _unit_stale(obj, src, flags_line):
+    if not os.path.isfile(obj):
+        return True
+    try:
+        if open(obj + '.flags').read() != flags_line:
+            return True
+    except OSError:
+        return True
+    deps = _deps(obj + '.d')
+    if deps is None:
+        return True
+    built = os.path.getmtime(obj)
+    return any((not os.path.isfile(p)) or os.path.getmtime(p) > built for p in deps + [src])
+
+
+def _compile(name, src_file, unit_flags, extra, obj_dir, force, verbose):
+    src = os.path.join(CSRC, src_file)
+    obj = os.path.join(obj_dir, name + '.o')
+    cmd = [hipcc()] + CFLAGS + list(unit_flags) + list(extra) + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, '-MD', '-MF',
+                                                                 obj + '.d', '-c', src, '-o', obj]
+    line = ' '.join(cmd)
+    if not force and not _unit_stale(obj, src, line):
+        return obj
+    if verbose:
+        print(line, flush=True)
+    subprocess.check_call(cmd)
+    with open(obj + '.flags', 'w') as f:
+        f.write(line)
+    return obj
+
+
+def build_named(name, out, extra=(), force=False, verbose=False, diag_unit=None, only=None):
+    """Compile every unit (objects under _obj/<name>/) with the ``extra`` flags and link them into ``out``.
+    ``diag_unit``: object name (e.g. 'k_step3') that additionally gets -DPRL_DIAG_EXPORT (csrc/prl_diag_export.hpp).
+    ``only``: compile just these object names (development: the link then needs the others to exist already)."""
+    obj_dir = os.path.join(_HERE, '_obj', name)
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = []
+    with ThreadPoolExecutor(max_workers=JOBS) as pool:
+        for uname, src_file, uflags in UNITS:
+            if only and uname not in only:
+                continue
+            ex = list(extra) + (['-DPRL_DIAG_EXPORT'] if diag_unit == uname else [])
+            jobs.append(pool.submit(_compile, uname, src_file, uflags, ex, obj_dir, force, verbose))
+        for j in jobs:
+            j.result()
+    objs = [os.path.join(obj_dir, u[0] + '.o') for u in UNITS]
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.isfile(out) or os.path.getmtime(out) < newest:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 def is_stale():
     if not os.path.isfile(LIBRARY):
         return True
-    built = os.path.getmtime(LIBRARY)
-    import glob
-    sources = [SOURCE, POLICY_SOURCE, HEADER] + glob.glob(os.path.join(CSRC, '*.hpp'))
-    return any(os.path.getmtime(p) > built for p in sources)
+    obj_dir = os.path.join(_HERE, '_obj', 'product')
+    for uname, src_file, uflags in UNITS:
+        obj = os.path.join(obj_dir, uname + '.o')
+        if not os.path.isfile(obj) or os.path.getmtime(obj) > os.path.getmtime(LIBRARY):
+            return True
+        deps = _deps(obj + '.d')
+        if deps is None or any(os.path.getmtime(p) > os.path.getmtime(obj) for p in deps + [os.path.join(CSRC, src_file)]):
+            return True
+    return False
 
 
 def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIBRARY
-    cmd = [hipcc()] + FLAGS + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, POLICY_SOURCE, '-o', LIBRARY]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return LIBRARY
+    return build_named('product', LIBRARY, force=force, verbose=verbose)
 
 
 # Diagnostic variants used by tests/test_gpu_forced_paths.py: the same sources with every fast path
@@ -56,16 +139,11 @@ def variant_path(name):
     return os.path.join(_HERE, '_variants', 'libpaintrl_hip_%s.so' % name)
 
 
-def build_variant(name, verbose=False, extra=()):
-    out = variant_path(name)
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(VARIANTS.get(name, [])) + list(extra) + \
-        ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, SOURCE, POLICY_SOURCE, '-o', out]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    return out
+def build_variant(name, verbose=False, extra=(), force=False, diag_unit=None, out=None):
+    return build_named(name, out or variant_path(name), extra=list(VARIANTS.get(name, [])) + list(extra), force=force,
+                       verbose=verbose, diag_unit=diag_unit)
 
 
 if __name__ == '__main__':
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force='--force' in sys.argv, verbose=True))

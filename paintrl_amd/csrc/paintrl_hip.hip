@@ -1,548 +1,23 @@
-// paintrl_hip.hip -- MI355X (gfx950) batched paint-coverage simulator: kernels + C ABI.
+// paintrl_hip.hip -- MI355X (gfx950) batched paint-coverage simulator: the host side of the C ABI (include/paintrl.h).
 //
-// One wavefront (64 lanes) advances one environment by one PaintGymEnv.step()
-// (PaintRLEnv/robot_gym_env.py:349-368): five dependent sub-shots (tool move ->
-// ray onto the collision triangles -> nearest vertex -> closest incident triangle
-// -> hook pose -> ball paint) and then the observation, all in ONE kernel.
-//
-//  * the env's coverage state (painted mask, last-shot mask, this-shot mask,
-//    union-of-valid mask) lives in registers for the whole step: 64-bit word w
-//    of a mask is owned by lane (w & 63), slot (w >> 6); HBM traffic per env-step
-//    is one coalesced read and one coalesced write of the two persistent masks
-//    plus a 128-byte scalar record;
-//  * static part tables are shared by all envs and stay L2-resident; samples and
-//    vertices are sorted by uniform-grid cell so a sub-shot touches 3 short
-//    contiguous ranges (coalesced 512-B loads, one sample per lane, hit mask by
-//    ballot);
-//  * collision triangles are culled with a 16-byte box per lane-triangle before
-//    the float64 Moller-Trumbore test; closest hit by wave min-reduction;
-//  * section / grid observations are popcounts over mask words; only words whose
-//    bounding box straddles the tool position are classified per sample.
-//
-// All arithmetic is float64 in the reference's operation order (see
-// oracle/paint_oracle.c for the scalar statement; numpy.dot -> explicit fma chain,
-// everything else unfused: this file must be compiled with -ffp-contract=off).
-// No MFMA: this is gather / scan / bit work.
-//
-// Layout of the translation unit: the device code lives in the prl_*.hpp headers next to this file
-// (prl_device: descriptor + wave helpers + reference arithmetic, prl_ray, prl_search, prl_paint,
-// prl_observe, prl_state); this file holds the kernels and the host side of the C ABI.
-#include <hip/hip_runtime.h>
+// Table upload (prl_part_create: the device layouts and everything derived from the host tables), batch state, and the
+// entry points that launch the kernels.  The kernels live in their own translation units, compiled side by side
+// (prl_launch.hpp): k_step.hip (one launch per batched step), k_cone.hip (PAINT_METHOD 'normal'), k_rollout.hip
+// (policy + step, persistent fragments), k_big.hip (parts beyond 16 384 samples), policy_mlp.hip (the policy alone).
+// The device code is in the prl_*.hpp headers next to this file.  There is no CPU fallback anywhere in the library.
+#include "prl_all.hpp"
+#include "prl_kargs.hpp"
+#define PRL_HAVE_F32X4
+#include "prl_policy.hpp"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
+#include <algorithm>
 #include <array>
-#include <cstdlib>
-#include <cstring>
+#include <cstdarg>
 #include <map>
 #include <new>
 #include <vector>
 
-#include "paintrl.h"
-
-#include "prl_diag.hpp"
-#include "prl_device.hpp"
-#include "prl_ray.hpp"
-#include "prl_search.hpp"
-#include "prl_cone.hpp"
-#include "prl_paint.hpp"
-#include "prl_observe.hpp"
-#include "prl_state.hpp"
-#include "prl_step.hpp"
-#define PRL_HAVE_F32X4
-#include "prl_policy.hpp"
-
 namespace {
-
-// ---------------------------------------------------------------- reset kernel (rge:370-387)
-template <int KW, bool GENSEC>
-__global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    if (a.reset_mask && !a.reset_mask[env]) return;
-    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
-    int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
-    start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
-    reset_state(P, S, start);
-    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    if (C.color_mode == PRL_COLOR_HSI) reset_thickness<KW>(P, a.thick + (size_t)env * 64 * a.mask_stride, lane, painted);
-    store_masks<KW>(a, env, P.n_words, lane, painted, last);
-    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) {
-        const int od = obs_dim_of(C.obs_mode, C.obs_grad);
-        for (int k = lane; k < od; k += 64) a.obs[(size_t)env * od + k] = ldg(P.reset_obs, start * od + k);
-    }
-}
-
-// The observation a reset to start point s returns, for every s of one part (PartDev::reset_obs): one wave per start
-// point, run once when a batch is created.  KW = 0: LDS-resident mask (large parts).
-template <int KW, bool GENSEC>
-__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const PrlConfig *cfg, double *out) {
-    const int lane = threadIdx.x & 63;
-    const int s = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    PartRef P = *(const PartDev CAS *)part;
-    CfgRef C = *(const PrlConfig CAS *)cfg;
-    if (s >= P.n_start) return;
-    const double pose[3] = {P.start_pos[3 * s], P.start_pos[3 * s + 1], P.start_pos[3 * s + 2]};
-    const int od = obs_dim_of(C.obs_mode, C.obs_grad);
-    const bool hsi = C.color_mode == PRL_COLOR_HSI;           // thickness mode: every texel reads "painted" after a reset
-    if constexpr (KW == 0) {
-        extern __shared__ uint64_t big_lds[];
-        uint64_t *m = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * P.n_words;
-        for (int w = lane; w < P.n_words; w += 64) m[w] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
-    } else {
-        uint64_t painted[KW_MAX] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int w = lane + 64 * k;
-            painted[k] = (hsi && w < P.n_words) ? ldg(P.word_valid, w) : 0;
-        }
-        observation_wave<KW, GENSEC>(P, C, pose, painted, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
-    }
-}
-
-// ---------------------------------------------------------------- observation of the current state (rge:306-319)
-template <int KW, bool GENSEC>
-__global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
-    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    load_masks<KW>(a, env, P.n_words, lane, painted, last);
-    observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wave_lds<GENSEC>().cnt);
-}
-
-// ---------------------------------------------------------------- step kernel (rge:349-368)
-// One launch = one batched step: one wavefront per env, STEP_WAVES envs per workgroup (prl_step.hpp holds the step).
-template <int KW, bool NORMAL, bool GENSEC, bool HSI = false, bool KD = false, int WAVES = STEP_WAVES_NARROW>
-__global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
-    // the one by-value argument, read in place (constant address space) wherever a field is needed
-    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = threadIdx.x & 63;
-    static_assert(!NORMAL || WAVES == CONE_WAVES, "cone beams: four waves per workgroup (LDS mask rows)");
-    const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC, KD, NORMAL>();
-    const int part_id = a.env_part ? a.env_part[env] : 0;
-    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
-    EnvState S;
-    TRACE_BEGIN();
-    load_state_motion(state_rec, S);
-    PROF_BEGIN();
-    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
-    double delta1, delta2, new_angle;
-    decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<KW, NORMAL, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                      new_angle, StepRows{&a}, wl PROF_PASS);
-    store_state_live(state_rec, S, lane, dn != 0);
-    STAMP(PH_STORE);
-    PROF_END();
-    TRACE_END(env, dn);
-}
-
-// ---------------------------------------------------------------- parts with more than 16 384 samples (KW > 4)
-// The reference's other parts (door_lf ... door_rr_big, Part_Dict rge:106-117: 18 000 - 71 000 front samples) do not
-// fit four mask words per lane.  Their kernels keep the env's masks in LDS instead (three copies of n_words words
-// per env in the step kernel, one in reset / observe), sized at launch; everything else is the same code.
-__device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, int n_words, int lane, int copies) {
-    extern __shared__ uint64_t big_lds[];
-    const int wave = rfl((int)(threadIdx.x >> 6));
-    uint64_t *base = big_lds + (size_t)wave * copies * a.mask_stride;
-    return BigMasks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, base,
-                    base + (copies > 1 ? a.mask_stride : 0), base + (copies > 2 ? 2 * a.mask_stride : 0), n_words, lane};
-}
-
-template <bool GENSEC, bool KD>
-__global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
-    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC, KD>();
-    const int part_id = a.env_part ? a.env_part[env] : 0;
-    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
-    EnvState S;
-    load_state_motion(state_rec, S);
-    const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
-    double delta1, delta2, new_angle;
-    decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
-    const int dn = step_env<0, false, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                    new_angle, StepRows{&a}, wl PROF_PASS);
-    store_state_live(state_rec, S, lane, dn != 0);
-}
-
-template <bool GENSEC>
-__global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    if (a.reset_mask && !a.reset_mask[env]) return;
-    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
-    int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
-    start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
-    reset_state(P, S, start);
-    for (int w = lane; w < P.n_words; w += 64) {
-        a.painted[(size_t)env * a.mask_stride + w] = 0;
-        a.last[(size_t)env * a.mask_stride + w] = 0;
-    }
-    store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
-    if (a.obs) {
-        const int od = obs_dim_of(C.obs_mode, C.obs_grad);
-        for (int k = lane; k < od; k += 64) a.obs[(size_t)env * od + k] = ldg(P.reset_obs, start * od + k);
-    }
-}
-
-template <bool GENSEC>
-__global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (env >= a.n_envs) return;
-    PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
-    extern __shared__ uint64_t big_lds[];
-    uint64_t *painted = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
-    for (int w = lane; w < P.n_words; w += 64) painted[w] = a.painted[(size_t)env * a.mask_stride + w];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    observation_big<GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
-                            wave_lds<GENSEC>().cnt);
-}
-
-// ---------------------------------------------------------------- rollout fragment: policy + step, T times, one launch
-// The caller of the step in BASELINE.json configs 3-4 is a rollout worker (paint_ppo.py:170-195, fragments of
-// sample_batch_size = 100 steps).  One launch per step makes every step end with a grid-wide wait for the slowest
-// of all waves, and costs two launches plus an observation round trip through HBM.  Here a four-wave workgroup owns
-// four envs for the whole fragment:
-//     repeat T times:  stage the 4 observations in LDS -> the policy's three layers on the matrix cores (rows 4..15
-//                      of the 16-row MFMA tiles are zero) -> one draw per env -> workgroup barrier
-//                      -> every wave steps its env (prl_step.hpp) -> workgroup barrier
-// so a slow env delays its three neighbours, not the whole batch, there is nothing to launch, and while one
-// workgroup of a CU runs its policy on the matrix pipe the other three step their envs on the vector pipe.  The
-// coverage masks stay in LDS from the first step to the last (no mask traffic to HBM in between); trajectory rows
-// are written straight into the caller's [T][N] buffers, bit for bit what T rounds of prl_policy_act +
-// prl_batch_step write.  All workgroups must be resident together (4 per CU at 4096 envs): 23 KB of LDS each.
-struct FragmentArgs {
-    StepArgs s;                    // batch-level fields; the per-step output rows come from FragmentRows
-    int T;
-    double *obs;                   // [T + 1][N][od]: row 0 = the observations before the first step (input)
-    double *final_obs;             // [T][N][od]
-    double *reward, *info;         // [T][N], [T][N][2]
-    uint8_t *done;                 // [T][N]
-    const int32_t *action;         // [T][N]: the actions to take
-};
-
-// One launch = policy + env step for every env (act_step_kernel below): the step kernel's arguments plus the policy's.
-struct ActStepArgs {
-    StepArgs s;                    // s.actions is unused: the actions come from the policy phase
-    PrlPolicyWeights w;
-    const double *obs_in;          // [N][od]: the observations the policy sees (what the previous step wrote)
-    int32_t *action;               // [N] out
-    float *logp, *value;           // [N] out
-    uint32_t *rng_count;           // [N]
-    uint64_t rng_seed;
-};
-
-// Envs (= waves) per workgroup of the two kernels below = rows of the policy's MFMA tiles: one workgroup per CU at
-// 4 096 envs, four waves per SIMD.
-constexpr int FRAG_WAVES = POLICY_WAVES;
-
-// Output rows of step t of a fragment (see StepRows in prl_step.hpp).
-struct FragmentRows {
-    const FragmentArgs CAS *f;
-    int t, n, od;
-    __device__ __forceinline__ uint8_t *thick() const { return nullptr; }
-    __device__ __forceinline__ int mask_stride() const { return 0; }
-    __device__ __forceinline__ double *obs() const { return f->obs + (size_t)(t + 1) * n * od; }
-    __device__ __forceinline__ double *final_obs() const { return f->final_obs ? f->final_obs + (size_t)t * n * od : nullptr; }
-    __device__ __forceinline__ double *reward() const { return f->reward + (size_t)t * n; }
-    __device__ __forceinline__ double *info() const { return f->info + (size_t)t * n * 2; }
-    __device__ __forceinline__ uint8_t *done() const { return f->done + (size_t)t * n; }
-    __device__ __forceinline__ const int *start_idx() const { return nullptr; }
-};
-
-// The masks of one env in the workgroup's LDS (same word-to-lane mapping as GlobalMasks).
-struct LdsMasks {
-    uint64_t *painted, *last;
-    int n_words, lane;
-    template <int KW>
-    __device__ __forceinline__ void load(uint64_t p[KW_MAX], uint64_t l[KW_MAX]) const {
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int w = lane + 64 * k;
-            const bool in = w < n_words;
-            p[k] = in ? painted[w] : 0;
-            l[k] = in ? last[w] : 0;
-        }
-    }
-    template <int KW>
-    __device__ __forceinline__ void store(const uint64_t p[KW_MAX], const uint64_t l[KW_MAX]) const {
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int w = lane + 64 * k;
-            if (w < n_words) {
-                painted[w] = p[k];
-                last[w] = l[k];
-            }
-        }
-    }
-};
-
-// Every iteration of the fragment loop starts from this pointer: the compiler cannot tell that it is the same
-// one each time, so nothing derived from the kernel arguments or the part descriptor is hoisted out of the loop
-// and held in registers across both phases (that cost the first version of this kernel 950 spilled registers).
-__device__ __forceinline__ const FragmentArgs CAS *opaque(const FragmentArgs CAS *p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-// ... and the same for what is derived from the lane and wave numbers (per-lane offsets, lane predicates).
-__device__ __forceinline__ int opaque_v(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ int opaque_s(int v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-
-template <int KW>
-__global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(FragmentArgs) {
-    extern __shared__ float lds[];
-    const FragmentArgs CAS *f0 = (const FragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane0 = threadIdx.x & 63, wave0 = rfl((int)(threadIdx.x >> 6));
-    const int lane = lane0, wave = wave0, env0 = blockIdx.x * FRAG_WAVES, env = env0 + wave;
-    {   // coverage masks: HBM -> LDS, once
-        const FragmentArgs CAS &f = *opaque(f0);
-        const StepArgs CAS &a = f.s;
-        if (env < a.n_envs) {
-            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
-            const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
-            uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
-            g.template load<KW>(p, l);
-            m.template store<KW>(p, l);
-        }
-    }
-    FRAG_DECL();
-    for (int t = 0;; ++t) {
-        const FragmentArgs CAS &f = *opaque(f0);
-        const StepArgs CAS &a = f.s;
-        const int lane = opaque_v(lane0), wave = opaque_s(wave0);
-        const int env0 = opaque_s((int)blockIdx.x) * FRAG_WAVES, env = env0 + wave;
-        const int n_envs = a.n_envs, T = f.T;
-        const size_t n = (size_t)n_envs;
-        if (t >= T) break;
-        FRAG_T(ft1);
-        if (env < n_envs) {                                           // exactly the per-step kernel's body
-            const int part_id = a.env_part ? a.env_part[env] : 0;
-            PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-            CfgRef C = *(const PrlConfig CAS *)a.cfg;
-            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const LdsMasks masks{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
-            double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
-            EnvState S;
-            load_state_motion(state_rec, S);
-            double delta1, delta2, new_angle;
-            decode_discrete_action(C, f.action[(size_t)t * n + env], delta1, delta2, new_angle);
-            const FragmentRows row{&f, t, n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
-            __shared__ int s_cand[FRAG_WAVES][64];
-            __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
-            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr};
-            PROF_BEGIN();
-            const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                            new_angle, row, wl PROF_PASS);
-            store_state_live(state_rec, S, lane, dn != 0);
-        }
-        FRAG_T(ft2);
-        FRAG_ACC(1, ft1, ft2);
-        FRAG_COUNT();
-    }
-    FRAG_FLUSH();
-    {   // coverage masks: LDS -> HBM
-        const FragmentArgs CAS &f = *opaque(f0);
-        const StepArgs CAS &a = f.s;
-        if (env < a.n_envs) {
-            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-            uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
-            const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
-            uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
-            m.template load<KW>(p, l);
-            g.template store<KW>(p, l);
-        }
-    }
-}
-// The env step of act_step_kernel: everything is derived afresh from laundered lane / wave numbers and from the
-// kernel-argument segment, so that nothing of the policy phase is still held in registers (the step is at its ceiling).
-template <int KW>
-__device__ __forceinline__ void act_step_env(int env, int lane, int wave, int act, int (*s_cand)[64],
-                                             double (*s_centres)[PAINT_PER_ACTION * 3 + 1]) {
-    const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const StepArgs CAS &a = f.s;
-    const int part_id = a.env_part ? a.env_part[env] : 0;
-    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
-    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
-    EnvState S;
-    load_state_motion(state_rec, S);
-    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
-    double delta1, delta2, new_angle;
-    decode_discrete_action(C, act, delta1, delta2, new_angle);
-    const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, nullptr};
-    PROF_BEGIN();
-    const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                                  new_angle, StepRows{&a}, wl PROF_PASS);
-    store_state_live(state_rec, S, lane, dn != 0);
-}
-
-// ---------------------------------------------------------------- policy + env step in one launch
-// What a rollout worker does per step (paint_ppo.py:170-195: policy forward, sample, env.step) as ONE kernel: the
-// sixteen envs of a workgroup first run the policy on their observations together (prl_policy.hpp: three MFMA layers,
-// ~3 us, bound by the weight reads it issues up front), each wave then steps its own env with the sampled action.
-// No second launch and no ~2.5 us of dispatch gaps per step; rows as prl_policy_act + prl_batch_step write them.
-template <int KW>
-__global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs) {
-    extern __shared__ float lds[];
-    __shared__ int s_cand[POLICY_WAVES][64];
-    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
-    const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const StepArgs CAS &a = f.s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
-    const int env0 = blockIdx.x * POLICY_WAVES, env = env0 + wave, n_envs = a.n_envs;
-    FRAG_DECL();
-    FRAG_T(ft0);
-    int act = 0;
-    {
-        PrlPolicyWeights W;                                      // (no implicit copy out of the constant address space)
-        W.in_dim = f.w.in_dim; W.h1 = f.w.h1; W.h2 = f.w.h2; W.n_actions = f.w.n_actions;
-        W.w1 = f.w.w1; W.b1 = f.w.b1; W.w2 = f.w.w2; W.b2 = f.w.b2; W.w3 = f.w.w3; W.b3 = f.w.b3;
-        const PolicyLds L = policy_lds_layout(W);
-        const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
-        SamplerPre sp;
-        policy_forward(W, f.obs_in + (size_t)env0 * W.in_dim, rows_real, lds, L, tid, env0, nullptr, f.rng_count, sp);
-        if (lane == 0 && wave < rows_real) {                      // every wave draws for its own env: no barrier after it
-            const int e = env0 + wave, A = W.n_actions;
-            const float u = policy_uniform(f.rng_seed, e, sp.count);
-            float lse;
-            float *Ow = lds + L.o_off;
-            act = policy_sample_row(A, lds + L.b3_off, Ow, wave, u, lse);
-            POL_STAMP(7);
-            f.action[e] = act;
-            f.logp[e] = Ow[wave * 17 + act] - lse;
-            f.value[e] = Ow[wave * 17 + A];
-        }
-    }
-    act = rfl(act);
-    FRAG_T(ft1);
-    FRAG_ACC(0, ft0, ft1);
-    FRAG_COUNT();
-    FRAG_FLUSH();
-    if (env >= n_envs) return;
-    act_step_env<KW>(opaque_s((int)blockIdx.x) * POLICY_WAVES + opaque_s(wave), opaque_v((int)(threadIdx.x & 63)), opaque_s(wave), act,
-                     s_cand, s_centres);
-}
-
-// ---------------------------------------------------------------- a whole fragment WITH the policy in one persistent launch
-// (prl_rollout_fragment with weights) -- the loop of act_step_kernel's two phases: the sixteen waves of a workgroup meet
-// at the policy's barriers, workgroups never wait for each other, nothing is launched in between.  Each phase starts
-// from laundered pointers and lane / wave numbers, so that neither holds the other's registers (5 spilled VGPRs, none in
-// a loop; the round's first version of this kernel spilled 954).  47.1 us per step against 50.4 for T launches of
-// act_step_kernel: no dispatch ramp, and only sixteen envs wait for their slowest.
-struct PolicyFragmentArgs {
-    FragmentArgs f;                // f.action is written here
-    PrlPolicyWeights w;
-    float *logp, *value, *last_value;
-    uint32_t *rng_count;
-    uint64_t rng_seed;
-};
-__device__ __forceinline__ const PolicyFragmentArgs CAS *opaque(const PolicyFragmentArgs CAS *p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-template <int KW>
-__global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(PolicyFragmentArgs) {
-    extern __shared__ float lds[];
-    __shared__ int s_cand[POLICY_WAVES][64];
-    __shared__ double s_centres[POLICY_WAVES][PAINT_PER_ACTION * 3 + 1];
-    const PolicyFragmentArgs CAS *g0 = (const PolicyFragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int wave0 = rfl((int)(threadIdx.x >> 6));
-    for (int t = 0;; ++t) {
-        const PolicyFragmentArgs CAS &g = *opaque(g0);
-        const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0), tid = 64 * wave + lane;
-        const int env0 = opaque_s((int)blockIdx.x) * POLICY_WAVES, env = env0 + wave;
-        const int n_envs = g.f.s.n_envs, T = g.f.T;
-        const size_t n = (size_t)n_envs;
-        int act = 0;
-        {
-            PrlPolicyWeights W;
-            W.in_dim = g.w.in_dim; W.h1 = g.w.h1; W.h2 = g.w.h2; W.n_actions = g.w.n_actions;
-            W.w1 = g.w.w1; W.b1 = g.w.b1; W.w2 = g.w.w2; W.b2 = g.w.b2; W.w3 = g.w.w3; W.b3 = g.w.b3;
-            const PolicyLds L = policy_lds_layout(W);
-            const int rows_real = n_envs - env0 < POLICY_WAVES ? n_envs - env0 : POLICY_WAVES;
-            SamplerPre sp;
-            policy_forward(W, g.f.obs + ((size_t)t * n + env0) * W.in_dim, rows_real, lds, L, tid, env0, nullptr, g.rng_count, sp);
-            if (lane == 0 && wave < rows_real) {
-                const int e = env0 + wave, A = W.n_actions;
-                const float u = policy_uniform(g.rng_seed, e, sp.count);
-                float lse;
-                float *Ow = lds + L.o_off;
-                act = policy_sample_row(A, lds + L.b3_off, Ow, wave, u, lse);
-                if (t < T) {
-                    const_cast<int32_t *>(g.f.action)[(size_t)t * n + e] = act;
-                    g.logp[(size_t)t * n + e] = Ow[wave * 17 + act] - lse;
-                    g.value[(size_t)t * n + e] = Ow[wave * 17 + A];
-                } else {
-                    g.last_value[e] = Ow[wave * 17 + A];          // the bootstrap value; its draw is discarded
-                }
-            }
-        }
-        if (t >= T) break;
-        act = rfl(act);
-        if (env < n_envs) {
-            const PolicyFragmentArgs CAS &h = *opaque(g0);
-            const StepArgs CAS &a = h.f.s;
-            const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0);
-            const int env = opaque_s((int)blockIdx.x) * POLICY_WAVES + wave;
-            const int part_id = a.env_part ? a.env_part[env] : 0;
-            PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-            CfgRef C = *(const PrlConfig CAS *)a.cfg;
-            double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
-            EnvState S;
-            load_state_motion(state_rec, S);
-            const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
-            double delta1, delta2, new_angle;
-            decode_discrete_action(C, act, delta1, delta2, new_angle);
-            const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
-            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, nullptr};
-            PROF_BEGIN();
-            const int dn = step_env<KW, false, false, true, false, false>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                                          new_angle, row, wl PROF_PASS);
-            store_state_live(state_rec, S, lane, dn != 0);
-        }
-        __syncthreads();            // the observations of step t are written (workgroup-scope fences included)
-    }
-}
 
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
 __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int n, const double *from,
@@ -606,6 +81,7 @@ struct PrlPart {
 struct PrlBatch {
     int device = 0, n_envs = 0, n_parts = 0, mask_stride = 0, kw = 0;
     bool kd = false;               // some part carries the reference's stale vertex kd-tree
+    int max_beams = 0;             // largest cone-beam count of the parts (PAINT_METHOD 'normal')
     PrlConfig cfg{};
     PartDev *parts_dev = nullptr;
     PrlConfig *cfg_dev = nullptr;
@@ -1001,56 +477,6 @@ int check_config(const PrlConfig *c) {
     return PRL_OK;
 }
 
-template <int KW, int WAVES>
-void launch_step_w(const StepArgs &a, bool gensec, bool hsi, bool kd, hipStream_t s) {
-    const dim3 grid((a.n_envs + WAVES - 1) / WAVES), block(64 * WAVES);
-    if (kd && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, true, WAVES>), grid, block, 0, s, a);
-    else if (kd) hipLaunchKernelGGL((step_kernel<KW, false, false, false, true, WAVES>), grid, block, 0, s, a);
-    else if (hsi && gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, true, false, WAVES>), grid, block, 0, s, a);
-    else if (hsi) hipLaunchKernelGGL((step_kernel<KW, false, false, true, false, WAVES>), grid, block, 0, s, a);
-    else if (gensec) hipLaunchKernelGGL((step_kernel<KW, false, true, false, false, WAVES>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<KW, false, false, false, false, WAVES>), grid, block, 0, s, a);
-}
-
-template <int KW>
-void launch_step(const StepArgs &a, bool normal, bool gensec, bool hsi, bool kd, bool wide, hipStream_t s) {
-    if (normal) {
-        const dim3 grid((a.n_envs + CONE_WAVES - 1) / CONE_WAVES), block(64 * CONE_WAVES);
-        if (gensec) hipLaunchKernelGGL((step_kernel<KW, true, true, false, false, CONE_WAVES>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((step_kernel<KW, true, false, false, false, CONE_WAVES>), grid, block, 0, s, a);
-    } else if (wide) {
-        launch_step_w<KW, STEP_WAVES_WIDE>(a, gensec, hsi, kd, s);
-    } else {
-        launch_step_w<KW, STEP_WAVES_NARROW>(a, gensec, hsi, kd, s);
-    }
-}
-
-template <int KW>
-void launch_reset(const StepArgs &a, bool gensec, hipStream_t s) {
-    const dim3 grid((a.n_envs + 3) / 4), block(256);
-    if (gensec) hipLaunchKernelGGL((reset_kernel<KW, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((reset_kernel<KW, false>), grid, block, 0, s, a);
-}
-
-template <int KW>
-void launch_observe(const StepArgs &a, bool gensec, hipStream_t s) {
-    const dim3 grid((a.n_envs + 3) / 4), block(256);
-    if (gensec) hipLaunchKernelGGL((observe_kernel<KW, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((observe_kernel<KW, false>), grid, block, 0, s, a);
-}
-
-// Large parts (more than 64 * KW_MAX mask words): dynamic LDS = 4 waves x copies x mask_stride words.
-int launch_big(void (*kernel)(StepArgs), const StepArgs &a, int copies, hipStream_t s) {
-    const size_t lds = (size_t)4 * copies * a.mask_stride * sizeof(uint64_t);
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(PRL_E_HIP, "hipFuncSetAttribute(%zu bytes of LDS): %s", lds, hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(kernel, dim3((a.n_envs + 3) / 4), dim3(256), lds, s, a);
-    return PRL_OK;
-}
-
 bool general_section(const PrlConfig &c) {
     return (c.obs_mode == PRL_OBS_SECTION || c.obs_mode == PRL_OBS_DISCRETE) && c.obs_grad != 4;
 }
@@ -1077,6 +503,28 @@ StepArgs base_args(PrlBatch *b) {
     a.thick = b->thick;
     a.state = b->state;
     return a;
+}
+
+// kernel-unit dispatch by mask width (prl_launch.hpp): kw = 1..4 register-resident masks, anything larger the LDS-mask unit
+#define PRL_KW_SWITCH(kw, call_suffix)                  \
+    ((kw) == 1   ? prl_k1_##call_suffix                  \
+     : (kw) == 2 ? prl_k2_##call_suffix                  \
+     : (kw) == 3 ? prl_k3_##call_suffix                  \
+     : (kw) == 4 ? prl_k4_##call_suffix                  \
+                 : prl_k0_##call_suffix)
+
+int launch_failed(int hip_error, const char *what) {
+    return fail(PRL_E_HIP, "%s: %s", what, hipGetErrorString(static_cast<hipError_t>(hip_error)));
+}
+
+PrlStepSel step_sel(const PrlBatch *b) {
+    PrlStepSel sel{};
+    sel.gensec = general_section(b->cfg) ? 1 : 0;
+    sel.hsi = b->cfg.color_mode == PRL_COLOR_HSI ? 1 : 0;
+    sel.kd = b->kd ? 1 : 0;
+    sel.wide = b->n_envs <= b->resident_envs ? 1 : 0;
+    sel.max_beams = b->max_beams;
+    return sel;
 }
 
 }  // namespace
@@ -1164,11 +612,7 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         if (parts[i]->dev.n_words > b->mask_stride) b->mask_stride = parts[i]->dev.n_words;
     b->kw = (b->mask_stride + 63) / 64;
     for (int i = 0; i < n_parts; ++i) b->kd = b->kd || parts[i]->dev.n_kd_nodes > 0;
-    if (b->kd && (cfg->paint_method == PRL_PAINT_NORMAL || cfg->color_mode == PRL_COLOR_HSI)) {
-        delete b;
-        return fail(PRL_E_UNSUPPORTED, "a part with the reference's stale vertex kd-tree (moved vertex rows) runs with "
-                                       "PAINT_METHOD 'fast' and COLOR_MODE 'RGB' only");
-    }
+    for (int i = 0; i < n_parts; ++i) b->max_beams = std::max(b->max_beams, parts[i]->dev.n_beams);
     if (b->kw > KW_MAX && cfg->color_mode == PRL_COLOR_HSI) {
         delete b;
         return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for parts of at most %d samples", 64 * 64 * KW_MAX);
@@ -1214,26 +658,9 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess) e = hipMemset(b->state, 0, state_bytes);
     // the observation a reset to each start point returns (PartDev::reset_obs), once per part
     for (int i = 0; i < n_parts && e == hipSuccess; ++i) {
-        const bool gs = general_section(*cfg);
-        const dim3 grid((pd[i].n_start + 3) / 4), block(256);
-        const int words = pd[i].n_words;
-        if (words > 64 * KW_MAX) {
-            void (*k)(const PartDev *, const PrlConfig *, double *) = gs ? reset_obs_kernel<0, true> : reset_obs_kernel<0, false>;
-            const size_t lds = (size_t)4 * words * sizeof(uint64_t);
-            if (lds > 64 * 1024)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i]);
-        } else {
-            const int kw = (words + 63) / 64;
-#define RESET_OBS_LAUNCH(KWV)                                                                                         \
-    if (gs) hipLaunchKernelGGL((reset_obs_kernel<KWV, true>), grid, block, 0, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i]); \
-    else hipLaunchKernelGGL((reset_obs_kernel<KWV, false>), grid, block, 0, 0, b->parts_dev + i, b->cfg_dev, b->reset_obs[i])
-            if (kw <= 1) { RESET_OBS_LAUNCH(1); }
-            else if (kw == 2) { RESET_OBS_LAUNCH(2); }
-            else if (kw == 3) { RESET_OBS_LAUNCH(3); }
-            else { RESET_OBS_LAUNCH(4); }
-#undef RESET_OBS_LAUNCH
-        }
+        const int words = pd[i].n_words, kw_i = words > 64 * KW_MAX ? 0 : (words + 63) / 64;
+        e = static_cast<hipError_t>(PRL_KW_SWITCH(kw_i, reset_obs)(
+            b->parts_dev + i, b->cfg_dev, b->reset_obs[i], pd[i].n_start, words, general_section(*cfg) ? 1 : 0));
         if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -1271,18 +698,7 @@ int prl_batch_reset(PrlBatch *b, const uint8_t *reset_mask, const int32_t *start
     a.reset_mask = reset_mask;
     a.start_idx = start_idx;
     a.obs = obs;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (b->kw) {
-    case 1: launch_reset<1>(a, general_section(b->cfg), s); break;
-    case 2: launch_reset<2>(a, general_section(b->cfg), s); break;
-    case 3: launch_reset<3>(a, general_section(b->cfg), s); break;
-    case 4: launch_reset<4>(a, general_section(b->cfg), s); break;
-    default: {
-        const int rc = launch_big(general_section(b->cfg) ? reset_kernel_big<true> : reset_kernel_big<false>, a, 0, s);
-        if (rc) return rc;
-    }
-    }
-    HIP_TRY(hipGetLastError());
+    if (int e = PRL_KW_SWITCH(b->kw, reset)(&a, general_section(b->cfg) ? 1 : 0, stream)) return launch_failed(e, "prl_batch_reset");
     return PRL_OK;
 }
 
@@ -1291,18 +707,7 @@ int prl_batch_observe(PrlBatch *b, double *obs, void *stream) {
     if (int rc = check_device(b)) return rc;
     StepArgs a = base_args(b);
     a.obs = obs;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (b->kw) {
-    case 1: launch_observe<1>(a, general_section(b->cfg), s); break;
-    case 2: launch_observe<2>(a, general_section(b->cfg), s); break;
-    case 3: launch_observe<3>(a, general_section(b->cfg), s); break;
-    case 4: launch_observe<4>(a, general_section(b->cfg), s); break;
-    default: {
-        const int rc = launch_big(general_section(b->cfg) ? observe_kernel_big<true> : observe_kernel_big<false>, a, 1, s);
-        if (rc) return rc;
-    }
-    }
-    HIP_TRY(hipGetLastError());
+    if (int e = PRL_KW_SWITCH(b->kw, observe)(&a, general_section(b->cfg) ? 1 : 0, stream)) return launch_failed(e, "prl_batch_observe");
     return PRL_OK;
 }
 
@@ -1319,7 +724,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     a.final_obs = final_obs;
     a.start_idx = start_idx;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL, hsi = b->cfg.color_mode == PRL_COLOR_HSI;
+    const bool normal = b->cfg.paint_method == PRL_PAINT_NORMAL;
     const bool timed = b->timing_every > 0 && (b->launch_no++ % b->timing_every) == 0;
     if (timed) {
         if (b->ev_used == b->ev_start.size()) {
@@ -1331,20 +736,9 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         }
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
-    const bool wide = b->n_envs <= b->resident_envs;
-    switch (b->kw) {
-    case 1: launch_step<1>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
-    case 2: launch_step<2>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
-    case 3: launch_step<3>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
-    case 4: launch_step<4>(a, normal, general_section(b->cfg), hsi, b->kd, wide, s); break;
-    default: {                                     // a part with more than 16 384 samples: masks in LDS
-        const bool gs = general_section(b->cfg);
-        const int rc = launch_big(b->kd ? (gs ? step_kernel_big<true, true> : step_kernel_big<false, true>)
-                                        : (gs ? step_kernel_big<true, false> : step_kernel_big<false, false>), a, 3, s);
-        if (rc) return rc;
-    }
-    }
-    HIP_TRY(hipGetLastError());
+    const PrlStepSel sel = step_sel(b);
+    const int e = normal ? PRL_KW_SWITCH(b->kw, cone)(&a, &sel, stream) : PRL_KW_SWITCH(b->kw, step)(&a, &sel, stream);
+    if (e) return launch_failed(e, "prl_batch_step");
     if (timed) {
         HIP_TRY(hipEventRecord(b->ev_stop[b->ev_used], s));
         b->ev_used += 1;
@@ -1419,7 +813,6 @@ static int check_rollout_batch(PrlBatch *b, const char *who) {
     if (!c.auto_reset) return fail(PRL_E_INVALID, "%s: the batch must be created with auto_reset", who);
     if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "%s: parts of at most %d samples", who, 64 * 64 * KW_MAX);
     if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "%s: COLOR_MODE 'RGB'", who);
-    if (b->kd) return fail(PRL_E_UNSUPPORTED, "%s: not for parts with the reference's stale vertex kd-tree", who);
     if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
         return fail(PRL_E_UNSUPPORTED, "%s: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for section / discrete observations", who);
     return PRL_OK;
@@ -1460,18 +853,7 @@ int prl_batch_act_step(PrlBatch *b, const PrlPolicyWeights *w, const double *obs
     f.rng_count = rng_count;
     f.rng_seed = rng_seed;
     const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
-    void (*kernel)(ActStepArgs) = nullptr;
-    switch (b->kw) {
-    case 1: kernel = act_step_kernel<1>; break;
-    case 2: kernel = act_step_kernel<2>; break;
-    case 3: kernel = act_step_kernel<3>; break;
-    default: kernel = act_step_kernel<4>; break;
-    }
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((b->n_envs + POLICY_WAVES - 1) / POLICY_WAVES), block(64 * POLICY_WAVES);
-    hipLaunchKernelGGL(kernel, grid, block, lds, static_cast<hipStream_t>(stream), f);
-    HIP_TRY(hipGetLastError());
+    if (int e = PRL_KW_SWITCH(b->kw, act_step)(&f, lds, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_batch_act_step");
     return PRL_OK;
 }
 
@@ -1505,17 +887,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
             g.rng_count = rng_count;
             g.rng_seed = rng_seed;
             const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
-            void (*kernel)(PolicyFragmentArgs) = nullptr;
-            switch (b->kw) {
-            case 1: kernel = rollout_policy_kernel<1>; break;
-            case 2: kernel = rollout_policy_kernel<2>; break;
-            case 3: kernel = rollout_policy_kernel<3>; break;
-            default: kernel = rollout_policy_kernel<4>; break;
-            }
-            if (lds > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kernel, dim3((b->n_envs + POLICY_WAVES - 1) / POLICY_WAVES), dim3(64 * POLICY_WAVES), lds, s, g);
-            HIP_TRY(hipGetLastError());
+            if (int e = PRL_KW_SWITCH(b->kw, rollout_policy)(&g, lds, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_rollout_fragment");
             return PRL_OK;
         }
     }
@@ -1529,59 +901,11 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     f.done = done;
     f.info = info;
     f.action = action;
-    const size_t lds = (size_t)FRAG_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
+    const size_t lds = (size_t)POLICY_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
     if (lds > 120 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
-    const dim3 grid((b->n_envs + FRAG_WAVES - 1) / FRAG_WAVES), block(64 * FRAG_WAVES);
-    void (*kernel)(FragmentArgs) = nullptr;
-    switch (b->kw) {
-    case 1: kernel = rollout_fragment_kernel<1>; break;
-    case 2: kernel = rollout_fragment_kernel<2>; break;
-    case 3: kernel = rollout_fragment_kernel<3>; break;
-    default: kernel = rollout_fragment_kernel<4>; break;
-    }
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, grid, block, lds, s, f);
-    HIP_TRY(hipGetLastError());
+    if (int e = PRL_KW_SWITCH(b->kw, rollout_fragment)(&f, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_rollout_fragment");
     return PRL_OK;
 }
-
-#ifdef PRL_PHASE_TIMING
-// diagnostic build only: read and clear the per-phase cycle sums
-int prl_debug_phase_cycles(unsigned long long *out, int n) {
-    unsigned long long host[16] = {0};
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_cycles), sizeof host) != hipSuccess) return PRL_E_HIP;
-    for (int k = 0; k < n && k < 16; ++k) out[k] = host[k];
-    unsigned long long zero[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
-    return PRL_OK;
-}
-#endif
-
-#ifdef PRL_FRAG_TIMING
-// diagnostic build only: read and clear the fragment kernel's phase sums
-int prl_debug_frag_ticks(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_frag_ticks), sizeof(unsigned long long) * 4) != hipSuccess) return PRL_E_HIP;
-    if (hipMemcpyFromSymbol(out + 4, HIP_SYMBOL(g_pol_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return PRL_E_HIP;
-    unsigned long long zero[4] = {0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_frag_ticks), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
-    return PRL_OK;
-}
-#endif
-
-#ifdef PRL_WAVE_TRACE
-// diagnostic build only: the last launch's per-env trace rows (start, end, path counters, done)
-int prl_debug_wave_trace(unsigned long long *out, int n_envs) {
-    if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
-    return PRL_OK;
-}
-int prl_debug_wave_trace16(unsigned long long *out, int n_envs) {
-    if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace16), sizeof(unsigned long long) * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
-    return PRL_OK;
-}
-#endif
 
 int prl_batch_timing_enable(PrlBatch *b, int enable) {
     if (!b) return fail(PRL_E_INVALID, "null batch");

@@ -134,7 +134,7 @@ __device__ void rays_general_lanes(PartRef P, const double o[3], const double ds
 
 // The rays of beams b0 + lane: hit[3] / t of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray.
 __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                int *cand_lds, double hit[3] PROF_ARG) {
+                                int *cand_lds, double hit[3]) {
     const int bm = b0 + lane;
     const bool have = bm < P.n_beams;
     double dst[3] = {pos[0], pos[1], pos[2]};
@@ -142,7 +142,6 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
     const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
     double t = INFINITY;
-    STAMP(PH_RAY);
     int state = have ? 0 : 2;                       // 0 walking, 1 hit, 2 finished without a hit (no beam), 3 -> wave-wide search
     if (P.col_convex && hint >= 0) {
         int f = hint, rk = 0;
@@ -164,7 +163,6 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 #ifdef PRL_FORCE_GENERAL_RAY
     if (have) state = 3;
 #endif
-    STAMP(PH_VERTEX);                               // (stamped builds: the walk counts as 'vertex', the search as 'bary')
     hit[0] = pos[0] + t * d0;
     hit[1] = pos[1] + t * d1;
     hit[2] = pos[2] + t * d2;
@@ -229,7 +227,6 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
             }
         }
     }
-    STAMP(PH_BARY);
     return state == 1;
 }
 
@@ -360,6 +357,29 @@ __device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, cons
         const double lim = (r == 0x7fffffff ? 1.0e30 : (double)r * P.fg_accept);
         if (need && best_pos >= 0 && best_d <= lim * lim) sidx = best_pos;
     }
+}
+
+// One trip of a shot: the beams b0 + lane of the cone at tool pose (pos, quat) -- the device position of the sample each
+// lane's beam paints (bpw:562-566: the sample nearest to the hit point), or -1 (no such beam, or it misses the part).
+__device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
+                                         int *cand_lds) {
+    double bh[3];
+    const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh);
+    WCNT16(3, __popcll(ballot64(hit)));
+    // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle go through
+    // the wave-wide search
+    int sidx = nearest_sample_lane(P, bh, hit);
+    if (__popcll(ballot64(sidx == -2)) > 3) nearest_samples_shared(P, bh, lane, sidx);   // (a recess of the part)
+    uint64_t rest = ballot64(sidx == -2);
+    WCNT16(1, __popcll(rest));
+    while (rest) {
+        const int L = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        const double h3[3] = {bcast_d(bh[0], L), bcast_d(bh[1], L), bcast_d(bh[2], L)};
+        const int s2 = nearest_sample_wave(P, h3, lane);
+        if (lane == L) sidx = s2;
+    }
+    return sidx;
 }
 
 }  // namespace

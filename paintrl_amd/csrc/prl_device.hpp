@@ -11,7 +11,10 @@ namespace {
 // backfilled sooner: at 8 192 envs 80.2 vs 90.2 us, at 32 768 298 vs 319); cone beams: 4.
 constexpr int STEP_WAVES_WIDE = 8, STEP_WAVES_NARROW = 4;
 constexpr int MAX_WAVES_PER_WG = STEP_WAVES_WIDE;   // per-wave LDS scratch rows
-constexpr int CONE_WAVES = 4;                    // ... of its cone-beam instantiations (8 KB of LDS mask rows per wave)
+#ifndef PRL_CONE_WAVES
+#define PRL_CONE_WAVES 8
+#endif
+constexpr int CONE_WAVES = PRL_CONE_WAVES;       // envs per workgroup of the cone-beam kernel (k_cone.hip): they share their beam trips
 constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples in registers
 constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3 copies x 4 waves x 1600 x 8 B = 150 KB of 160 KB
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
@@ -165,25 +168,16 @@ struct WaveLds {
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
     int *cnt;           // [128], only with the atan2-sector observation
     double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
-    uint64_t *mask;     // [4][64 * KW_MAX], only in the cone-beam kernels: a shot's hit bits (zero between shots), then
-                        // the env's painted / last-shot / union-of-valid masks while the shots run (prl_step.hpp)
+    uint64_t *mask;     // (unused)
 };
-template <bool GENSEC, bool KD = false, bool CONE = false>
+template <bool GENSEC, bool KD = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[MAX_WAVES_PER_WG][64];
     __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
     __shared__ double s_kd[KD ? MAX_WAVES_PER_WG : 1][KD ? KD_HEAP * 5 : 1];
-    __shared__ uint64_t s_mask[CONE ? CONE_WAVES : 1][CONE ? 4 * 64 * KW_MAX : 1];     // (32 KB at four waves)
     const int w = rfl((int)(threadIdx.x >> 6));
-    if constexpr (CONE) {
-#pragma unroll
-        for (int k = 0; k < KW_MAX; ++k) s_mask[w][(threadIdx.x & 63) + 64 * k] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], s_mask[CONE ? w : 0]};
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], nullptr};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

@@ -59,238 +59,122 @@ __device__ __forceinline__ void reset_thickness(PartRef P, uint8_t *thick, int l
     }
 }
 
-// Advances env `env` by one step.  In: the motion part of S (load_state_motion) and the coverage masks in
-// registers; with LATE_ACC the episode accumulators are read from `state_rec` only after the five sub-shots (the
-// per-step kernel: their scalar registers are then free during the shots), otherwise S is complete on entry (the
-// fragment kernel keeps it in registers from step to step).  Out: S and the masks advanced (reset if the episode
-// ended and C.auto_reset), the observation in row `env` of a.obs (the post-reset one after an auto-reset, the
-// terminal one then goes to a.final_obs if that is not null), reward / done / info rows through lane 0; the
-// output addresses are formed where they are used, so that they hold no registers during the shots.  Returns done.
-// NORMAL = PAINT_METHOD 'normal' (cone beams, rob:280-285 + bpw:562-566); false = 'fast' (ball query).
-//
-// The coverage masks are not touched by the five sub-shots of the ball-query paint method, so they are fetched
-// through `masks` (GlobalMasks: HBM, LdsMasks: the fragment kernel's LDS copy) only when painting starts and put
-// back after the observation: twelve vector registers less during the shots.
-//
-// `a` (RowIO) names this step's output rows: obs / final_obs / reward / info / done / start_idx members that are
-// evaluated where they are used.  Both implementations read the kernel arguments through the constant address
-// space at that point; handing the kernel's by-value argument struct down by reference instead makes the compiler
-// copy all of it into registers at kernel entry.
-// HSI = COLOR_MODE 'HSI' (bpw:384-434): thickness bytes in a.thick, float "succeed counter" (prl_paint.hpp).
-// KD: parts of the batch may carry the reference's stale vertex kd-tree (prl_search.hpp nearest_vertex_kd).
-template <int KW, bool NORMAL, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, typename MaskIO, typename RowIO>
-__device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
-                                        const double *state_rec, const MaskIO &masks, double delta1, double delta2,
-                                        double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
-    // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
-    constexpr bool BIG = KW == 0;
-    PRIO_YOUNG_DECL();
-    static_assert(!(BIG && NORMAL), "cone-beam painting keeps per-shot masks in 64-word-per-slot LDS rows: small parts only");
-    static_assert(!(HSI && (BIG || NORMAL)), "thickness mode is built for ball-query painting of small parts");
-    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
-    if constexpr (BIG) masks.template load<KW>(painted, last);
-    if constexpr (NORMAL) {
-        // cone-beam painting updates the masks shot by shot: they wait in this wave's LDS rows (wl.mask + 256 painted,
-        // + 512 last shot, + 768 union of the shots' valid sets), not in 24 vector registers held through the rays
-        masks.template load<KW>(painted, last);
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            wl.mask[256 + lane + 64 * k] = painted[k];
-            wl.mask[512 + lane + 64 * k] = last[k];
-            wl.mask[768 + lane + 64 * k] = 0;
-        }
-    }
-    const int counter_before = S.terminate_counter;
+// What the five sub-shots of a step carry from one to the next (rob:302-329): tool position and normal (vector
+// registers holding wave-uniform values: every consumer is a vector instruction, and scalar registers are the
+// scarce kind), the per-shot move, the facet the last ray hit and the triangle the last shot hooked to.
+struct ShotCtx {
+    double cur_pose[3], cur_norm[3];
+    double d1, d2;                 // the action's move per sub-shot along axis a1 / a2 (rob:403-409)
+    double dvec[3];                // the guided point's offset from the pose (bpw:865-880), see shots_begin
+    int facet_hint, last_tri;
+};
 
-    // ---- five chained sub-shots   rob:302-329 + 403-424
-    double cur_pose[3] = {S.pose[0], S.pose[1], S.pose[2]}, cur_norm[3];
-    tcp_orn_norm(S.pose, S.quat, cur_norm);
-    // pose and normal stay in vector registers (wave-uniform values): scalar registers are
-    // the scarce kind in this kernel, and every consumer is a vector instruction anyway
-    // (the per-shot deltas and the turning angle are read rarely: those three do live in scalar registers)
-    const double d1 = uni_d(delta1 / PAINT_PER_ACTION), d2 = uni_d(delta2 / PAINT_PER_ACTION);
-    new_angle = uni_d(new_angle);
+__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double delta1, double delta2, ShotCtx &X) {
+    X.cur_pose[0] = S.pose[0];
+    X.cur_pose[1] = S.pose[1];
+    X.cur_pose[2] = S.pose[2];
+    tcp_orn_norm(S.pose, S.quat, X.cur_norm);
+    // (the per-shot deltas and the turning angle are read rarely: those do live in scalar registers)
+    X.d1 = uni_d(delta1 / PAINT_PER_ACTION);
+    X.d2 = uni_d(delta2 / PAINT_PER_ACTION);
     // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
-    int facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
+    X.facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
     // The tool quaternion is a function of the tool normal alone (rob:93-100), so it is not carried through the
     // shots (eight vector registers): after the last one it is read from the record of the triangle that shot
     // hooked to, or recomputed from the normal after a miss -- the same arithmetic either way.
-    int last_tri = -1;
-    uint32_t n_succeeded_l = 0;
-    double *cen = wl.cen;
+    X.last_tri = -1;
     // the guided point's offset from the pose (bpw:865-880: d1 along axis a1, d2 * lwr along a2) is the same for the
     // five shots; the third component is -0.0, the one addend that leaves every double (either zero too) unchanged
     // (held in scalar registers: as three vector-register pairs it was what the act-and-step kernel spilled to scratch
     // and fetched back in every shot)
-    const double delta_2 = d2 * P.lwr;
-    const double dvec[3] = {uni_d(P.a1 == 0 ? d1 : (P.a2 == 0 ? delta_2 : -0.0)), uni_d(P.a1 == 1 ? d1 : (P.a2 == 1 ? delta_2 : -0.0)),
-                            uni_d(P.a1 == 2 ? d1 : (P.a2 == 2 ? delta_2 : -0.0))};
-#if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
-    for (int shot = 0; shot < 0; ++shot) {
-#else
-    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-#endif
-        // Issue priority by progress (s_setprio 3: shots 0-1, 2: shots 2-4, 1: painting, 0: observation; the two youngest
-        // waves of a SIMD one level higher from shot 2 on).  The SIMD's
-        // arbiter serves its oldest wave first: of the four envs that share a SIMD the youngest then ends 14 us after
-        // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
-        // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
-        if (shot <= 1) PRIO_BY_PROGRESS(3);
-        else PRIO_YOUNG_OLD(3, 2);
-        // bpw:865-880 get_guided_point
-        const double pt[3] = {cur_pose[0] + dvec[0], cur_pose[1] + dvec[1], cur_pose[2] + dvec[2]};
-        const double end[3] = {pt[0] + cur_norm[0], pt[1] + cur_norm[1], pt[2] + cur_norm[2]};
-        double t, hit[3], pos[3], orn[3], quat[4];
-        STAMP(PH_MATH);
+    const double delta_2 = X.d2 * P.lwr;
+    X.dvec[0] = uni_d(P.a1 == 0 ? X.d1 : (P.a2 == 0 ? delta_2 : -0.0));
+    X.dvec[1] = uni_d(P.a1 == 1 ? X.d1 : (P.a2 == 1 ? delta_2 : -0.0));
+    X.dvec[2] = uni_d(P.a1 == 2 ? X.d1 : (P.a2 == 2 ? delta_2 : -0.0));
+}
+
+// One sub-shot (rob:302-329 + bpw:865-880 + 525-534): guided point, ray, hook point -- or the tool-frame move after a
+// miss with the off-part bookkeeping of rob:292-300.  Advances X and S.pose; `center` = the shot centre (rob:277-278),
+// `quat` = the tool quaternion at the new pose (the ball painter never reads it: dead code there).
+template <bool KD>
+__device__ __forceinline__ void sub_shot(PartRef P, int lane, EnvState &S, ShotCtx &X, const WaveLds &wl, double center[3],
+                                         double quat[4] PROF_ARG) {
+    // bpw:865-880 get_guided_point
+    const double pt[3] = {X.cur_pose[0] + X.dvec[0], X.cur_pose[1] + X.dvec[1], X.cur_pose[2] + X.dvec[2]};
+    const double end[3] = {pt[0] + X.cur_norm[0], pt[1] + X.cur_norm[1], pt[2] + X.cur_norm[2]};
+    double t, hit[3], pos[3], orn[3];
+    STAMP(PH_MATH);
 #if defined(PRL_CUT) && PRL_CUT >= 5
-        bool on = true;
-        t = 0;
-        hit[0] = end[0] * 0.1 + pt[0] * 0.9, hit[1] = end[1] * 0.1 + pt[1] * 0.9, hit[2] = end[2] * 0.1 + pt[2] * 0.9;
+    bool on = true;
+    t = 0;
+    hit[0] = end[0] * 0.1 + pt[0] * 0.9, hit[1] = end[1] * 0.1 + pt[1] * 0.9, hit[2] = end[2] * 0.1 + pt[2] * 0.9;
 #else
-        bool on = ray_closest_wave(P, pt, end, lane, t, hit, facet_hint, wl.cand) >= 0;
+    bool on = ray_closest_wave(P, pt, end, lane, t, hit, X.facet_hint, wl.cand) >= 0;
 #endif
-        STAMP(PH_RAY);
-        double center[3];                                  // rob:277-278 shot centre
+    STAMP(PH_RAY);
 #if defined(PRL_CUT) && PRL_CUT >= 4
-        if (on) {
-            for (int k = 0; k < 3; ++k) pos[k] = hit[k] - 0.1 * cur_norm[k], orn[k] = cur_norm[k], center[k] = hit[k];
-            quat[0] = quat[1] = quat[2] = 0, quat[3] = 1;
-        }
-#else
-        if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, last_tri, wl.kd_heap PROF_PASS);
-#endif
-        if (!on) {
-            last_tri = -1;
-            orn[0] = cur_norm[0];
-            orn[1] = cur_norm[1];
-            orn[2] = cur_norm[2];
-            pose_orn_quat(orn, quat);
-            transform_point(cur_pose, quat, d2, d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
-            transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, center);
-            if (S.last_on_part) {                                    // rob:292-300
-                S.last_on_part = 0;
-            } else {
-                S.terminate_counter += 1;
-                if (S.terminate_counter > NOT_ON_PART_TERMINATE) S.terminate = 1;
-            }
-        } else {
-            S.last_on_part = 1;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cur_pose[k] = pos[k];
-            cur_norm[k] = orn[k];
-            S.pose[k] = pos[k];
-        }
-        // painting is deferred until all five centres are known
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (lane == 0) cen[3 * shot + k] = center[k];
-        STAMP(PH_MATH);
-        if constexpr (NORMAL) {
-            // rob:251-258, 280-285: one ray per cone beam from the tool to the beam's end point on the
-            // plane 0.2 ahead; bpw:562-566: every hit paints the sample nearest to it.  No hit at all:
-            // the reference returns early and leaves the last-shot set untouched.
-            int beam_hits = 0;
-            for (int b0 = 0; b0 < P.n_beams; b0 += 64) {          // 64 beams per trip, one per lane (prl_cone.hpp)
-                double bh[3];
-                const bool hit = cone_rays_lanes(P, pos, quat, b0, facet_hint, lane, wl.cand, bh PROF_PASS);
-                STAMP(PH_RAY);                                    // (stamped builds: the cone's rays count as 'ray',
-                uint64_t hm = ballot64(hit);                       //  its nearest-sample queries as 'paint', fallbacks as 'apply')
-                beam_hits += __popcll(hm);
-                // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle
-                // go through the wave-wide search.  Bits are collected in this wave's LDS mask row.
-                int sidx = nearest_sample_lane(P, bh, hit);
-                STAMP(PH_BALL);
-                if (__popcll(ballot64(sidx == -2)) > 3) nearest_samples_shared(P, bh, lane, sidx);   // (a recess: prl_cone.hpp)
-                uint64_t rest = ballot64(sidx == -2);
-                WCNT16(1, __popcll(rest));
-                WCNT16(3, __popcll(hm));
-                while (rest) {
-                    const int L = __builtin_ctzll(rest);
-                    rest &= rest - 1;
-                    const double h3[3] = {bcast_d(bh[0], L), bcast_d(bh[1], L), bcast_d(bh[2], L)};
-                    const int s2 = nearest_sample_wave(P, h3, lane);
-                    if (lane == L) sidx = s2;
-                }
-                if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&wl.mask[sidx >> 6]), 1ull << (sidx & 63));
-                STAMP(PH_APPLY);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int w = lane + 64 * k;
-                const uint64_t c = wl.mask[w];
-                wl.mask[w] = 0;                                // (clean for the next shot)
-                if (beam_hits > 0) {
-                    const uint64_t pw = wl.mask[256 + w], lw = wl.mask[512 + w];
-                    n_succeeded_l += __popcll(c & ~pw);
-                    wl.mask[256 + w] = pw | c;
-                    wl.mask[768 + w] |= c & ~lw;
-                    wl.mask[512 + w] = c;
-                }
-            }
-        }
+    if (on) {
+        for (int k = 0; k < 3; ++k) pos[k] = hit[k] - 0.1 * X.cur_norm[k], orn[k] = X.cur_norm[k], center[k] = hit[k];
+        quat[0] = quat[1] = quat[2] = 0, quat[3] = 1;
     }
-    // lane 0 wrote the shot centres to LDS, every lane reads them below: order the two within the wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (last_tri >= 0) {
-        const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)last_tri * (TRI_REC / 2);
+#else
+    if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, X.last_tri, wl.kd_heap PROF_PASS);
+#endif
+    if (!on) {
+        X.last_tri = -1;
+        orn[0] = X.cur_norm[0];
+        orn[1] = X.cur_norm[1];
+        orn[2] = X.cur_norm[2];
+        pose_orn_quat(orn, quat);
+        transform_point(X.cur_pose, quat, X.d2, X.d1, 0.0, pos);      // rob:317, tool frame [delta2, delta1, 0]
+        transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, center);
+        if (S.last_on_part) {                                    // rob:292-300
+            S.last_on_part = 0;
+        } else {
+            S.terminate_counter += 1;
+            if (S.terminate_counter > NOT_ON_PART_TERMINATE) S.terminate = 1;
+        }
+    } else {
+        S.last_on_part = 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        X.cur_pose[k] = pos[k];
+        X.cur_norm[k] = orn[k];
+        S.pose[k] = pos[k];
+    }
+    STAMP(PH_MATH);
+}
+
+// After the last sub-shot: the tool quaternion of the final pose (rob:93-100), see shots_begin.
+__device__ __forceinline__ void shots_end(PartRef P, EnvState &S, const ShotCtx &X) {
+    if (X.last_tri >= 0) {
+        const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)X.last_tri * (TRI_REC / 2);
         const f64x2 qa = rj[8], qb = rj[9];
         S.quat[0] = qa.x;
         S.quat[1] = qa.y;
         S.quat[2] = qb.x;
         S.quat[3] = qb.y;
     } else {
-        pose_orn_quat(cur_norm, S.quat);
+        pose_orn_quat(X.cur_norm, S.quat);
     }
-    PRIO_YOUNG_OLD(2, 1);
-    if constexpr (!NORMAL && !BIG) masks.template load<KW>(painted, last);
-    STAMP(PH_LOAD);
-    // bpw:568-577 fast_paint + _paint for the five shots
-    int succeeded = 0, pixel_counter = 0;
-    double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
-    if constexpr (HSI) {
-        paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
-                            succeeded_f, pixel_counter);
-    } else if constexpr (NORMAL) {
-        uint32_t pix_l = 0;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            painted[k] = wl.mask[256 + lane + 64 * k];
-            last[k] = wl.mask[512 + lane + 64 * k];
-            pix_l += __popcll(wl.mask[768 + lane + 64 * k]);
-        }
-        const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
-        succeeded = (int)(sums >> 32);
-        pixel_counter = (int)(sums & 0xffffffffu);
-    } else {
-        if constexpr (BIG) {
-            paint_shots_union(P, C.paint_radius, cen, lane, LdsWords{masks.painted, masks.last, masks.new_last, lane},
-                              succeeded, pixel_counter);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
-            uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
-#if !defined(PRL_CUT) || PRL_CUT < 2
-            paint_shots_union(P, C.paint_radius, cen, lane, RegWords<KW>{painted, last, new_last, lane}, succeeded,
-                              pixel_counter);
-#endif
-#pragma unroll
-            for (int k = 0; k < KW; ++k) last[k] = new_last[k];
-        }
-    }
-    STAMP(PH_BALL);
+}
+
+// The rest of a step once the shots are painted: robot bookkeeping (rob:352-358, 425-431), reward / penalty /
+// termination (rge:321-340, 289-304), observation (rge:306-319), episode statistics, in-kernel auto-reset
+// (rge:370-387), masks back through `masks`.  `succeeded_f` = newly painted samples of the five shots (HSI: the float
+// sum of deposited fractions), `pixel_counter` = size of the union of the shots' valid sets (rob:425).  Returns done.
+template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, typename MaskIO, typename RowIO>
+__device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
+                                           const double *state_rec, const MaskIO &masks, uint64_t painted[KW_MAX],
+                                           uint64_t last[KW_MAX], double succeeded_f, int pixel_counter, int counter_before,
+                                           double new_angle, int facet_hint, const RowIO &a, const WaveLds &wl PROF_ARG) {
+    constexpr bool BIG = KW == 0;
+    PRIO_YOUNG_DECL();
     if constexpr (LATE_ACC) load_state_accumulators(state_rec, S);
     const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
     S.last_angle = new_angle;
     S.facet_hint = facet_hint;
-    if constexpr (!HSI) succeeded_f = (double)succeeded;
     const double rate = pixel_counter ? succeeded_f / (double)pixel_counter : 0.0;           // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
 
@@ -361,6 +245,97 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     STAMP(PH_OBS);
     masks.template store<KW>(painted, last);
     return dn;
+}
+
+// Advances env `env` by one step (PAINT_METHOD 'fast': the ball query of bpw:568-570; the cone beams of
+// PAINT_METHOD 'normal' have their own kernel, prl_cone_step.hpp, around the same sub_shot / finish_step).  In: the
+// motion part of S (load_state_motion); with LATE_ACC the episode accumulators are read from `state_rec` only after
+// the five sub-shots (the per-step kernel: their scalar registers are then free during the shots), otherwise S is
+// complete on entry.  Out: S and the masks advanced (reset if the episode ended and C.auto_reset), the observation in
+// row `env` of a.obs (the post-reset one after an auto-reset, the terminal one then goes to a.final_obs if that is not
+// null), reward / done / info rows through lane 0; the output addresses are formed where they are used, so that they
+// hold no registers during the shots.  Returns done.
+//
+// The coverage masks are not touched by the five sub-shots, so they are fetched through `masks` (GlobalMasks: HBM,
+// LdsMasks: the fragment kernel's LDS copy) only when painting starts and put back after the observation: twelve
+// vector registers less during the shots.
+//
+// `a` (RowIO) names this step's output rows: obs / final_obs / reward / info / done / start_idx members that are
+// evaluated where they are used.  Both implementations read the kernel arguments through the constant address
+// space at that point; handing the kernel's by-value argument struct down by reference instead makes the compiler
+// copy all of it into registers at kernel entry.
+// HSI = COLOR_MODE 'HSI' (bpw:384-434): thickness bytes in a.thick, float "succeed counter" (prl_paint.hpp).
+// KD: parts of the batch may carry the reference's stale vertex kd-tree (prl_search.hpp nearest_vertex_kd).
+template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, typename MaskIO, typename RowIO>
+__device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
+                                        const double *state_rec, const MaskIO &masks, double delta1, double delta2,
+                                        double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
+    // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
+    constexpr bool BIG = KW == 0;
+    PRIO_YOUNG_DECL();
+    uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
+    if constexpr (BIG) masks.template load<KW>(painted, last);
+    const int counter_before = S.terminate_counter;
+
+    // ---- five chained sub-shots   rob:302-329 + 403-424
+    ShotCtx X;
+    shots_begin(P, S, delta1, delta2, X);
+    new_angle = uni_d(new_angle);
+    double *cen = wl.cen;
+#if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
+    for (int shot = 0; shot < 0; ++shot) {
+#else
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+#endif
+        // Issue priority by progress (s_setprio 3: shots 0-1, 2: shots 2-4, 1: painting, 0: observation; the two youngest
+        // waves of a SIMD one level higher from shot 2 on).  The SIMD's
+        // arbiter serves its oldest wave first: of the four envs that share a SIMD the youngest then ends 14 us after
+        // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
+        // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
+        if (shot <= 1) PRIO_BY_PROGRESS(3);
+        else PRIO_YOUNG_OLD(3, 2);
+        double center[3], quat[4];                         // rob:277-278 shot centre
+        sub_shot<KD>(P, lane, S, X, wl, center, quat PROF_PASS);
+        // painting is deferred until all five centres are known
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane == 0) cen[3 * shot + k] = center[k];
+    }
+    // lane 0 wrote the shot centres to LDS, every lane reads them below: order the two within the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    shots_end(P, S, X);
+    PRIO_YOUNG_OLD(2, 1);
+    if constexpr (!BIG) masks.template load<KW>(painted, last);
+    STAMP(PH_LOAD);
+    // bpw:568-577 fast_paint + _paint for the five shots
+    int succeeded = 0, pixel_counter = 0;
+    double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
+    if constexpr (HSI) {
+        paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
+                            succeeded_f, pixel_counter);
+    } else {
+        if constexpr (BIG) {
+            paint_shots_union(P, C.paint_radius, cen, lane, LdsWords{masks.painted, masks.last, masks.new_last, lane},
+                              succeeded, pixel_counter);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+#if !defined(PRL_CUT) || PRL_CUT < 2
+            paint_shots_union(P, C.paint_radius, cen, lane, RegWords<KW>{painted, last, new_last, lane}, succeeded,
+                              pixel_counter);
+#endif
+#pragma unroll
+            for (int k = 0; k < KW; ++k) last[k] = new_last[k];
+        }
+        succeeded_f = (double)succeeded;
+    }
+    STAMP(PH_BALL);
+    return finish_step<KW, GENSEC, LATE_ACC, HSI>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
+                                                  pixel_counter, counter_before, new_angle, X.facet_hint, a, wl PROF_PASS);
 }
 
 // Output rows of the per-step kernel: the launch's StepArgs, read from the kernel-argument segment when used.
