@@ -25,7 +25,8 @@ FLAGS = CFLAGS + ['-shared']
 JOBS = int(os.environ.get('PAINTRL_BUILD_JOBS', '0')) or min(8, os.cpu_count() or 1)
 
 # (object name, source file, extra flags)
-UNITS = [('host', 'paintrl_hip.hip', []), ('policy', 'policy_mlp.hip', []), ('k_big', 'k_big.hip', [])]
+UNITS = [('host', 'paintrl_hip.hip', []), ('policy', 'policy_mlp.hip', []), ('k_big', 'k_big.hip', []),
+         ('k_cone_beams', 'k_cone_beams.hip', [])]
 for _kw in (1, 2, 3, 4):
     UNITS += [('k_step%d' % _kw, 'k_step.hip', ['-DPRL_KW=%d' % _kw]), ('k_cone%d' % _kw, 'k_cone.hip', ['-DPRL_KW=%d' % _kw]),
               ('k_rollout%d' % _kw, 'k_rollout.hip', ['-DPRL_KW=%d' % _kw])]

@@ -17,6 +17,10 @@
 #include <new>
 #include <vector>
 
+#ifndef PRL_FINE_CELL
+#define PRL_FINE_CELL 2.0          // edge of a fine sample-grid cell in mean sample spacings (prl_cone.hpp)
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------- rayTestBatch drop-in: one wave per ray
@@ -88,6 +92,10 @@ struct PrlBatch {
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
+    double *cone_shots = nullptr, *cone_aux = nullptr;      // PAINT_METHOD 'normal' only (StepArgs)
+    int *cone_hits = nullptr, *cone_work = nullptr;
+    double *cone_far = nullptr;
+    int cone_nb = 0;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
@@ -311,6 +319,87 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
                     }
             UP(col_enbr, enbr.data(), enbr.size());
         }
+        // front-facet grid for the cone beams' walks (prl_cone.hpp): for the centre of every cell of a grid over the set's
+        // extent in the principal plane, the facet a line along axis a0 meets first coming from the tool's side; cells the
+        // set does not cover take the facet of the nearest covered cell.  Only a starting point: any facet is correct.
+        {
+            const int a0 = t->axis0, a1 = t->axis1, a2 = t->axis2;
+            if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2) return fail(PRL_E_INVALID, "axes must be a permutation of 0,1,2");
+            double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY, zsum = 0;
+            int n_real = 0;
+            for (int i = 0; i < d.n_col_pad; ++i) {
+                if (t->col_orient[i] == 0) continue;
+                const double *r = rec.data() + (size_t)i * 12;
+                for (int c = 0; c < 3; ++c) {
+                    double v[3];
+                    for (int k = 0; k < 3; ++k) v[k] = r[k] + (c == 1 ? r[3 + k] : (c == 2 ? r[6 + k] : 0.0));
+                    lo1 = std::fmin(lo1, v[a1]), hi1 = std::fmax(hi1, v[a1]);
+                    lo2 = std::fmin(lo2, v[a2]), hi2 = std::fmax(hi2, v[a2]);
+                    zsum += v[a0];
+                }
+                ++n_real;
+            }
+            d.hg_nx = d.hg_ny = 0;
+            if (n_real > 0 && hi1 > lo1 && hi2 > lo2 && t->start_pos && t->n_start > 0) {
+                const bool from_above = t->start_pos[a0] >= zsum / (3.0 * n_real);          // the tool's side of the part
+                double cell = 0.7 * std::sqrt((hi1 - lo1) * (hi2 - lo2) / (double)n_real);
+                while ((hi1 - lo1) / cell > 192 || (hi2 - lo2) / cell > 192) cell *= 1.5;
+                const int nx = (int)std::floor((hi1 - lo1) / cell) + 1, ny = (int)std::floor((hi2 - lo2) / cell) + 1;
+                std::vector<int32_t> g((size_t)nx * ny, -1);
+                for (int i = 0; i < d.n_col_pad; ++i) {
+                    if (t->col_orient[i] == 0) continue;
+                    const double *r = rec.data() + (size_t)i * 12;
+                    // the facet in the principal plane: p = q0 + u f1 + v f2; cells whose centre it covers
+                    const double q1 = r[a1], q2 = r[a2], f11 = r[3 + a1], f12 = r[3 + a2], f21 = r[6 + a1], f22 = r[6 + a2];
+                    const double den = f11 * f22 - f12 * f21;
+                    if (!(std::fabs(den) > 1e-14)) continue;                                 // edge-on
+                    const double x0 = std::fmin(q1, std::fmin(q1 + f11, q1 + f21)), x1 = std::fmax(q1, std::fmax(q1 + f11, q1 + f21));
+                    const double y0 = std::fmin(q2, std::fmin(q2 + f12, q2 + f22)), y1 = std::fmax(q2, std::fmax(q2 + f12, q2 + f22));
+                    const int cx0 = std::max(0, (int)std::floor((x0 - lo1) / cell - 0.5)), cx1 = std::min(nx - 1, (int)std::ceil((x1 - lo1) / cell));
+                    const int cy0 = std::max(0, (int)std::floor((y0 - lo2) / cell - 0.5)), cy1 = std::min(ny - 1, (int)std::ceil((y1 - lo2) / cell));
+                    for (int cy = cy0; cy <= cy1; ++cy)
+                        for (int cx = cx0; cx <= cx1; ++cx) {
+                            const double px = lo1 + (cx + 0.5) * cell - q1, py = lo2 + (cy + 0.5) * cell - q2;
+                            const double u = (px * f22 - py * f21) / den, v = (py * f11 - px * f12) / den;
+                            if (u < -1e-9 || v < -1e-9 || u + v > 1 + 1e-9) continue;
+                            const double z = r[a0] + u * r[3 + a0] + v * r[6 + a0];
+                            int32_t &slot = g[(size_t)cy * nx + cx];
+                            if (slot >= 0) {
+                                const double *ro = rec.data() + (size_t)slot * 12;
+                                const double qo1 = ro[a1], qo2 = ro[a2], o11 = ro[3 + a1], o12 = ro[3 + a2], o21 = ro[6 + a1], o22 = ro[6 + a2];
+                                const double deno = o11 * o22 - o12 * o21;
+                                const double pxo = lo1 + (cx + 0.5) * cell - qo1, pyo = lo2 + (cy + 0.5) * cell - qo2;
+                                const double uo = (pxo * o22 - pyo * o21) / deno, vo = (pyo * o11 - pxo * o12) / deno;
+                                const double zo = ro[a0] + uo * ro[3 + a0] + vo * ro[6 + a0];
+                                if (from_above ? !(z > zo) : !(z < zo)) continue;
+                            }
+                            slot = i;
+                        }
+                }
+                // cells beside the set: the facet of the nearest covered cell (breadth-first from the covered ones)
+                std::vector<int> queue;
+                for (int c = 0; c < nx * ny; ++c)
+                    if (g[c] >= 0) queue.push_back(c);
+                for (size_t h = 0; h < queue.size(); ++h) {
+                    const int c = queue[h], cx = c % nx, cy = c / nx;
+                    static const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
+                    for (int k = 0; k < 4; ++k) {
+                        const int ex = cx + dx[k], ey = cy + dy[k];
+                        if (ex < 0 || ex >= nx || ey < 0 || ey >= ny || g[(size_t)ey * nx + ex] >= 0) continue;
+                        g[(size_t)ey * nx + ex] = g[c];
+                        queue.push_back(ey * nx + ex);
+                    }
+                }
+                if (!queue.empty()) {
+                    d.hg_o1 = lo1;
+                    d.hg_o2 = lo2;
+                    d.hg_inv = 1.0 / cell;
+                    d.hg_nx = nx;
+                    d.hg_ny = ny;
+                    UP(hg_facet, g.data(), g.size());
+                }
+            }
+        }
     }
     d.n_col_chunks = t->n_col_chunks;
     if (d.n_col_chunks != d.n_col_pad / 64) return fail(PRL_E_INVALID, "n_col_chunks must be n_collision_pad / 64");
@@ -362,7 +451,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
                 hi2 = std::fmax(hi2, x2[i]);
             }
         if ((int)real.size() != t->n_samples) return fail(PRL_E_INVALID, "word_valid marks %zu samples, n_samples is %d", real.size(), t->n_samples);
-        double cell = 2.0 * std::sqrt(std::fmax((hi1 - lo1) * (hi2 - lo2), 1e-12) / (double)real.size());
+        double cell = PRL_FINE_CELL * std::sqrt(std::fmax((hi1 - lo1) * (hi2 - lo2), 1e-12) / (double)real.size());
         cell = std::fmax(cell, 1e-6);
         while (((hi1 - lo1) / cell + 1) * ((hi2 - lo2) / cell + 1) > 4.0e6) cell *= 2;
         const double inv = 1.0 / cell;
@@ -392,6 +481,27 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
         UP(fg_rec, rec.data(), rec.size());
+        {   // chessboard distance of every cell to the nearest cell that holds a sample (breadth-first over 8 neighbours)
+            std::vector<uint8_t> gap((size_t)nx * ny, 255);
+            std::vector<int> queue;
+            for (int c = 0; c < nx * ny; ++c)
+                if (start[(size_t)c + 1] > start[c]) {
+                    gap[c] = 0;
+                    queue.push_back(c);
+                }
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int c = queue[h], cx = c % nx, cy = c / nx;
+                if (gap[c] >= 254) continue;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ex = cx + dx, ey = cy + dy;
+                        if (ex < 0 || ex >= nx || ey < 0 || ey >= ny || gap[(size_t)ey * nx + ex] != 255) continue;
+                        gap[(size_t)ey * nx + ex] = (uint8_t)(gap[c] + 1);
+                        queue.push_back(ey * nx + ex);
+                    }
+            }
+            UP(fg_gap, gap.data(), gap.size());
+        }
     }
     {   // outline of the collision set in the principal plane (Andrew's monotone chain over the projected corners)
         std::vector<std::pair<double, double>> pts;
@@ -502,6 +612,12 @@ StepArgs base_args(PrlBatch *b) {
     a.last = b->last;
     a.thick = b->thick;
     a.state = b->state;
+    a.cone_shots = b->cone_shots;
+    a.cone_aux = b->cone_aux;
+    a.cone_hits = b->cone_hits;
+    a.cone_work = b->cone_work;
+    a.cone_far = b->cone_far;
+    a.cone_nb = b->cone_nb;
     return a;
 }
 
@@ -523,7 +639,6 @@ PrlStepSel step_sel(const PrlBatch *b) {
     sel.hsi = b->cfg.color_mode == PRL_COLOR_HSI ? 1 : 0;
     sel.kd = b->kd ? 1 : 0;
     sel.wide = b->n_envs <= b->resident_envs ? 1 : 0;
-    sel.max_beams = b->max_beams;
     return sel;
 }
 
@@ -653,6 +768,21 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         e = hipMalloc(reinterpret_cast<void **>(&b->thick), mask_bytes * 8);        // one byte per sample
         if (e == hipSuccess) e = hipMemset(b->thick, 255, mask_bytes * 8);
     }
+    if (e == hipSuccess && cfg->paint_method == PRL_PAINT_NORMAL) {
+        // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
+        b->cone_nb = ((b->max_beams + 63) / 64) * 64;
+        const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
+        e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_hits), sizeof(int) * PAINT_PER_ACTION * (size_t)b->cone_nb * n_envs);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * (items + 4));
+        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * (items + 4));
+        // hit points handed to the far search: 64 per env and step (a typical step has a dozen; a full list sends the
+        // rest through the general code)
+        const int far_cap = (int)std::min<size_t>((size_t)n_envs * 64, (size_t)1 << 26);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_far), sizeof(double) * 4 * (size_t)far_cap);
+        if (e == hipSuccess) e = hipMemcpy(b->cone_work + 2, &far_cap, sizeof(int), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemset(b->painted, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->last, 0, mask_bytes);
     if (e == hipSuccess) e = hipMemset(b->state, 0, state_bytes);
@@ -684,6 +814,11 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
+    (void)hipFree(b->cone_shots);
+    (void)hipFree(b->cone_aux);
+    (void)hipFree(b->cone_hits);
+    (void)hipFree(b->cone_work);
+    (void)hipFree(b->cone_far);
     for (double *p : b->reset_obs) (void)hipFree(p);
     (void)hipFree(b->state);
     delete b;
@@ -737,7 +872,14 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
         HIP_TRY(hipEventRecord(b->ev_start[b->ev_used], s));
     }
     const PrlStepSel sel = step_sel(b);
-    const int e = normal ? PRL_KW_SWITCH(b->kw, cone)(&a, &sel, stream) : PRL_KW_SWITCH(b->kw, step)(&a, &sel, stream);
+    int e;
+    if (normal) {                                  // tool path, beams, the beams' leftovers, fold + finish (k_cone_beams.hip)
+        e = prl_kc_path(&a, sel.kd, sel.wide, stream);
+        if (!e) e = prl_kc_beams(&a, stream);
+        if (!e) e = PRL_KW_SWITCH(b->kw, cone)(&a, &sel, stream);
+    } else {
+        e = PRL_KW_SWITCH(b->kw, step)(&a, &sel, stream);
+    }
     if (e) return launch_failed(e, "prl_batch_step");
     if (timed) {
         HIP_TRY(hipEventRecord(b->ev_stop[b->ev_used], s));

@@ -17,8 +17,24 @@
 
 namespace {
 
+// -DPRL_CONE_TRACE (tools/cone_stats.py): how many beams take which path, summed over a run (global counters, read back
+// through prl_debug_cone_stats of the k_cone_beams unit).  The product build defines none of this.
+#ifdef PRL_CONE_TRACE
+__device__ unsigned long long g_cone_stat[16];
+#define CONE_STAT(k, v)                                                              \
+    do {                                                                             \
+        const unsigned long long v_ = (unsigned long long)(v);                       \
+        if ((threadIdx.x & 63) == 0 && v_) atomicAdd(&g_cone_stat[k], v_);           \
+    } while (0)
+#else
+#define CONE_STAT(k, v)
+#endif
+#define CONE_CNT_ARG
+#define CONE_CNT_PASS
+#define CONE_CNT(slot, v)
+
 #ifndef PRL_WALK_STEPS
-#define PRL_WALK_STEPS 8
+#define PRL_WALK_STEPS 12
 #endif
 constexpr int CONE_WALK_STEPS = PRL_WALK_STEPS;
 #ifndef PRL_CONE_JOINT_FROM
@@ -32,11 +48,14 @@ constexpr int CONE_FAR_K0 = PRL_CONE_FAR_K0;
 #define FAR_BAND 4.0e-6f              // m^2, see nearest_samples_shared             // first widening (fine cells) of the shared far scan     // more stragglers than this in a trip: searched together
 #define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
 
-// One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0): Moller-Trumbore on
-// the facet record, arithmetic as in mt_rec.  Returns 1 = entered at an interior point (t, exact closest hit),
-// 0 = keep walking (`next` = the facet across the most violated edge, or -1), -1 = give up (degenerate / behind).
-__device__ __forceinline__ int cone_walk_step(PartRef P, int i, const double o[3], double d0, double d1, double d2,
-                                              double dd, double &t_out, int &rank_out, int &next) {
+#define CONE_SIL_MIN_COS2 1.0e-6     // squared cosine between beam and the normal of a facet counted as facing away from it
+
+// One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0), reached across an
+// edge of facet `prev` (-1: the walk starts here): Moller-Trumbore on the facet record, arithmetic as in mt_rec.
+// Returns 1 = entered at an interior point (t, exact closest hit), 2 = proven miss, 0 = keep walking (`next` = the
+// facet across the most violated edge, or -1), -1 = give up (degenerate / behind).
+__device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const double o[3], double d0, double d1, double d2,
+                                              double dd, double &t_out, int &rank_out, int &next, bool &solid) {
     const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
     const int i6 = i * 6;
     const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4),
@@ -57,21 +76,45 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, const double o[3
     const double q2 = s0 * e11 - s1 * e10;
     const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
     const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-    const bool entering = orient * det > 0 && det * det >= FACET_MIN_COS2 * dd * nn;
-    if (!entering) {
-        // The walk has gone over the hull's horizon (or grazes).  The hull lies on the inner side of this facet's
-        // plane: if both ends of the beam are clear of the plane on the OUTER side, by more than any tolerance of the
-        // triangle tests, the beam misses the whole set -- no search needed.  (Most beams that miss pass beside the
-        // part; the walk ends on a rim facet whose plane separates them.)
+    const bool front = orient * det > 0;                      // the beam meets this facet's plane from outside
+    solid = front && det * det >= FACET_MIN_COS2 * dd * nn;   // ... at more than a grazing angle
+    if (!solid) {
+        // The walk has reached the hull's horizon (or grazes).  Two certificates that the beam misses the whole set, by
+        // more than any tolerance of the triangle tests -- then no search is needed:
+        // (a) the hull lies on the inner side of this facet's plane: both ends of the beam clear of it on the OUTER side;
         const double n0 = e11 * e22 - e12 * e21, n1 = e12 * e20 - e10 * e22, n2 = e10 * e21 - e11 * e20;   // e1 x e2
         const double so = ((s0 * n0 + s1 * n1) + s2 * n2) * orient;                     // origin, outward if > 0
         const double se = so + ((d0 * n0 + d1 * n1) + d2 * n2) * orient;                // end point
         const double clear = CONE_MISS_MARGIN * CONE_MISS_MARGIN * nn;                  // (distance margin)^2 |n|^2
         if (so > 0 && se > 0 && so * so > clear && se * se > clear) return 2;
-        return -1;
+        // (b) the edge the walk just crossed is a SILHOUETTE edge of the hull as seen along the beam: the facet it left
+        // faces the beam (`prev` is only passed for a facet the beam enters at more than a grazing angle), this one
+        // faces away.  The plane through such an edge that contains the beam's direction supports the hull (its
+        // normal lies between the two facets' outward normals), so a LINE that runs on its outer side, more than the
+        // margin away, misses the hull -- most beams that miss pass beside the part and end exactly like this.
+        if (!front && prev >= 0 && orient * det < 0 && det * det >= CONE_SIL_MIN_COS2 * dd * nn) {
+            const int b0 = ldg(P.col_enbr, 3 * i), b1 = ldg(P.col_enbr, 3 * i + 1), b2 = ldg(P.col_enbr, 3 * i + 2);
+            const int k = b0 == prev ? 0 : (b1 == prev ? 1 : (b2 == prev ? 2 : -1));
+            if (k >= 0) {
+                // edge k of this facet (part_fill: 0 = v0 .. v0 + e2, 1 = v0 .. v0 + e1, 2 = v0 + e1 .. v0 + e2): a point
+                // of it relative to the beam's origin, its direction, and the facet's third corner relative to that point
+                const double a0 = k == 2 ? s0 - e10 : s0, a1 = k == 2 ? s1 - e11 : s1, a2 = k == 2 ? s2 - e12 : s2;     // o - point
+                const double g0 = k == 0 ? e20 : (k == 1 ? e10 : e20 - e10), g1 = k == 0 ? e21 : (k == 1 ? e11 : e21 - e11),
+                             g2 = k == 0 ? e22 : (k == 1 ? e12 : e22 - e12);
+                const double c0 = k == 0 ? e10 : (k == 1 ? e20 : -e10), c1 = k == 0 ? e11 : (k == 1 ? e21 : -e11),
+                             c2 = k == 0 ? e12 : (k == 1 ? e22 : -e12);
+                const double m0 = g1 * d2 - g2 * d1, m1 = g2 * d0 - g0 * d2, m2 = g0 * d1 - g1 * d0;               // edge x beam
+                const double side_o = (a0 * m0 + a1 * m1) + a2 * m2, side_p = (c0 * m0 + c1 * m1) + c2 * m2;
+                const double mm = (m0 * m0 + m1 * m1) + m2 * m2;
+                if (side_o * side_p < 0 && side_o * side_o > CONE_MISS_MARGIN * CONE_MISS_MARGIN * mm) return 2;
+            }
+        }
+        if (!front) return prev < 0 ? -2 : -3;               // (the codes only matter to the statistics of diagnostic builds)
+        // a facet met at a grazing angle decides nothing, but the walk may pass through it
     }
-    if (!(t >= 0.0)) return -1;                              // behind the origin
+    if (!(t >= 0.0)) return -4;                              // behind the origin
     if (u >= m && v >= m && (u + v) <= 1.0 - m) {
+        if (!solid) return -5;                               // a grazing entry decides nothing (the walk may pass through such facets)
         // entered at an interior point: the closest hit of the whole set (ray_closest_wave's single-facet criterion);
         // beyond the beam's end point it means the beam stops short of the part: a miss
         if (!(t <= 1.0)) return 2;
@@ -132,34 +175,73 @@ __device__ void rays_general_lanes(PartRef P, const double o[3], const double ds
     tri_out = best_i;
 }
 
-// The rays of beams b0 + lane: hit[3] / t of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray.
-__device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                int *cand_lds, double hit[3]) {
+// The beams b0 + lane of the cone at tool pose (pos, quat) (rob:251-258): end point `dst` of this lane's beam, and its walk
+// over the hull.  Returns the lane's state: 1 = hit at parameter t (exact closest hit of the whole set), 2 = no beam, or
+// a proven miss, 3 = not settled (the caller searches).
+__device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int lane,
+                                               double dst[3], double &t) {
     const int bm = b0 + lane;
     const bool have = bm < P.n_beams;
-    double dst[3] = {pos[0], pos[1], pos[2]};
+    dst[0] = pos[0], dst[1] = pos[1], dst[2] = pos[2];
     if (have) transform_point(pos, quat, ldg(P.beams, 3 * bm), ldg(P.beams, 3 * bm + 1), ldg(P.beams, 3 * bm + 2), dst);
     const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
     const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
-    double t = INFINITY;
-    int state = have ? 0 : 2;                       // 0 walking, 1 hit, 2 finished without a hit (no beam), 3 -> wave-wide search
-    if (P.col_convex && hint >= 0) {
-        int f = hint, rk = 0;
+    t = INFINITY;
+    int state = have ? 0 : 2;                       // 0 walking
+    if (P.col_convex && P.hg_nx > 0) {
+        // every lane starts on the facet the front-facet grid (part_fill) names for the middle of its beam -- the tool hovers
+        // one hook distance above the part and the beams are two long, so that is about where it lands: one to three steps
+        // instead of a walk from the facet under the tool to the rim of the cone, and a start for the beams of a tool
+        // that has left the part (whose own ray missed)
+        const double m1 = sel3(pos[0], pos[1], pos[2], P.a1) + 0.5 * sel3(d0, d1, d2, P.a1);
+        const double m2 = sel3(pos[0], pos[1], pos[2], P.a2) + 0.5 * sel3(d0, d1, d2, P.a2);
+        int cx = cell_coord(m1, P.hg_o1, P.hg_inv, P.hg_nx), cy = cell_coord(m2, P.hg_o2, P.hg_inv, P.hg_ny);
+        cx = cx < 0 ? 0 : (cx > P.hg_nx - 1 ? P.hg_nx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > P.hg_ny - 1 ? P.hg_ny - 1 : cy);
+        int f = have ? ldg(P.hg_facet, cy * P.hg_nx + cx) : -1, prev = -1, rk = 0;
+        if (have && f < 0) state = 3;
+        CONE_STAT(1, __popcll(ballot64(have)));
         for (int step = 0; step < CONE_WALK_STEPS; ++step) {
             if (ballot64(state == 0) == 0) break;
+            CONE_STAT(13, 1);
+            CONE_STAT(15, __popcll(ballot64(state == 0)));
             if (state == 0) {
                 int next;
-                const int r = cone_walk_step(P, f, pos, d0, d1, d2, dd, t, rk, next);
+                bool solid;
+                const int r = cone_walk_step(P, f, prev, pos, d0, d1, d2, dd, t, rk, next, solid);
+                CONE_STAT(5, __popcll(ballot64(r == -1)));
+                CONE_STAT(6, __popcll(ballot64(r == -2)));
+                CONE_STAT(7, __popcll(ballot64(r == -3)));
+                CONE_STAT(8, __popcll(ballot64(r == -4)));
+                CONE_STAT(9, __popcll(ballot64(r == 0 && next < 0)));
                 if (r == 1) state = 1;
                 else if (r == 2) state = 2;
                 else if (r < 0 || next < 0) state = 3;
-                else f = next;
+                else {
+                    prev = solid ? f : -1;                   // (the silhouette certificate needs a facet that is entered for sure)
+                    f = next;
+                }
             }
         }
+        CONE_STAT(10, __popcll(ballot64(state == 0)));
         if (state == 0) state = 3;
+        CONE_STAT(2, __popcll(ballot64(state == 1)));
+        CONE_STAT(3, __popcll(ballot64(state == 2 && have)));
+        CONE_STAT(4, __popcll(ballot64(state == 3)));
     } else if (have) {
         state = 3;
     }
+    return state;
+}
+
+// The rays of beams b0 + lane: hit[3] of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray (where
+// the wave-wide searches of leftover rays start).
+__device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
+                                int *cand_lds, double hit[3] CONE_CNT_ARG) {
+    const bool have = b0 + lane < P.n_beams;
+    double dst[3], t;
+    int state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
+    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
 #ifdef PRL_FORCE_GENERAL_RAY
     if (have) state = 3;
 #endif
@@ -199,7 +281,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     }
     // the stragglers (edge and vertex hits, and every miss), together
     const uint64_t todo = ballot64(state == 3);
-    WCNT16(0, __popcll(todo));
+    CONE_CNT(0, __popcll(todo));                     // rays the walk did not settle
     if (__popcll(todo) > CONE_JOINT_FROM) {
         double tw;
         int tri;
@@ -232,26 +314,42 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 
 // ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1), one hit point per lane
 // The nearest sample of this lane's point `pt` (if `want`), exact, equal distances resolved to the lowest reference
-// index -- as nearest_sample_wave, but 64 queries at once: each lane scans the (2k+1)^2 block of FINE grid cells around
+// index -- as nearest_sample_wave, but 64 queries at once: each lane scans the (2r+1)^2 block of FINE grid cells around
 // its point (PartDev::fg_*: ~4 samples a cell, so a 3 x 3 block holds ~36 candidates where the painter's own sample
 // grid holds ~1 350), rows as contiguous record ranges, four records per trip so that their reads travel together.
-// A sample outside the block is more than k cells away in the principal plane: the best of the block is the answer
-// once it lies within k * 0.99 * cell.  Returns the device position of the sample, -1 if not `want`, or -2 if three
-// rings did not settle it (a hit point centimetres off the sampled surface): the caller asks nearest_sample_wave.
-__device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
+// A sample outside the block is more than r cells away in the principal plane: the best of the block is the answer
+// once it lies within r * 0.99 * cell.  r starts at 1 -- or, where the collision hull spans a hole or a recess of the
+// part and every hit lies centimetres from the samples, at what PartDev::fg_gap (cells to the nearest cell that holds a
+// sample) says will be needed; a block whose best does not settle the query names the radius that will.  Returns the
+// device position of the sample, -1 if not `want`, or -2 if that did not end within CONE_RING_MAX cells / three
+// blocks: the caller asks the wave-wide searches.
+#define CONE_RING_MAX 48
+// G > 1 (the far kernel): G adjacent lanes share one query -- same `pt` and `want` in all of them, lane `sub` of the
+// group takes every G-th row of the block, the group's best is combined at the end (every lane of it returns the same).
+template <bool FAR, int G = 1>
+__device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3], bool want, int sub = 0) {
+    constexpr int RMAX = FAR ? CONE_RING_MAX : 3;     // the beams kernel's common case stops at three rings (prl_cone.hpp header)
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     int result = want ? -2 : -1;
     bool open = want;
-    for (int ring = 1; ring <= 3; ++ring) {
+    int r = 1;
+    if (FAR && want) {
+        const int ccx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), ccy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
+        const int gap = (int)ldg(P.fg_gap, ccy * P.fg_nx + ccx);
+        r = gap <= 1 ? 1 : gap + 2;
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+        if (open && r > RMAX) open = false;                           // (stays -2)
         if (ballot64(open) == 0) break;
+        const int rmax = -wave_min_i(open ? -r : 0);                  // wave-uniform trip count, per-lane ranges
         double best_d = INFINITY;
         int best_rank = 0x7fffffff, best_pos = -1;
-        const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.fg_nx - 1 ? P.fg_nx - 1 : icx + ring;
-        for (int dy = -ring; dy <= ring; ++dy) {                    // wave-uniform trip count, per-lane ranges
-            const int cy = icy + dy;
-            const bool row_ok = open && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
+        const int cx0 = icx - r < 0 ? 0 : icx - r, cx1 = icx + r > P.fg_nx - 1 ? P.fg_nx - 1 : icx + r;
+        for (int dy0 = -rmax; dy0 <= rmax; dy0 += G) {
+            const int dy = dy0 + sub, cy = icy + dy;
+            const bool row_ok = open && dy >= -r && dy <= r && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
             const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
             const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
             for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4) {
@@ -277,10 +375,26 @@ __device__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
                 }
             }
         }
-        const double lim = ring * P.fg_accept;
+        if constexpr (G > 1) {                                        // the group's best: (distance, rank) lexicographic
+#pragma unroll
+            for (int m = 1; m < G; m <<= 1) {
+                const double od = __hiloint2double(__shfl_xor(__double2hiint(best_d), m), __shfl_xor(__double2loint(best_d), m));
+                const int ork = __shfl_xor(best_rank, m), opos = __shfl_xor(best_pos, m);
+                if (od < best_d || (od == best_d && ork < best_rank)) {
+                    best_d = od;
+                    best_rank = ork;
+                    best_pos = opos;
+                }
+            }
+        }
+        const double lim = r * P.fg_accept;
         if (open && best_pos >= 0 && best_d <= lim * lim) {
             result = best_pos;
             open = false;
+        } else if (open) {
+            // the block that will settle it: its radius times 0.99 cells reaches the best found so far
+            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : 2 * r + 2;
+            r = need > r ? need : r + 1;
         }
     }
 #ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the wave-wide search
@@ -362,16 +476,17 @@ __device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, cons
 // One trip of a shot: the beams b0 + lane of the cone at tool pose (pos, quat) -- the device position of the sample each
 // lane's beam paints (bpw:562-566: the sample nearest to the hit point), or -1 (no such beam, or it misses the part).
 __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                         int *cand_lds) {
+                                         int *cand_lds CONE_CNT_ARG) {
     double bh[3];
-    const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh);
-    WCNT16(3, __popcll(ballot64(hit)));
+    const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh CONE_CNT_PASS);
+    CONE_CNT(3, __popcll(ballot64(hit)));             // beams that hit the part
     // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle go through
     // the wave-wide search
-    int sidx = nearest_sample_lane(P, bh, hit);
+    int sidx = nearest_sample_lane<true>(P, bh, hit);
+    CONE_CNT(1, __popcll(ballot64(sidx == -2)));      // hit points three rings of the fine grid did not settle
     if (__popcll(ballot64(sidx == -2)) > 3) nearest_samples_shared(P, bh, lane, sidx);   // (a recess of the part)
     uint64_t rest = ballot64(sidx == -2);
-    WCNT16(1, __popcll(rest));
+    CONE_CNT(2, __popcll(rest));                      // ... and the shared scan neither: one wave-wide search each
     while (rest) {
         const int L = __builtin_ctzll(rest);
         rest &= rest - 1;
@@ -380,6 +495,22 @@ __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const d
         if (lane == L) sidx = s2;
     }
     return sidx;
+}
+
+// The common case of cone_trip alone, for the beams kernel (k_cone_beams.hip): walk + the fine grid's three rings, nothing
+// wave-wide and nothing long.  Per lane: `state` as cone_walk_lanes returns it (3: a ray the walk left over), `bh` the
+// hit point if state = 1, `sidx` as cone_trip returns it where the lane is settled, or -2: a hit point centimetres from
+// every sample (the collision hull spans a hole or a recess of the part there).
+__device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], const double quat[4], int b0, int lane,
+                                               int &state, double bh[3], int &sidx) {
+    double dst[3], t;
+    state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
+    bh[0] = pos[0] + t * (dst[0] - pos[0]);
+    bh[1] = pos[1] + t * (dst[1] - pos[1]);
+    bh[2] = pos[2] + t * (dst[2] - pos[2]);
+    sidx = nearest_sample_lane<false>(P, bh, state == 1);
+    CONE_STAT(0, 1);
+    CONE_STAT(11, __popcll(ballot64(sidx == -2)));
 }
 
 }  // namespace

@@ -61,6 +61,7 @@ struct PartDev {
     int fg_nx, fg_ny;
     gint_p fg_start;              // [fg_nx * fg_ny + 1]
     gdouble_p fg_rec;             // [n_samples][4]
+    gu8_p fg_gap;                 // [fg_nx * fg_ny]: cells (chessboard distance, capped at 255) to the nearest cell holding a sample
     // outline of the collision set in the principal plane (convex polygon, derived in part_fill) and its extent along
     // the third axis: a beam whose stretch inside that slab projects outside the outline misses the part (prl_cone.hpp)
     int n_outline;                // edges, 0 = no test; the table is padded to a multiple of 64 rows
@@ -96,6 +97,11 @@ struct PartDev {
     int col_convex, nbr_width;
     gint_p col_nbr, col_orient;
     gint_p col_enbr;              // convex sets: [n_col_pad][3] facet across the edge u = 0 / v = 0 / u + v = 1, or -1 (derived)
+    // convex sets: the facet met by a line along axis a0 through the centre of each cell of a grid over the set's outline
+    // (the one on the tool's side; cells beside the set hold their nearest neighbour's): where a cone beam's walk starts
+    double hg_o1, hg_o2, hg_inv;
+    int hg_nx, hg_ny;             // 0: no grid
+    gint_p hg_facet;              // [hg_ny][hg_nx] (derived in part_fill)
     gdouble_p col_rec;            // convex sets: [n_col_pad][12] v0 e1 e2 | edge margin | |e1 x e2|^2 | orient (derived in part_fill)
     int n_col_chunks;
     gfloat_p col_chunk_bbox;
@@ -132,6 +138,14 @@ struct StepArgs {
     uint8_t *done;
     const int *start_idx;
     const uint8_t *reset_mask;
+    // PAINT_METHOD 'normal' only: what the three cone-beam kernels of a step hand to each other (k_cone_beams.hip)
+    double *cone_shots;           // [n_envs][5][8]: tool pose after each sub-shot (pos, quat) | {i32 facet hint, 0}
+    double *cone_aux;             // [n_envs][2]: new turning angle | {i32 off-part counter before the step, i32 facet hint}
+    int *cone_hits;               // [n_envs][5][cone_nb]: device position of the sample each beam paints, or -1
+    int *cone_work;               // [0] = number of beam trips handed to the general search, [1] = number of hit points handed
+                                  // to the far search, [2] = capacity of cone_far, [4 ..] = the trips' ids
+    double *cone_far;             // [capacity][4]: hit point x y z | {i32 index into cone_hits, i32 part id}
+    int cone_nb;                  // beams per shot, padded to 64 (the largest beam count of the batch's parts)
 };
 
 // ---------------------------------------------------------------- table loads

@@ -17,7 +17,6 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
     int hsi;                         // COLOR_MODE 'HSI'
     int kd;                          // some part carries the reference's stale vertex kd-tree
     int wide;                        // eight envs per workgroup (the whole launch is resident at once)
-    int max_beams;                   // cone beams: the largest beam count of the batch's parts (sizes the hit lists)
 };
 
 #define PRL_K_PROTOS(KW)                                                                                               \
@@ -30,6 +29,10 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
     PRL_HIDDEN int prl_k##KW##_act_step(const void *act_step_args, size_t policy_lds, int kd, void *stream);           \
     PRL_HIDDEN int prl_k##KW##_rollout_policy(const void *policy_fragment_args, size_t policy_lds, int kd, void *stream); \
     PRL_HIDDEN int prl_k##KW##_rollout_fragment(const void *fragment_args, int kd, void *stream);
+
+// PAINT_METHOD 'normal': the tool path and the beams of a step (k_cone_beams.hip); prl_k<KW>_cone finishes it
+PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream);
+PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream);
 
 PRL_K_PROTOS(0)
 PRL_K_PROTOS(1)

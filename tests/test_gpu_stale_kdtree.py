@@ -78,13 +78,83 @@ def test_stale_tree_on_a_large_part_and_in_a_mixed_batch():
     env.close()
 
 
-def test_stale_tree_limits_are_reported():
-    from paintrl_amd import _lib
+@pytest.mark.parametrize('kw,n,steps', [(dict(paint_method='normal'), 40, 8),
+                                        (dict(paint_method='normal', obs_mode='grid', overlap_penalty=True), 24, 6),
+                                        (dict(color_mode='HSI'), 96, 30)])
+def test_stale_tree_composes_with_cone_beams_and_thickness(kw, n, steps):
+    """The reference's own sheet (square.urdf, Part_NO 1) carries moved vertex rows: PAINT_METHOD 'normal' and
+    COLOR_MODE 'HSI' have to work on such parts too.  HSI rewards to 1e-12 (summation order), everything else exact."""
     tables = synthetic_tables('test')
-    with pytest.raises(_lib.PaintRLError, match='kd-tree'):
-        _env(tables, 4, paint_method='normal')
-    with pytest.raises(_lib.PaintRLError, match='kd-tree'):
-        _env(tables, 4, color_mode='HSI')
+    sp = start_points_for(tables, 'all')
+    hsi = kw.get('color_mode') == 'HSI'
+    env = _env(tables, n, sp, max_possible_point=14000, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=14000, **kw)
+    rng = np.random.RandomState(13)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        if hsi:
+            assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=1e-12) and np.array_equal(env.thickness(), orc.thick)
+        else:
+            assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(i.cpu().numpy(), ii), 'reward, step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    assert np.array_equal(env.parts[0].mask_to_canonical(words), np.stack([orc.painted_bits(e) for e in range(n)]))
+    env.close()
+
+
+def test_stale_tree_in_the_rollout_kernels():
+    """prl_rollout_fragment (given actions and with the policy) and prl_batch_act_step on a part with the stale tree:
+    rows bit for bit those of one prl_batch_step (+ prl_policy_act) launch per step."""
+    import torch
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    tables = synthetic_tables('test')
+    sp = start_points_for(tables, 'all')
+    n, T = 150, 30
+    kw = dict(auto_reset=True, seed=21, max_possible_point=14000)
+    env_a, env_b = _env(tables, n, sp, **kw), _env(tables, n, sp, **kw)
+    start = np.random.RandomState(1).randint(0, len(sp), size=n)
+    o0 = env_a.reset(start_idx=start).clone()
+    env_b.reset(start_idx=start)
+    dev, od = env_a.device, env_a.obs_dim
+    f64 = dict(dtype=torch.float64, device=dev)
+    obs, fin = torch.zeros((T + 1, n, od), **f64), torch.zeros((T, n, od), **f64)
+    rew, info = torch.zeros((T, n), **f64), torch.zeros((T, n, 2), **f64)
+    done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    act = torch.randint(0, 4, (T, n), generator=gen, device=dev, dtype=torch.int32)
+    obs[0].copy_(o0)
+    env_a.rollout_fragment(T, obs, fin, rew, done, info, act)
+    torch.cuda.synchronize()
+    for t in range(T):
+        o, r, d, i = env_b.step(act[t])
+        assert torch.equal(obs[t + 1], o) and torch.equal(rew[t], r) and torch.equal(done[t].bool(), d), 'row %d' % t
+    assert torch.equal(env_a.painted_words(), env_b.painted_words())
+    env_a.close()
+    env_b.close()
+    envs = [_env(tables, n, sp, **kw) for _ in range(3)]
+    torch.manual_seed(3)
+    policy = MLPPolicy(envs[0].obs_dim, 4).to(envs[0].device)
+    workers = [RolloutWorker(envs[0], policy, fragment=T, seed=5), RolloutWorker(envs[1], policy, fragment=T, seed=5, persistent=True),
+               RolloutWorker(envs[2], policy, fragment=T, seed=5, act_step=True)]
+    for frag in range(2):
+        out = [w.collect() for w in workers]
+        torch.cuda.synchronize()
+        for other in (1, 2):
+            for k in out[0][0]:
+                assert torch.equal(out[0][0][k], out[other][0][k]), (frag, other, k)
+            assert torch.equal(out[0][1], out[other][1])
+    assert torch.equal(envs[0].painted_words(), envs[1].painted_words()) and torch.equal(envs[0].painted_words(), envs[2].painted_words())
+    for e in envs:
+        e.close()
 
 
 @pytest.mark.skipif(not os.path.isfile(os.path.join(GOLDEN, 'episodes_sparse.npz')), reason='fixture not generated')

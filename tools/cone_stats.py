@@ -1,0 +1,61 @@
+"""Diagnostic: which paths the cone beams of the bench workload take (PAINT_METHOD 'normal', k_cone_beams.hip).
+Built HERE beforehand (this script builds nothing and spawns nothing):
+
+    python tools/build_variant.py conestat -DPRL_CONE_TRACE --diag-unit k_cone_beams
+    gpurun -- timeout -k 5 120 python tools/cone_stats.py
+
+The counters of the rest kernel's trips are included (it runs the same walk).  Never used by the product or the tests.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from paintrl_amd import build as hb  # noqa: E402
+
+NAMES = ['trips of the beams kernel', 'beams walked', 'hits', 'proven misses', 'rays the walk left over', '  det ~ 0',
+         '  start facet not entered', '  horizon without a certificate', '  behind the origin', '  no neighbour across the edge',
+         '  steps exhausted', 'hit points past three rings', 'trips handed to the rest kernel', 'walk loop trips', '-', 'lane-steps']
+
+
+def main():
+    import torch
+    from paintrl_amd import _lib, part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    hb.LIBRARY = os.environ.get('PRL_TRACE_LIB') or os.path.join(REPO, 'tools', '_ab', 'conestat.so')
+    os.environ['PAINTRL_LAX_SYMBOLS'] = '1'
+    _lib._lib = None
+    lib = _lib.load()
+    lib.prl_debug_cone_stats.argtypes = [C.c_void_p]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(os.environ.get('PRL_PART', 'door_test')), tex_size=(240, 240))
+    n = int(os.environ.get('PRL_ENVS', '4096'))
+    steps = int(os.environ.get('PRL_TRACE_STEPS', '20'))
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1234)
+    acts = torch.randint(0, 4, (40 + steps, n), generator=gen, device='cuda', dtype=torch.int32)
+    env = BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=5678, paint_method='normal')
+    env.reset()
+    for s in range(40):
+        env.step_raw(acts[s])
+    torch.cuda.synchronize()
+    out = np.zeros(16, dtype=np.uint64)
+    lib.prl_debug_cone_stats(out.ctypes.data)
+    for s in range(40, 40 + steps):
+        env.step_raw(acts[s])
+    torch.cuda.synchronize()
+    assert lib.prl_debug_cone_stats(out.ctypes.data) == 0
+    env.close()
+    per = out.astype(np.float64) / (steps * n)
+    print('per env-step (%d envs, %d steps; beams kernel + rest kernel together):' % (n, steps))
+    for k, nm in enumerate(NAMES):
+        if nm != '-':
+            print('  %-40s %10.3f' % (nm, per[k]))
+    print('  mean walk loop trips per beam trip %.2f, mean steps per walked beam %.2f' % (out[13] / max(out[0], 1), out[15] / max(out[1], 1)))
+
+
+if __name__ == '__main__':
+    main()

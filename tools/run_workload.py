@@ -21,11 +21,12 @@ def main():
     ap.add_argument('--obs-mode', default='section')
     ap.add_argument('--steps', type=int, default=80)
     ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--paint-method', default='fast', choices=['fast', 'normal'])
     ap.add_argument('--fragment', action='store_true', help='the steps as ONE launch of the persistent fragment kernel (given actions)')
     a = ap.parse_args()
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
     env = BatchedPaintEnv(DeviceTables(tables), a.envs, auto_reset=True, seed=5678, obs_mode=a.obs_mode,
-                          overlap_penalty=a.obs_mode == 'grid')
+                          overlap_penalty=a.obs_mode == 'grid', paint_method=a.paint_method)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (a.steps, a.envs), generator=gen, device='cuda', dtype=torch.int32)
