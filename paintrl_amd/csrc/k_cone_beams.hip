@@ -1,7 +1,7 @@
 // k_cone_beams.hip -- PAINT_METHOD 'normal' (rob:251-285 + bpw:562-566): every sub-shot casts the part's cone beams
 // (104-140 rays on the reference's parts) from the tool and paints the sample nearest to each hit.
 //
-// A batched step is FIVE launches on the caller's stream, handing over through HBM buffers of the batch:
+// A batched step is FOUR launches on the caller's stream, handing over through HBM buffers of the batch:
 //   cone_path_kernel    one wave per env: the five sub-shots of the tool (prl_step.hpp sub_shot: ray, hook point); the
 //                       five tool poses go to cone_shots.  The tool path of a step does not depend on what the beams paint.
 //   cone_beams_kernel   one wave per beam TRIP (env, shot, 64 beams), one beam per lane: walk over the hull, nearest
@@ -10,11 +10,10 @@
 //                       an env are independent of each other and the hardware dispatcher balances them over the chip:
 //                       with one wave per env a launch was as long as its slowest env (an env at the rim of the part, or
 //                       over a recess of it, takes several times the work of one in the middle).
-//   cone_far_kernel     the hit points the beams kernel found centimetres from every sample (the hull spans a hole or a
-//                       recess of the part there), from a list, 64 per wave: the same block search at the radius each
-//                       needs.
-//   cone_rest_kernel    the few trips with a ray the walk left over, from a work list: the general searches
-//                       (prl_cone.hpp cone_trip).
+//   cone_rest_kernel    two work lists side by side: the hit points the beams kernel found centimetres to decimetres from
+//                       every sample (the hull spans windows and recesses of the part, and stands above a curved panel),
+//                       64 per wave, each lane walking the box pyramid over the samples (nearest_sample_tree); and the
+//                       few trips with a ray the walk left over, through the general searches (cone_trip).
 //   cone_finish_kernel  (k_cone.hip, per mask width) one wave per env: the five hit lists folded shot by shot into the
 //                       coverage masks (bpw:572-577), reward, termination, observation, auto-reset.
 // The extra HBM traffic (10 MB of hit lists written and read per 4 096-env step) is 3 us at HBM speed.
@@ -25,7 +24,7 @@ namespace {
 
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
 constexpr int REST_WGS = 1024;       // workgroups of the work-list kernels (grid-stride over their lists): every trip of a
-constexpr int FAR_WGS = 2048;        // typical step gets its own wave, every far hit point its own eight lanes
+constexpr int FAR_WGS = 1024;        // typical step gets its own wave
 
 template <bool KD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
@@ -121,6 +120,13 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     if (redo) {
         CONE_STAT(12, 1);
         if (lane == 0) a.cone_work[4 + atomicAdd(a.cone_work, 1)] = item;
+        // a reservation that ran over the end of the far list: the entries of it that do lie inside are marked void (the
+        // far role of cone_rest_kernel walks the list up to its capacity)
+        if (far && ballot64(state == 3) == 0) {
+            const int slot = far_base + lane;
+            if (lane < (int)__popcll(far) && slot < a.cone_work[2])
+                reinterpret_cast<f64x2 *>(a.cone_far)[2 * (size_t)slot + 1] = f64x2{0.0, __hiloint2double(0, -1)};
+        }
         return;
     }
     if (sidx == -2) {
@@ -137,45 +143,45 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
 // and env they come from: every lane runs the block search at the radius its own cell asks for (prl_cone.hpp
 // nearest_sample_lane<true>: 10-20 cells over the window of a door, where a lane of the beams kernel would drag the 60
 // settled lanes of its trip through as many rows).
-constexpr int FAR_GROUP = 8;         // lanes that share one far hit point (they split the rows of its block)
-__global__ __launch_bounds__(256) void cone_far_kernel(StepArgs) {
-    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = threadIdx.x & 63, sub = lane & (FAR_GROUP - 1), per_wave = 64 / FAR_GROUP;
-    int n_far = rfl(a.cone_work[1]);
-    n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);      // (entries beyond the capacity went to the trip list)
-    for (int i0 = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)) * per_wave; i0 < n_far; i0 += per_wave * 4 * FAR_WGS) {
-        const int mine_i = i0 + lane / FAR_GROUP;
-        const bool have = mine_i < n_far;
-        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(have ? mine_i : i0);
-        const f64x2 e0 = e[0], e1 = e[1];
-        const double pt[3] = {e0.x, e0.y, e1.x};
-        const int dest = __double2loint(e1.y), part = __double2hiint(e1.y);
-        uint64_t todo = ballot64(have);
-        while (todo) {                                                   // (one trip unless the batch mixes parts)
-            const int p = __builtin_amdgcn_readlane(part, __builtin_ctzll(todo));
-            const bool mine = have && part == p;
-            todo &= ~ballot64(mine);
-            PartRef P = *(const PartDev CAS *)(a.parts + p);
-            int sidx = nearest_sample_lane<true, FAR_GROUP>(P, pt, mine, sub);
-            uint64_t rest = ballot64(mine && sidx == -2 && sub == 0);   // beyond CONE_RING_MAX cells: the wave-wide search
-            while (rest) {
-                const int L = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                const double h3[3] = {bcast_d(pt[0], L), bcast_d(pt[1], L), bcast_d(pt[2], L)};
-                const int s2 = nearest_sample_wave(P, h3, lane);
-                if (lane == L) sidx = s2;
-            }
-            if (mine && sub == 0) a.cone_hits[dest] = sidx;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs) {
+// What the beams kernel left, in ONE launch (the two lists are short and their items long chains of dependent reads: side
+// by side they take as long as the slower of the two):
+//   workgroups [0, FAR_WGS): the hit points three rings of the fine grid did not settle, 64 per wave whatever trip, shot
+//     and env they come from -- every lane walks the box pyramid over the samples for its own point (prl_cone.hpp
+//     nearest_sample_tree);
+//   workgroups [FAR_WGS, FAR_WGS + REST_WGS): the trips with a ray the walk left over, one per wave, through the general
+//     code (prl_cone.hpp cone_trip).
+// Dynamic LDS: the lanes' tree stacks, 2 x tree_cap ints each.
+__global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) {
+    extern __shared__ int s_tree[];
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
+    int *stack = s_tree + threadIdx.x;                                  // entry k of this lane: stack[256 k]
+    if (blockIdx.x < FAR_WGS) {
+        int n_far = rfl(a.cone_work[1]);
+        n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);  // (entries beyond the capacity went to the trip list)
+        for (int i0 = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; i0 < n_far; i0 += 64 * 4 * FAR_WGS) {
+            const bool in = i0 + lane < n_far;
+            const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + lane : i0);
+            const f64x2 e0 = e[0], e1 = e[1];
+            const double pt[3] = {e0.x, e0.y, e1.x};
+            const int dest = __double2loint(e1.y), part = __double2hiint(e1.y);
+            const bool have = in && dest >= 0;                           // (void entries: see cone_beams_kernel)
+            uint64_t todo = ballot64(have);
+            while (todo) {                                               // (one trip unless the batch mixes parts)
+                const int p = __builtin_amdgcn_readlane(part, __builtin_ctzll(todo));
+                const bool mine = have && part == p;
+                todo &= ~ballot64(mine);
+                PartRef P = *(const PartDev CAS *)(a.parts + p);
+                int sidx = mine ? -2 : -1;
+                nearest_sample_far<256>(P, pt, lane, sidx, stack, tree_cap);
+                if (mine) a.cone_hits[dest] = sidx;
+            }
+        }
+        return;
+    }
     const WaveLds wl = wave_lds<false, false>();
     const int n_work = rfl(a.cone_work[0]);
-    for (int i = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)); i < n_work; i += 4 * REST_WGS) {
+    for (int i = rfl((blockIdx.x - FAR_WGS) * 4 + (threadIdx.x >> 6)); i < n_work; i += 4 * REST_WGS) {
         const int item = rfl(a.cone_work[4 + i]);
         int env, shot, b0;
         if (!beam_item(a, item, env, shot, b0)) continue;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs) {
         const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
         const double quat[4] = {uni_d(sh[3]), uni_d(sh[4]), uni_d(sh[5]), uni_d(sh[6])};
         const int hint = rfl(__double2loint(sh[7]));
-        const int sidx = cone_trip(P, pos, quat, b0, (hint >= 0 && hint < P.n_col_pad) ? hint : -1, lane, wl.cand);
+        const int sidx = cone_trip<256>(P, pos, quat, b0, (hint >= 0 && hint < P.n_col_pad) ? hint : -1, lane, wl.cand, stack, tree_cap);
         if (b0 + lane < P.n_beams) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane] = sidx;
     }
 }
@@ -211,8 +217,12 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
-    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
+    const size_t lds = sizeof(int) * 2 * 256 * (size_t)a.cone_tree_cap;
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cone_rest_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(cone_rest_kernel, dim3(FAR_WGS + REST_WGS), dim3(256), lds, s, a, a.cone_tree_cap);
     return (int)hipGetLastError();
 }
 

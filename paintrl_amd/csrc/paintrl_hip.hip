@@ -95,7 +95,7 @@ struct PrlBatch {
     double *cone_shots = nullptr, *cone_aux = nullptr;      // PAINT_METHOD 'normal' only (StepArgs)
     int *cone_hits = nullptr, *cone_work = nullptr;
     double *cone_far = nullptr;
-    int cone_nb = 0;
+    int cone_nb = 0, cone_tree_cap = 0;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
@@ -481,26 +481,64 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
         UP(fg_rec, rec.data(), rec.size());
-        {   // chessboard distance of every cell to the nearest cell that holds a sample (breadth-first over 8 neighbours)
-            std::vector<uint8_t> gap((size_t)nx * ny, 255);
-            std::vector<int> queue;
-            for (int c = 0; c < nx * ny; ++c)
-                if (start[(size_t)c + 1] > start[c]) {
-                    gap[c] = 0;
-                    queue.push_back(c);
-                }
-            for (size_t h = 0; h < queue.size(); ++h) {
-                const int c = queue[h], cx = c % nx, cy = c / nx;
-                if (gap[c] >= 254) continue;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int ex = cx + dx, ey = cy + dy;
-                        if (ex < 0 || ex >= nx || ey < 0 || ey >= ny || gap[(size_t)ey * nx + ex] != 255) continue;
-                        gap[(size_t)ey * nx + ex] = (uint8_t)(gap[c] + 1);
-                        queue.push_back(ey * nx + ex);
-                    }
+        {
+            std::vector<float> rec32(real.size() * 4);
+            for (size_t j = 0; j < real.size(); ++j) {
+                for (int k = 0; k < 3; ++k) rec32[j * 4 + k] = (float)rec[j * 4 + k];
+                int32_t pair[2];
+                std::memcpy(pair, &rec[j * 4 + 3], sizeof pair);
+                std::memcpy(&rec32[j * 4 + 3], &pair[1], sizeof(int32_t));
             }
-            UP(fg_gap, gap.data(), gap.size());
+            UP(fg_rec32, rec32.data(), rec32.size());
+        }
+        {   // box pyramid (PartDev::py_*): bounding boxes of the samples of every cell, then of 2 x 2 nodes, up to one node
+            d.py_levels = 0;
+            std::vector<float> box;
+            std::vector<int> lnx, lny, loff;
+            int cnx = nx, cny = ny;
+            for (int l = 0; l < PY_MAX_LEVELS; ++l) {
+                lnx.push_back(cnx), lny.push_back(cny), loff.push_back((int)(box.size() / 8));
+                box.resize(box.size() + (size_t)cnx * cny * 8);
+                float *lv = box.data() + (size_t)loff[l] * 8;
+                for (int c = 0; c < cnx * cny; ++c) {
+                    float *b = lv + (size_t)c * 8;
+                    b[0] = b[1] = b[2] = INFINITY, b[4] = b[5] = b[6] = -INFINITY, b[3] = b[7] = 0.0f;
+                }
+                if (l == 0) {
+                    for (size_t j = 0; j < real.size(); ++j) {
+                        float *b = lv + (size_t)cell_of[j] * 8;
+                        for (int k = 0; k < 3; ++k) {
+                            const double v = t->sample_xyz[k][real[j]];
+                            b[k] = std::fmin(b[k], std::nextafterf((float)v, -INFINITY));
+                            b[4 + k] = std::fmax(b[4 + k], std::nextafterf((float)v, INFINITY));
+                        }
+                    }
+                } else {
+                    const float *pv = box.data() + (size_t)loff[l - 1] * 8;
+                    const int pnx = lnx[l - 1], pny = lny[l - 1];
+                    for (int cy = 0; cy < cny; ++cy)
+                        for (int cx = 0; cx < cnx; ++cx) {
+                            float *b = lv + ((size_t)cy * cnx + cx) * 8;
+                            for (int sy = 0; sy < 2; ++sy)
+                                for (int sx = 0; sx < 2; ++sx) {
+                                    const int px = 2 * cx + sx, py = 2 * cy + sy;
+                                    if (px >= pnx || py >= pny) continue;
+                                    const float *q = pv + ((size_t)py * pnx + px) * 8;
+                                    for (int k = 0; k < 3; ++k) b[k] = std::fmin(b[k], q[k]), b[4 + k] = std::fmax(b[4 + k], q[4 + k]);
+                                }
+                        }
+                }
+                d.py_levels = l + 1;
+                if (cnx == 1 && cny == 1) break;
+                cnx = (cnx + 1) / 2, cny = (cny + 1) / 2;
+            }
+            if (lnx.back() != 1 || lny.back() != 1) d.py_levels = 0;      // (a grid beyond 4096 cells a side: no pyramid)
+            for (int l = 0; l < PY_MAX_LEVELS; ++l) {
+                d.py_off[l] = l < d.py_levels ? loff[l] : 0;
+                d.py_nx[l] = l < d.py_levels ? lnx[l] : 0;
+                d.py_ny[l] = l < d.py_levels ? lny[l] : 0;
+            }
+            UP(py_box, box.data(), box.size());
         }
     }
     {   // outline of the collision set in the principal plane (Andrew's monotone chain over the projected corners)
@@ -618,6 +656,7 @@ StepArgs base_args(PrlBatch *b) {
     a.cone_work = b->cone_work;
     a.cone_far = b->cone_far;
     a.cone_nb = b->cone_nb;
+    a.cone_tree_cap = b->cone_tree_cap;
     return a;
 }
 
@@ -771,6 +810,7 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess && cfg->paint_method == PRL_PAINT_NORMAL) {
         // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
         b->cone_nb = ((b->max_beams + 63) / 64) * 64;
+        for (int i = 0; i < n_parts; ++i) b->cone_tree_cap = std::max(b->cone_tree_cap, 3 * parts[i]->dev.py_levels + 2);
         const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
         e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
@@ -779,7 +819,7 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * (items + 4));
         // hit points handed to the far search: 64 per env and step (a typical step has a dozen; a full list sends the
         // rest through the general code)
-        const int far_cap = (int)std::min<size_t>((size_t)n_envs * 64, (size_t)1 << 26);
+        const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 64, 4096), (size_t)1 << 26);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_far), sizeof(double) * 4 * (size_t)far_cap);
         if (e == hipSuccess) e = hipMemcpy(b->cone_work + 2, &far_cap, sizeof(int), hipMemcpyHostToDevice);
     }

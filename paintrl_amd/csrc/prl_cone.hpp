@@ -29,9 +29,6 @@ __device__ unsigned long long g_cone_stat[16];
 #else
 #define CONE_STAT(k, v)
 #endif
-#define CONE_CNT_ARG
-#define CONE_CNT_PASS
-#define CONE_CNT(slot, v)
 
 #ifndef PRL_WALK_STEPS
 #define PRL_WALK_STEPS 12
@@ -41,13 +38,14 @@ constexpr int CONE_WALK_STEPS = PRL_WALK_STEPS;
 #define PRL_CONE_JOINT_FROM 5
 #endif
 constexpr int CONE_JOINT_FROM = PRL_CONE_JOINT_FROM;
-#ifndef PRL_CONE_FAR_K0
-#define PRL_CONE_FAR_K0 4
-#endif
-constexpr int CONE_FAR_K0 = PRL_CONE_FAR_K0;
-#define FAR_BAND 4.0e-6f              // m^2, see nearest_samples_shared             // first widening (fine cells) of the shared far scan     // more stragglers than this in a trip: searched together
 #define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
 
+// A beam ENTERS a facet for the purposes of the walk from this squared cosine on.  The single-facet criterion (prl_ray.hpp)
+// needs the entry point FACET_EDGE_MARGIN = 1e-6 m clear of the facet's edges and the other facets' tolerance fringes (1e-9 of
+// a triangle height: under 1e-9 m) out of the beam's way before it: a beam that comes down on the facet at |cos| c passes
+// c x 1e-6 m above the facet's plane where it crosses the edge, so any c well above 1e-3 will do; 0.032 here (the tool's
+// own rays keep prl_ray.hpp's 0.1).
+#define CONE_MIN_COS2 1.0e-3
 #define CONE_SIL_MIN_COS2 1.0e-6     // squared cosine between beam and the normal of a facet counted as facing away from it
 
 // One step of the walk for this lane's ray (origin o, direction d, |d|^2 = dd) on facet i (>= 0), reached across an
@@ -77,7 +75,7 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const 
     const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
     const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
     const bool front = orient * det > 0;                      // the beam meets this facet's plane from outside
-    solid = front && det * det >= FACET_MIN_COS2 * dd * nn;   // ... at more than a grazing angle
+    solid = front && det * det >= CONE_MIN_COS2 * dd * nn;    // ... at more than a grazing angle
     if (!solid) {
         // The walk has reached the hull's horizon (or grazes).  Two certificates that the beam misses the whole set, by
         // more than any tolerance of the triangle tests -- then no search is needed:
@@ -237,7 +235,7 @@ __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], c
 // The rays of beams b0 + lane: hit[3] of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray (where
 // the wave-wide searches of leftover rays start).
 __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                int *cand_lds, double hit[3] CONE_CNT_ARG) {
+                                int *cand_lds, double hit[3]) {
     const bool have = b0 + lane < P.n_beams;
     double dst[3], t;
     int state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
@@ -281,7 +279,6 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
     }
     // the stragglers (edge and vertex hits, and every miss), together
     const uint64_t todo = ballot64(state == 3);
-    CONE_CNT(0, __popcll(todo));                     // rays the walk did not settle
     if (__popcll(todo) > CONE_JOINT_FROM) {
         double tw;
         int tri;
@@ -318,37 +315,25 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 // its point (PartDev::fg_*: ~4 samples a cell, so a 3 x 3 block holds ~36 candidates where the painter's own sample
 // grid holds ~1 350), rows as contiguous record ranges, four records per trip so that their reads travel together.
 // A sample outside the block is more than r cells away in the principal plane: the best of the block is the answer
-// once it lies within r * 0.99 * cell.  r starts at 1 -- or, where the collision hull spans a hole or a recess of the
-// part and every hit lies centimetres from the samples, at what PartDev::fg_gap (cells to the nearest cell that holds a
-// sample) says will be needed; a block whose best does not settle the query names the radius that will.  Returns the
-// device position of the sample, -1 if not `want`, or -2 if that did not end within CONE_RING_MAX cells / three
-// blocks: the caller asks the wave-wide searches.
-#define CONE_RING_MAX 48
-// G > 1 (the far kernel): G adjacent lanes share one query -- same `pt` and `want` in all of them, lane `sub` of the
-// group takes every G-th row of the block, the group's best is combined at the end (every lane of it returns the same).
-template <bool FAR, int G = 1>
-__device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3], bool want, int sub = 0) {
-    constexpr int RMAX = FAR ? CONE_RING_MAX : 3;     // the beams kernel's common case stops at three rings (prl_cone.hpp header)
+// once it lies within r * 0.99 * cell; a block whose best does not settle the query names the radius that will.  Returns
+// the device position of the sample, -1 if not `want`, or -2 if three rings do not settle it (a hit point centimetres off
+// the sampled surface): the caller asks nearest_sample_tree.
+__device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     int result = want ? -2 : -1;
     bool open = want;
     int r = 1;
-    if (FAR && want) {
-        const int ccx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), ccy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
-        const int gap = (int)ldg(P.fg_gap, ccy * P.fg_nx + ccx);
-        r = gap <= 1 ? 1 : gap + 2;
-    }
     for (int pass = 0; pass < 3; ++pass) {
-        if (open && r > RMAX) open = false;                           // (stays -2)
+        if (open && r > 3) open = false;                              // (stays -2)
         if (ballot64(open) == 0) break;
         const int rmax = -wave_min_i(open ? -r : 0);                  // wave-uniform trip count, per-lane ranges
         double best_d = INFINITY;
         int best_rank = 0x7fffffff, best_pos = -1;
         const int cx0 = icx - r < 0 ? 0 : icx - r, cx1 = icx + r > P.fg_nx - 1 ? P.fg_nx - 1 : icx + r;
-        for (int dy0 = -rmax; dy0 <= rmax; dy0 += G) {
-            const int dy = dy0 + sub, cy = icy + dy;
+        for (int dy = -rmax; dy <= rmax; ++dy) {
+            const int cy = icy + dy;
             const bool row_ok = open && dy >= -r && dy <= r && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
             const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
             const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
@@ -375,18 +360,6 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
                 }
             }
         }
-        if constexpr (G > 1) {                                        // the group's best: (distance, rank) lexicographic
-#pragma unroll
-            for (int m = 1; m < G; m <<= 1) {
-                const double od = __hiloint2double(__shfl_xor(__double2hiint(best_d), m), __shfl_xor(__double2loint(best_d), m));
-                const int ork = __shfl_xor(best_rank, m), opos = __shfl_xor(best_pos, m);
-                if (od < best_d || (od == best_d && ork < best_rank)) {
-                    best_d = od;
-                    best_rank = ork;
-                    best_pos = opos;
-                }
-            }
-        }
         const double lim = r * P.fg_accept;
         if (open && best_pos >= 0 && best_d <= lim * lim) {
             result = best_pos;
@@ -397,103 +370,240 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
             r = need > r ? need : r + 1;
         }
     }
-#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the wave-wide search
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the tree walk
     if (want) result = -2;
 #endif
     return result;
 }
 
-// ---------------------------------------------------------------- nearest samples of points FAR from the sampled surface
-// Where the collision hull spans a recess of the part, every hit of a shot lies centimetres above the samples: three
-// rings of the fine grid do not settle any of them, and a wave-wide search per hit (4 us each, ~520 a step) made such
-// an env five times slower than the rest -- and the launch waits for it.  Here the needy lanes share one scan: the block
-// of fine cells around ALL their points, widened by `k` cells, is read once (64 records at a time, one per lane, handed
-// round by lane broadcast) and every needy lane measures every record against its own point.  A lane whose cell is at
-// least r cells inside the block (a block side on the grid's own border counts as infinitely far) has seen every sample
-// closer than r cells: its best is exact once within r * 0.99 * cell.  k = 4, 8, 16 (measured: 664 steps/s; from 8: 641; from 6: 340), then the wave-wide search.
-// (Tried: a small first block whose best distance sizes the second -- slower, 468 vs 696 steps/s: over a hole in the
-// part the bound is loose and the sized block larger than the one doubling reaches.)
-__device__ __attribute__((noinline)) void nearest_samples_shared(PartRef P, const double pt[3], int lane, int &sidx) {
+// ---------------------------------------------------------------- the same query on float records (the beams kernel)
+// The beams kernel is bound by the bytes its lanes gather through the CU's L1 (rocprofv3: TA busy 85 %), and most of
+// them are the 32-byte float64 records of this query.  Here the block is scanned on 16-byte records (x y z rounded to
+// float | device position) keeping the three nearest in float; only the ones that float arithmetic cannot tell from the
+// nearest are then measured in float64 (one, as a rule), so the answer is the float64 one bit for bit:
+//   a coordinate c, |c| <= M, rounds to float with error <= 2^-24 M; a difference of two such floats is exact before its
+//   own rounding, so each float difference is off by E <= 2^-23 M (1 + 2^-24); the float squared distance (three
+//   products, two sums, each rounded) is then off by at most  band(d) = 3.5 d E + 3 E^2 + 2^-22 d^2  for a distance d.
+// A record is a contender if its float distance minus its band does not exceed the nearest's plus its band.  Three
+// contenders: there may be a fourth -- the lane reports -2 and the far kernel's tree walk answers exactly.  Rings and
+// the acceptance test (on the exact distance) as in nearest_sample_lane.
+__device__ __forceinline__ float nn_band(float d2, float E) {
+    const float d = __builtin_sqrtf(d2) * 1.0001f + 1e-12f;
+    return 3.5f * d * E + 3.0f * E * E + 2.4e-7f * d2 + 1e-30f;
+}
+
+__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
-    const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
-    for (int k = CONE_FAR_K0; k <= 4 * CONE_FAR_K0; k *= 2) {
-        const bool need = sidx == -2;
-        if (ballot64(need) == 0) return;
-        const int ccx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), ccy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
-        int bx0 = wave_min_i(need ? ccx : 0x7fffffff) - k, bx1 = -wave_min_i(need ? -ccx : 0x7fffffff) + k;
-        int by0 = wave_min_i(need ? ccy : 0x7fffffff) - k, by1 = -wave_min_i(need ? -ccy : 0x7fffffff) + k;
-        const bool open_x0 = bx0 <= 0, open_x1 = bx1 >= P.fg_nx - 1, open_y0 = by0 <= 0, open_y1 = by1 >= P.fg_ny - 1;
-        bx0 = bx0 < 0 ? 0 : bx0;
-        by0 = by0 < 0 ? 0 : by0;
-        bx1 = bx1 > P.fg_nx - 1 ? P.fg_nx - 1 : bx1;
-        by1 = by1 > P.fg_ny - 1 ? P.fg_ny - 1 : by1;
-        double best_d = INFINITY;
-        int best_rank = 0x7fffffff, best_pos = -1;
-        // float pre-test: a record is measured in float64 only if, in float, it comes within FAR_BAND of some needy lane's
-        // best so far.  Coordinates are below 2 m and differences below 1 m here, so a float squared distance is within
-        // 1e-6 m^2 of the exact one (rounding the six coordinates: 6 x 1.2e-7 x 2 x 1; the arithmetic: 1e-7): a record
-        // the test drops is farther than the lane's best and could neither replace nor tie it.
-        const float pfx = (float)pt[0], pfy = (float)pt[1], pfz = (float)pt[2];
-        float bestf = INFINITY;                                                  // >= best_d
-        for (int cy = by0; cy <= by1; ++cy) {                                   // wave-uniform loops
-            const int b = P.fg_start[cy * P.fg_nx + bx0], e = P.fg_start[cy * P.fg_nx + bx1 + 1];
-            for (int i0 = b; i0 < e; i0 += 64) {
-                const int i = i0 + lane < e ? i0 + lane : e - 1;
-                const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
-                const float fx = (float)ra.x, fy = (float)ra.y, fz = (float)rb.x;
-                const int n = e - i0 < 64 ? e - i0 : 64;
-                for (int j = 0; j < n; ++j) {
-                    const float ex = bcast_f(fx, j) - pfx, ey = bcast_f(fy, j) - pfy, ez = bcast_f(fz, j) - pfz;
-                    const float ddf = ex * ex + ey * ey + ez * ez;
-                    if (ballot64(need && ddf <= bestf + FAR_BAND) == 0) continue;
-                    const double x = bcast_d(ra.x, j), y = bcast_d(ra.y, j), z = bcast_d(rb.x, j);
-                    const int rk = __builtin_amdgcn_readlane(__double2loint(rb.y), j);
-                    const int ps = __builtin_amdgcn_readlane(__double2hiint(rb.y), j);
-                    const double dx = x - pt[0], dy = y - pt[1], dz = z - pt[2];
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                        best_d = dd;
-                        best_rank = rk;
-                        best_pos = ps;
-                        bestf = nextafterf((float)dd, INFINITY);
-                    }
+    const f32x4 GAS *rec = reinterpret_cast<const f32x4 GAS *>(P.fg_rec32);
+    const float qx = (float)pt[0], qy = (float)pt[1], qz = (float)pt[2];
+    const double mq = fmax(fmax(fabs(pt[0]), fabs(pt[1])), fmax(fabs(pt[2]), P.samp_absmax));
+    const float E = (float)(mq * 1.1920929e-7 * 1.001);              // 2^-23 M, rounded up
+    int result = want ? -2 : -1;
+    bool open = want && mq < 1.0e6;
+    int r = 1;
+    for (int pass = 0; pass < 3; ++pass) {
+        if (open && r > 3) open = false;                              // (stays -2)
+        if (ballot64(open) == 0) break;
+        const int rmax = -wave_min_i(open ? -r : 0);                  // wave-uniform trip count, per-lane ranges
+        float d1 = INFINITY, d2 = INFINITY, d3 = INFINITY;
+        int p1 = -1, p2 = -1, p3 = -1;
+        const int cx0 = icx - r < 0 ? 0 : icx - r, cx1 = icx + r > P.fg_nx - 1 ? P.fg_nx - 1 : icx + r;
+        for (int dy = -rmax; dy <= rmax; ++dy) {
+            const int cy = icy + dy;
+            const bool row_ok = open && dy >= -r && dy <= r && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
+            const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
+            const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
+            for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4) {
+                f32x4 rc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rc[q] = ldg(rec, i0 + q < e ? i0 + q : (e > b ? e - 1 : 0));   // (in range)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float ex = rc[q].x - qx, ey = rc[q].y - qy, ez = rc[q].z - qz;
+                    const float dd = i0 + q < e ? __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) : INFINITY;
+                    const int ps = __float_as_int(rc[q].w);
+                    // keep the three nearest (d1 <= d2 <= d3)
+                    const bool lt3 = dd < d3, lt2 = dd < d2, lt1 = dd < d1;
+                    d3 = lt2 ? d2 : (lt3 ? dd : d3);
+                    p3 = lt2 ? p2 : (lt3 ? ps : p3);
+                    d2 = lt1 ? d1 : (lt2 ? dd : d2);
+                    p2 = lt1 ? p1 : (lt2 ? ps : p2);
+                    d1 = lt1 ? dd : d1;
+                    p1 = lt1 ? ps : p1;
                 }
             }
         }
-        // cells between this lane's (clamped) cell and the nearest CLOSED side of the block
-        int r = 0x7fffffff;
-        if (!open_x0) r = ccx - bx0 < r ? ccx - bx0 : r;
-        if (!open_x1) r = bx1 - ccx < r ? bx1 - ccx : r;
-        if (!open_y0) r = ccy - by0 < r ? ccy - by0 : r;
-        if (!open_y1) r = by1 - ccy < r ? by1 - ccy : r;
-        // (a point outside the grid is farther from every sample beyond the block than its clamped cell is)
-        const double lim = (r == 0x7fffffff ? 1.0e30 : (double)r * P.fg_accept);
-        if (need && best_pos >= 0 && best_d <= lim * lim) sidx = best_pos;
+        // float64 for the contenders
+        double best_d = INFINITY;
+        int best_rank = 0x7fffffff, best_pos = -1;
+        const float lim1 = d1 + nn_band(d1, E);
+        const bool c2 = open && p2 >= 0 && d2 - nn_band(d2, E) <= lim1, c3 = open && p3 >= 0 && d3 - nn_band(d3, E) <= lim1;
+        if (open && p1 >= 0) {
+            const double dx = ldg(P.samp[0], p1) - pt[0], dy = ldg(P.samp[1], p1) - pt[1], dz = ldg(P.samp[2], p1) - pt[2];
+            best_d = (dx * dx + dy * dy) + dz * dz;
+            best_pos = p1;
+        }
+        if (ballot64(c2) != 0) {
+            if (c2) {
+                best_rank = ldg(P.samp_rank, p1);
+                const double dx = ldg(P.samp[0], p2) - pt[0], dy = ldg(P.samp[1], p2) - pt[1], dz = ldg(P.samp[2], p2) - pt[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                const int rk = ldg(P.samp_rank, p2);
+                if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                    best_d = dd;
+                    best_pos = p2;
+                }
+            }
+        }
+        const double lim = r * P.fg_accept;
+        if (open && c3) {
+            open = false;                                            // three the float distances cannot order: the tree decides
+        } else if (open && best_pos >= 0 && best_d <= lim * lim) {
+            result = best_pos;
+            open = false;
+        } else if (open) {
+            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : 2 * r + 2;
+            r = need > r ? need : r + 1;
+        }
+    }
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the far kernel's tree walk
+    if (want) result = -2;
+#endif
+    return result;
+}
+
+// ---------------------------------------------------------------- nearest sample by branch and bound (any distance)
+// The same query where the ring argument has no grip: the collision hull spans the windows and recesses of a part, and
+// stands decimetres above a curved panel, so a hit point can lie 3 - 30 cm from the nearest sample; a block of cells
+// whose radius reaches that far holds thousands of samples.  Here every lane walks the box pyramid over the fine grid
+// (PartDev::py_*) depth first, nearest child first: a node is visited only if the distance from the point to its
+// bounding box (boxes rounded outward, so never more than to any sample inside) does not exceed the best found so far;
+// the samples of a cell are measured as in nearest_sample_lane (float64, equal distances to the lowest reference index).
+// ~10 node visits and a handful of cells per query whatever the distance.  `stack`: 2 x cap ints per lane in LDS (this
+// lane's column: stack[k * TREE_STRIDE]), cap >= tree_stack_cap(levels): a visit takes one entry off and puts at most four
+// on.  Returns the device position of the sample; -1 if not `want` or the part has no pyramid.
+__host__ __device__ constexpr int tree_stack_cap(int levels) { return 3 * levels + 2; }
+template <int TREE_STRIDE>
+__device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3], bool want, int *stack, int cap) {
+    if (P.py_levels <= 0) return -1;
+    const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.py_box);
+    const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
+    double best_d = INFINITY;
+    int best_rank = 0x7fffffff, best_pos = -1, sp = 0;
+    if (want) {                                          // the root: level py_levels - 1 is one node
+        stack[0] = (int)((unsigned)(P.py_levels - 1) << 28);
+        stack[cap * TREE_STRIDE] = 0;                    // its bound (float bits): 0
+        sp = 1;
+    }
+    while (ballot64(sp > 0) != 0) {
+        if (sp > 0) {
+            --sp;
+            const int node = stack[sp * TREE_STRIDE];
+            const float bound = __int_as_float(stack[(cap + sp) * TREE_STRIDE]);
+            if ((double)bound <= best_d) {
+                const int level = (int)((unsigned)node >> 28), cy = (node >> 14) & 0x3fff, cx = node & 0x3fff;
+                if (level == 0) {
+                    const int c = cy * P.fg_nx + cx;
+                    const int b = ldg(P.fg_start, c), e = ldg(P.fg_start, c + 1);
+                    for (int i0 = b; i0 < e; i0 += 4) {
+                        f64x2 ra[4], rb[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int i = i0 + q < e ? i0 + q : e - 1;
+                            ra[q] = ldg(rec, 2 * i);
+                            rb[q] = ldg(rec, 2 * i + 1);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (i0 + q < e) {
+                                const double dx = ra[q].x - pt[0], dy = ra[q].y - pt[1], dz = rb[q].x - pt[2];
+                                const double dd = (dx * dx + dy * dy) + dz * dz;
+                                const int rk = __double2loint(rb[q].y);
+                                if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                                    best_d = dd;
+                                    best_rank = rk;
+                                    best_pos = __double2hiint(rb[q].y);
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const int cl = level - 1, cnx = P.py_nx[cl], cny = P.py_ny[cl], off = P.py_off[cl];
+                    float key[4];
+                    int val[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
+                        const bool in = px < cnx && py < cny;
+                        const int n = off + (in ? py * cnx + px : 0);
+                        const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);
+                        const double ex = fmax(fmax((double)lo.x - pt[0], pt[0] - (double)hi.x), 0.0);
+                        const double ey = fmax(fmax((double)lo.y - pt[1], pt[1] - (double)hi.y), 0.0);
+                        const double ez = fmax(fmax((double)lo.z - pt[2], pt[2] - (double)hi.z), 0.0);
+                        const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
+                        key[q] = (in && d2 <= best_d) ? __double2float_rd(d2) : INFINITY;
+                        val[q] = (int)(((unsigned)cl << 28) | ((unsigned)py << 14) | (unsigned)px);
+                    }
+                    // farthest first onto the stack, so that the nearest child is looked at next
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 3 - a; ++b2)
+                            if (key[b2] < key[b2 + 1]) {
+                                const float tk = key[b2];
+                                key[b2] = key[b2 + 1];
+                                key[b2 + 1] = tk;
+                                const int tv = val[b2];
+                                val[b2] = val[b2 + 1];
+                                val[b2 + 1] = tv;
+                            }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (key[q] < INFINITY && sp < cap) {
+                            stack[sp * TREE_STRIDE] = val[q];
+                            stack[(cap + sp) * TREE_STRIDE] = __float_as_int(key[q]);
+                            ++sp;
+                        }
+                }
+            }
+        }
+    }
+    return want ? best_pos : -1;
+}
+
+// What is left of a hit point's query after three rings of the fine grid: the tree walk, or (a part without the box
+// pyramid) one wave-wide search per point.  `stack` / `cap` / TREE_STRIDE as nearest_sample_tree wants them.
+template <int TREE_STRIDE>
+__device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3], int lane, int &sidx, int *stack, int cap) {
+    const bool need = sidx == -2;
+    if (ballot64(need) == 0) return;
+    if (P.py_levels > 0) {
+        const int s2 = nearest_sample_tree<TREE_STRIDE>(P, pt, need, stack, cap);
+        if (need) sidx = s2;
+        return;
+    }
+    uint64_t rest = ballot64(need);
+    while (rest) {
+        const int L = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        const double h3[3] = {bcast_d(pt[0], L), bcast_d(pt[1], L), bcast_d(pt[2], L)};
+        const int s2 = nearest_sample_wave(P, h3, lane);
+        if (lane == L) sidx = s2;
     }
 }
 
 // One trip of a shot: the beams b0 + lane of the cone at tool pose (pos, quat) -- the device position of the sample each
 // lane's beam paints (bpw:562-566: the sample nearest to the hit point), or -1 (no such beam, or it misses the part).
+// The general code: whatever the walk leaves over is searched (cone_rays_lanes), whatever the rings do not settle is
+// walked down the tree.
+template <int TREE_STRIDE>
 __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                         int *cand_lds CONE_CNT_ARG) {
+                                         int *cand_lds, int *stack, int cap) {
     double bh[3];
-    const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh CONE_CNT_PASS);
-    CONE_CNT(3, __popcll(ballot64(hit)));             // beams that hit the part
-    // nearest sample of every hit point: one query per lane; the few that the fine grid does not settle go through
-    // the wave-wide search
-    int sidx = nearest_sample_lane<true>(P, bh, hit);
-    CONE_CNT(1, __popcll(ballot64(sidx == -2)));      // hit points three rings of the fine grid did not settle
-    if (__popcll(ballot64(sidx == -2)) > 3) nearest_samples_shared(P, bh, lane, sidx);   // (a recess of the part)
-    uint64_t rest = ballot64(sidx == -2);
-    CONE_CNT(2, __popcll(rest));                      // ... and the shared scan neither: one wave-wide search each
-    while (rest) {
-        const int L = __builtin_ctzll(rest);
-        rest &= rest - 1;
-        const double h3[3] = {bcast_d(bh[0], L), bcast_d(bh[1], L), bcast_d(bh[2], L)};
-        const int s2 = nearest_sample_wave(P, h3, lane);
-        if (lane == L) sidx = s2;
-    }
+    const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh);
+    int sidx = nearest_sample_lane(P, bh, hit);
+    nearest_sample_far<TREE_STRIDE>(P, bh, lane, sidx, stack, cap);
     return sidx;
 }
 
@@ -505,10 +615,17 @@ __device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], c
                                                int &state, double bh[3], int &sidx) {
     double dst[3], t;
     state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
+#ifdef PRL_FORCE_GENERAL_RAY                          // diagnostic build: every trip through the rest kernel's general code
+    if (b0 + lane < P.n_beams) state = 3;
+#endif
     bh[0] = pos[0] + t * (dst[0] - pos[0]);
     bh[1] = pos[1] + t * (dst[1] - pos[1]);
     bh[2] = pos[2] + t * (dst[2] - pos[2]);
-    sidx = nearest_sample_lane<false>(P, bh, state == 1);
+#ifdef PRL_CONE_F64_RECORDS                           // (A/B switch: the float64 records in the beams kernel too)
+    sidx = nearest_sample_lane(P, bh, state == 1);
+#else
+    sidx = nearest_sample_lane_f32(P, bh, state == 1);
+#endif
     CONE_STAT(0, 1);
     CONE_STAT(11, __popcll(ballot64(sidx == -2)));
 }

@@ -31,6 +31,7 @@ constexpr double SHOT_CENTRE_OFFSET = 0.1;      // rob:277-278: the shot centre 
 // a hit on this triangle makes of its normal, computed once on upload with the device's own arithmetic:
 // quat = get_pose_orn(-normal) (rob:93-100), centre_off = R(quat) (0, 0, 0.1) (rob:277-278).
 constexpr int TRI_REC = 24;
+constexpr int PY_MAX_LEVELS = 13;               // box pyramid over the fine sample grid (PartDev::py_*): grids up to 4096 cells wide
 
 // Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
 // space and would emit flat_load (out-of-order, waits on vmcnt AND lgkmcnt).  Typing them as global
@@ -61,7 +62,14 @@ struct PartDev {
     int fg_nx, fg_ny;
     gint_p fg_start;              // [fg_nx * fg_ny + 1]
     gdouble_p fg_rec;             // [n_samples][4]
-    gu8_p fg_gap;                 // [fg_nx * fg_ny]: cells (chessboard distance, capped at 255) to the nearest cell holding a sample
+    gfloat_p fg_rec32;            // [n_samples][4]: the same records as x y z rounded to float | device position (int bits)
+    // box pyramid over the fine grid (derived in part_fill): level 0 = the cells, level l = 2^l x 2^l of them; a node is the
+    // bounding box of its samples as 8 floats (lo x y z, 0, hi x y z, 0; rounded outward; empty: lo = +inf, hi = -inf).
+    // nearest_sample_tree walks it branch and bound: exact nearest samples of points centimetres to decimetres from the
+    // sampled surface (the collision hull spans windows and recesses of the part), where a ring of cells has no grip.
+    int py_levels;                // 0: no pyramid
+    int py_off[PY_MAX_LEVELS], py_nx[PY_MAX_LEVELS], py_ny[PY_MAX_LEVELS];      // first node / dimensions of each level
+    gfloat_p py_box;
     // outline of the collision set in the principal plane (convex polygon, derived in part_fill) and its extent along
     // the third axis: a beam whose stretch inside that slab projects outside the outline misses the part (prl_cone.hpp)
     int n_outline;                // edges, 0 = no test; the table is padded to a multiple of 64 rows
@@ -145,6 +153,7 @@ struct StepArgs {
     int *cone_work;               // [0] = number of beam trips handed to the general search, [1] = number of hit points handed
                                   // to the far search, [2] = capacity of cone_far, [4 ..] = the trips' ids
     double *cone_far;             // [capacity][4]: hit point x y z | {i32 index into cone_hits, i32 part id}
+    int cone_tree_cap;            // stack entries per lane of the far kernel's tree walks (tree_stack_cap of the deepest pyramid)
     int cone_nb;                  // beams per shot, padded to 64 (the largest beam count of the batch's parts)
 };
 
