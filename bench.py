@@ -36,6 +36,7 @@ ENVS_PER_GPU = 4096
 FRAGMENT = 100                  # rollout fragment length (paint_ppo.py:190 sample_batch_size)
 TIMING_EVERY = 8                # runs of > SAMPLE_ABOVE steps also bracket every 8th launch with its own HIP event
 SAMPLE_ABOVE = 256              # pair (a pair costs ~3.5 us of stream time, so short runs are left unperturbed)
+REPEATS = 5                     # the timed region (K steps) is run this many times; value = the median
 PREWARM_SECONDS = 0.4           # untimed stepping of a scratch batch first: the timed region then runs at
                                 # the clocks a long job holds, also at the driver's --warmup 5 --steps 20
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -82,6 +83,16 @@ def usable_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def _oracle_rate(tables, n_envs, steps_sample, threads, obs_mode='section', overlap=False):
     import numpy as np
     import oracle
@@ -106,6 +117,7 @@ def cpu_baseline(tables, steps_sample=300, n_envs=ENVS_PER_GPU, obs_mode='sectio
     one_steps = max(2, steps_sample // 12)
     dt_one = _oracle_rate(tables, n_envs, one_steps, 1, obs_mode, overlap)
     out = {'value': steps_sample / dt_all, 'unit': 'batched steps/s (%d envs each)' % n_envs, 'cores': cores,
+           'cpu_model': cpu_model(),
            'kind': 'port', 'env_steps_per_s': steps_sample * n_envs / dt_all,
            'sample': '%d batched steps of %d envs (same door, same action distribution, reset on done), '
                      'oracle/paint_oracle.c with OpenMP over envs, %.1f s wall' % (steps_sample, n_envs, dt_all),
@@ -125,26 +137,35 @@ def cpu_baseline(tables, steps_sample=300, n_envs=ENVS_PER_GPU, obs_mode='sectio
     return out
 
 
-def valu_issue_bound(kernel_us, obs_mode):
-    """Second roofline: the step kernel against its own vector-issue bound, from the committed SQ counters.
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round that has one (the evidence bench.py quotes is committed, not measured
+    in the run: `measured_at_commit` inside says what it was measured on)."""
+    import glob
+    import re
+    hits = [(int(re.search(r'r(\d+)_', os.path.basename(p)).group(1)), p)
+            for p in glob.glob(os.path.join(REPO, 'profiles', 'r[0-9]*_' + suffix))]
+    return max(hits)[1] if hits else None
 
-    A wave64 VALU instruction occupies a SIMD-32 for 2 cycles (f32 / int) or 4 (f64, half rate); with W waves
-    per SIMD the SIMD cannot finish before W x (per-wave issue cycles).  frac = that time / measured kernel time."""
-    path = os.path.join(REPO, 'profiles', 'r02_sq_counters.json')
-    if not os.path.isfile(path) or not kernel_us:
+
+def valu_issue_bound(kernel_us, obs_mode):
+    """Second roofline: the step kernel against its own vector-issue bound -- instruction counts from the committed SQ
+    counters, priced with the issue costs measured on this chip (tools/valu_model.py: 2 cycles for 32-bit VOP1 / VOP2,
+    4 for float64 / VOP3 / DPP / lane moves, 16 for float64 reciprocals and square roots), W waves per SIMD."""
+    path = latest_profile('valu_model.json')
+    if not path or not kernel_us:
         return None
     with open(path) as f:
-        c = json.load(f).get(obs_mode)
+        m = json.load(f)
+    c = m.get(obs_mode)
     if not c:
         return None
-    waves_per_simd = c['waves'] / float(N_SIMD)
-    cycles = waves_per_simd * (2.0 * (c['valu_per_wave'] - c['valu_f64_per_wave']) + 4.0 * c['valu_f64_per_wave'])
-    bound_us = cycles / (CLOCK_GHZ * 1e3)
-    return {'bound': 'valu_issue', 'valu_per_wave': c['valu_per_wave'], 'valu_f64_per_wave': c['valu_f64_per_wave'],
-            'salu_per_wave': c.get('salu_per_wave'), 'waves': c['waves'], 'cycles_per_instr': {'f32_int': 2, 'f64': 4},
-            'clock_ghz': CLOCK_GHZ, 'issue_bound_us': bound_us, 'frac': bound_us / kernel_us,
-            'source': 'profiles/r02_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_INSTS_VALU_*_F64, '
-                      'SQ_INSTS_SALU on the same command)'}
+    return {'bound': 'valu_issue', 'valu_per_wave': c['valu_per_wave'], 'valu_f64_per_wave': c['f64_per_wave'],
+            'valu_f64_trans_per_wave': c['f64_trans_per_wave'], 'price_cycles': m['price_cycles'],
+            'share_of_non_f64_at_2_cycles': c['share_of_the_rest_at_2_cycles'], 'clock_ghz': CLOCK_GHZ,
+            'issue_bound_us': c['issue_bound_us'], 'frac': c['issue_bound_us'] / kernel_us,
+            'sq_active_inst_valu_us': c['sq_active_inst_valu_us'], 'sq_active_inst_valu_frac': c['sq_active_inst_valu_us'] / kernel_us,
+            'source': os.path.relpath(path, REPO) + ' (tools/valu_model.py: rocprofv3 --pmc counts x tools/microbench/valu_rate '
+                      'issue costs, split by the static encoding mix of the kernel)', 'measured_at_commit': m.get('measured_at_commit')}
 
 
 # ---------------------------------------------------------------------------- self-launch (N > 1)
@@ -169,10 +190,19 @@ def launch_ranks(n, argv):
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:
-        for p in procs:
-            rc = p.wait() or rc
-            if rc:                                  # a rank failed: its peers would wait in a collective forever
-                break
+        left = list(enumerate(procs))
+        while left and not rc:                      # poll: the FIRST rank to fail ends the job (its peers would wait in a
+            for r, p in list(left):                 # collective forever) and is named
+                code = p.poll()
+                if code is None:
+                    continue
+                left.remove((r, p))
+                if code:
+                    sys.stderr.write('bench.py: rank %d of %d exited with status %d; stopping the other ranks\n' % (r, n, code))
+                    rc = code
+                    break
+            else:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -257,7 +287,7 @@ def main():
     sub_streams = [torch.cuda.Stream(device=device) for _ in subs] if len(subs) > 1 else [None]
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
-    total = args.steps + args.warmup
+    total = args.warmup + REPEATS * args.steps
     actions = torch.randint(0, 4, (total, args.envs), generator=gen, device=device, dtype=torch.int32)
     if args.actions == 'sweep':
         pattern = torch.tensor(([1] * 12 + [0] * 2 + [3] * 12 + [0] * 2), dtype=torch.int32, device=device)
@@ -374,9 +404,7 @@ def main():
 
     run(0, args.warmup)
     stream_sync()
-    pdist.barrier()
-    stream_sync()
-    # kernel time for the roofline: ONE HIP event pair on the launch stream around the whole timed region (the
+    # kernel time for the roofline: ONE HIP event pair on the launch stream around each timed region (the
     # launches are back to back, the host runs ahead), divided by the launches -- an upper bound on the kernel's
     # duration (it includes the ~1 us dispatch gaps) that cannot exceed ms_per_step and does not perturb the run;
     # long runs additionally sample single launches with their own event pairs
@@ -384,15 +412,23 @@ def main():
     for e in subs:
         e.timing(timing_every)
     region_ok = len(subs) == 1 and graph is None
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(main_stream)
-    run(args.warmup, total)
-    ev1.record(main_stream)
-    stream_sync()
-    pdist.barrier()
-    stream_sync()
-    elapsed = time.perf_counter() - t0
+    # the timed region -- EXACTLY --steps steps between barrier + synchronize on both sides, MAX over ranks -- REPEATS
+    # times back to back; the reported value is the median region
+    elapsed_all, region_ms_all = [], []
+    for rep in range(REPEATS):
+        k0 = args.warmup + rep * args.steps
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pdist.barrier()
+        stream_sync()
+        t0 = time.perf_counter()
+        ev0.record(main_stream)
+        run(k0, k0 + args.steps)
+        ev1.record(main_stream)
+        stream_sync()
+        pdist.barrier()
+        stream_sync()
+        elapsed_all.append(pdist.max_over_ranks(time.perf_counter() - t0, device))
+        region_ms_all.append(ev0.elapsed_time(ev1))
     if gatherer is not None:
         gatherer.wait()
     kernel_ms, launches = 0.0, 0
@@ -400,7 +436,9 @@ def main():
         ms_, n_ = e.timing_read()
         kernel_ms, launches = kernel_ms + ms_, launches + n_
         e.timing(0)
-    elapsed = pdist.max_over_ranks(elapsed, device)
+    order = sorted(range(REPEATS), key=lambda r: elapsed_all[r])
+    med = order[REPEATS // 2]
+    elapsed = elapsed_all[med]
 
     episodes = sum(int(e.state()['episode'].sum()) for e in subs) - args.envs
     if rank == 0:
@@ -410,19 +448,21 @@ def main():
         sampled_us = 1e3 * kernel_ms / launches if launches and kernel_ms > 0 else None
         avg_kernel_s = None
         if region_ok and args.policy == 'random':
-            avg_kernel_s = ev0.elapsed_time(ev1) / 1e3 / args.steps       # one step = one step_kernel launch
+            avg_kernel_s = region_ms_all[med] / 1e3 / args.steps       # one step = one step_kernel launch
             assert avg_kernel_s * 1e3 <= ms_per_step * 1.001, \
                 'kernel %.1f us > step %.1f us' % (avg_kernel_s * 1e6, ms_per_step * 1e3)
         elif sampled_us:
             avg_kernel_s = sampled_us / 1e6
         achieved = survey_launch / avg_kernel_s / 1e9 if avg_kernel_s else None
-        traffic = None
+        traffic, traffic_at = None, None
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         # the committed PMC measurement is for the default workload (section / grid) only
         if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' \
                 and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast':
             with open(tpath) as f:
-                traffic = json.load(f).get('bytes_per_launch_%s' % args.obs_mode)
+                tj = json.load(f)
+            traffic = tj.get('bytes_per_launch_%s' % args.obs_mode)
+            traffic_at = tj.get('measured_at_commit', 'round %s (no commit recorded)' % tj.get('round'))
         value = world * args.steps / elapsed
         if args.policy == 'random':
             act_desc = 'on-part serpentine' if args.actions == 'sweep' else 'random'
@@ -439,6 +479,8 @@ def main():
             'metric': 'batched env steps/sec (door panel, N=4096)', 'value': value,
             'unit': 'batched steps/s (%d envs each)' % args.envs, 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'repeats': {'n': REPEATS, 'value_is': 'median', 'values': [world * args.steps / t for t in elapsed_all],
+                        'min': world * args.steps / max(elapsed_all), 'max': world * args.steps / min(elapsed_all)},
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel%s, OBS_MODE=%r%s, %d envs per GPU, '
                                    '%s discrete-4 actions, in-kernel auto-reset'
@@ -455,6 +497,10 @@ def main():
                                          if len(subs) > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
+                         'traffic_over_algorithmic': traffic / survey_launch if traffic else None,
+                         'traffic_measured_at': traffic_at,
+                         'traffic_from': 'profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
+                                         'FETCH_SIZE x2 calibrated on copy_mask_kernel); not measured in this run',
                          'algorithmic_bytes_per_env_step': survey_env, 'bytes_per_launch': survey_launch,
                          'layout_bytes_per_env_step': per_env, 'layout_static_table_bytes': static,
                          'layout_bytes_per_launch': per_launch,

@@ -11,10 +11,22 @@ from . import spaces
 
 
 class ParamTestEnv(spaces.Env):
+    """``OBS_MODE`` (class attribute, read when an env is constructed, pte:99, 132-139): 'section' (four quadrant ratios,
+    pte:66-93), 'grid' (Grid10Observation pte:49-63: 10 x 10 cells of 2 x 2 interior squares -- as in the reference only
+    sizes up to 22 fit), 'direct' (DirectObservation pte:23-30: the whole world), anything else (the reference's 'simple'):
+    no status part.  The agent's position / size is appended in every mode (pte:199-203)."""
     reward_range = (-1e3, 1e3)
     action_space = spaces.Discrete(4)
     OBS_MODE = 'section'
     observation_space = spaces.Box(low=0.0, high=1.0, shape=(6,), dtype=np.float64)
+
+    @classmethod
+    def change_obs_mode(cls, mode, size=22):
+        """Set OBS_MODE and the matching observation_space (the reference derives the space from the class attribute
+        when the class body runs, pte:101-108; 'direct' there is written for size 42)."""
+        cls.OBS_MODE = mode
+        shape = {'section': (6,), 'simple': (2,), 'direct': (size * size + 2,), 'grid': (102,)}.get(mode, (2,))
+        cls.observation_space = spaces.Box(low=0.0, high=1.0, shape=shape, dtype=np.float64)
 
     def __init__(self, size, max_len=900, train_mode=True, termination_by_repeat=False):
         self.size = size
@@ -27,6 +39,8 @@ class ParamTestEnv(spaces.Env):
         self._init_world[:, list(edge)] = 0
         self.init_reward_counter = int(self._init_world.sum())
         self.ACTION_DEF = {0: '>', 1: '^', 2: '<', 3: 'v'}
+        self._obs_mode = self.OBS_MODE                                      # pte:132-139: fixed at construction
+        self._grid_max_counter = int(self.init_reward_counter / 100)           # pte:54
         self.reset()
 
     def get_current_pos(self):
@@ -78,16 +92,28 @@ class ParamTestEnv(spaces.Env):
             return True
         return bool(self._repeat_visit and self.repeat_termination)
 
-    def _observation(self):                                                     # pte:66-93, 199-203
-        x, y = self._i, self._j
+    def _status(self):
         n = self.size
-        inner = self.world[1:n - 1, 1:n - 1]
-        # quadrants of the interior relative to the agent: (i<=x, j<=y), (i<=x, j>y), (i>x, j<=y), (i>x, j>y)
-        xi = max(min(x, n - 2), 0)
-        yj = max(min(y, n - 2), 0)
-        quads = (inner[:xi, :yj], inner[:xi, yj:], inner[xi:, :yj], inner[xi:, yj:])
-        obs = [0 if q.size == 0 else q.sum() / q.size for q in quads]
-        return np.append(np.asarray(obs, dtype=np.float64), [self._i / n, self._j / n])
+        if self._obs_mode == 'section':                                         # pte:66-93
+            x, y = self._i, self._j
+            inner = self.world[1:n - 1, 1:n - 1]
+            # quadrants of the interior relative to the agent: (i<=x, j<=y), (i<=x, j>y), (i>x, j<=y), (i>x, j>y)
+            xi = max(min(x, n - 2), 0)
+            yj = max(min(y, n - 2), 0)
+            quads = (inner[:xi, :yj], inner[:xi, yj:], inner[xi:, :yj], inner[xi:, yj:])
+            return np.asarray([0 if q.size == 0 else q.sum() / q.size for q in quads], dtype=np.float64)
+        if self._obs_mode == 'grid':                                            # pte:49-63 Grid10Observation
+            obs = np.zeros((10, 10), dtype=np.float64)
+            for i in range(1, n - 1):                                           # (row-major like the reference's dict walk:
+                for j in range(1, n - 1):                                       #  the float sums are order dependent)
+                    obs[int(i / 2 + 0.5) - 1][int(j / 2 + 0.5) - 1] += self.world[i, j] / self._grid_max_counter
+            return obs.reshape((100,))
+        if self._obs_mode == 'direct':                                          # pte:23-30 DirectObservation
+            return self.world.astype(np.float64).reshape(-1)
+        return np.array([])                                                     # pte:17-20 NoObservation
+
+    def _observation(self):                                                     # pte:199-203
+        return np.append(self._status(), [self._i / self.size, self._j / self.size])
 
     def step(self, action):                                                     # pte:218-236
         immediate = self._move(action)

@@ -216,7 +216,7 @@ def table_digest(drv):
                 normals_head=fn[:32], normals_tail=fn[-32:], construct_s=np.float64(drv.construct_s))
 
 
-def param_test_golden(pte):
+def param_test_golden(pte, cases=((22, 'zigzag'), (20, 'spiral'), (14, 'zigzag'))):
     """G1: ParamTestEnv trajectories under this project's zigzag / spiral drivers."""
     out = {}
 
@@ -263,11 +263,26 @@ def param_test_golden(pte):
         return dict(actions=np.asarray(acts, dtype=np.int32), obs=np.asarray(O, dtype=np.float64),
                     reward=np.asarray(R, dtype=np.float64), done=np.asarray(D, dtype=bool))
 
-    for size, pol in ((22, 'zigzag'), (20, 'spiral'), (14, 'zigzag')):
+    for size, pol in cases:
         r = run(size, pol)
         for k, v in r.items():
             out['%s%d_%s' % (pol, size, k)] = v
     return out
+
+
+def main_param_test_modes():
+    """G1 for the other OBS_MODEs of ParamTestEnv (pte:17-64, 132-139): 'grid' (Grid10Observation), 'direct'
+    (DirectObservation), 'simple' (NoObservation) under the zigzag driver -> g1_param_test_modes.npz."""
+    rge, bpw, rob, pte, stub = ref_import.load_reference('hull')
+    out = {}
+    for mode, size in (('grid', 22), ('direct', 12), ('simple', 14), ('grid', 16)):
+        pte.ParamTestEnv.OBS_MODE = mode
+        g = param_test_golden(pte, cases=((size, 'zigzag'),))
+        for k, v in g.items():
+            out['%s_%s' % (mode, k)] = v
+    pte.ParamTestEnv.OBS_MODE = 'section'
+    np.savez_compressed(os.path.join(HERE, 'g1_param_test_modes.npz'), **out)
+    print({k: v.shape for k, v in out.items()})
 
 
 def main_termination():
@@ -410,5 +425,7 @@ def save_episodes(tag, eps):
 if __name__ == '__main__':
     if '--termination' in sys.argv:
         main_termination()
+    elif '--param-test-modes' in sys.argv:
+        main_param_test_modes()
     else:
         main()

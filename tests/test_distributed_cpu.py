@@ -1,4 +1,4 @@
-"""World-size-2 gloo tests of the env-shard layer (no GPU): shard ranges, per-rank seeds,
+"""World-size-2 and -8 gloo tests of the env-shard layer (no GPU): shard ranges, per-rank seeds,
 the all_gather of episode returns, MAX-over-ranks timing, and shard equivalence through the oracle."""
 import os
 import socket
@@ -29,7 +29,7 @@ def _worker(rank, world, port, out_dir):
     from conftest import synthetic_tables
     r, lr, w = pdist.init_process_group('gloo')
     assert (r, w) == (rank, world)
-    n_total, steps = 8, 12
+    n_total, steps = 16, 12
     lo, hi = pdist.shard_range(n_total, rank, world)
     tables = synthetic_tables('door_test')
     sp = part_tables.start_points(tables, 'all')
@@ -46,30 +46,37 @@ def _worker(rank, world, port, out_dir):
     pdist.barrier()
     np.save(os.path.join(out_dir, 'rank%d.npy' % rank), gathered.numpy())
     assert tmax == float(world)
-    assert pdist.rank_seed(5678, 0) != pdist.rank_seed(5678, 1)
+    assert len({pdist.rank_seed(5678, r) for r in range(world)}) == world
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_shard_equals_single_rank(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_ranks_equal_single_rank(tmp_path, world):
+    """World size 2 and 8 (the node BASELINE.json's config 4 names): every rank's all_gather of the episode returns
+    equals one rank running all the envs."""
     import oracle
     from conftest import synthetic_tables
     from paintrl_amd import part_tables
-    world = 2
+    oracle.build()                                        # once, before the ranks start
+    synthetic_tables('door_test')
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    g0, g1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
-    assert np.array_equal(g0, g1) and g0.shape == (8,)
-    # the gathered per-env returns equal one rank running all 8 envs
+    g = [np.load(tmp_path / ('rank%d.npy' % r)) for r in range(world)]
+    assert all(np.array_equal(g[0], x) for x in g[1:]) and g[0].shape == (16,)
+    # the gathered per-env returns equal one rank running all 16 envs
     tables = synthetic_tables('door_test')
     sp = part_tables.start_points(tables, 'all')
     rng = np.random.RandomState(3)
-    start = rng.randint(0, len(sp), size=8)
-    acts = rng.randint(0, 4, size=(12, 8))
-    env = oracle.Oracle(tables, 8, start_points=sp)
+    start = rng.randint(0, len(sp), size=16)
+    acts = rng.randint(0, 4, size=(12, 16))
+    env = oracle.Oracle(tables, 16, start_points=sp)
     env.reset(start)
     for k in range(12):
         env.step(acts[k])
-    want = np.array([env.state(i)['total_return'] for i in range(8)])
-    assert np.array_equal(g0, want)
+    want = np.array([env.state(i)['total_return'] for i in range(16)])
+    assert np.array_equal(g[0], want)
 
 
 def test_shard_range_validation():
@@ -81,3 +88,19 @@ def test_shard_range_validation():
         pass
     else:
         raise AssertionError('uneven shard must be rejected')
+
+
+def test_bench_launcher_names_the_failing_rank():
+    """`python bench.py --gpus 8` started plainly becomes the launcher of its 8 ranks; here (no GPU) every rank fails at
+    once, and the launcher must stop the others, name a failed rank and pass its status on."""
+    import subprocess
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip('needs a box without a GPU: the ranks must fail')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                          '--envs', '64', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert 'of 8 exited with status' in out.stderr, out.stderr[-1500:]

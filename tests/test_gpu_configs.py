@@ -164,18 +164,19 @@ def test_two_ranks_on_one_device_equal_single_rank(tmp_path):
     env.close()
 
 
-def test_bench_self_launches_two_ranks(tmp_path):
+@pytest.mark.parametrize('ranks', [2, 4])
+def test_bench_self_launches_its_ranks(tmp_path, ranks):
     """`python bench.py --gpus 2` started plainly spawns its own ranks (here both on GPU 0 over gloo) and rank 0
     prints the one JSON line with the world size it really ran at."""
     env = dict(os.environ, PAINTRL_SINGLE_DEVICE='1', PAINTRL_DIST_BACKEND='gloo')
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
-    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '120', '--warmup',
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(ranks), '--steps', '120', '--warmup',
                           '10', '--envs', '512', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and 'world size 2' in rec['config']['parallelism']
+    assert rec['n_gpus'] == ranks and 'world size %d' % ranks in rec['config']['parallelism']
     assert rec['value'] > 0 and rec['roofline']['avg_kernel_us'] <= 1e3 * rec['ms_per_step'] * 1.001

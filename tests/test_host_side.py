@@ -66,6 +66,27 @@ def test_param_test_env_golden(size, driver, steps, total):
         env.step(7)
 
 
+@pytest.mark.parametrize('mode,size', [('grid', 22), ('direct', 12), ('simple', 14), ('grid', 16)])
+def test_param_test_env_observation_modes(mode, size):
+    """G1 for the other OBS_MODEs (pte:17-64): Grid10Observation, DirectObservation, NoObservation -- every observation,
+    reward and done flag of the reference's run under the same actions."""
+    z = np.load(os.path.join(GOLDEN, 'g1_param_test_modes.npz'))
+    key = '%s_zigzag%d' % (mode, size)
+    try:
+        ParamTestEnv.change_obs_mode(mode, size)
+        env = ParamTestEnv(size)
+        obs = env.reset()
+        assert obs.shape == z[key + '_obs'][0].shape == ParamTestEnv.observation_space.shape
+        assert np.array_equal(obs, z[key + '_obs'][0])
+        for k, a in enumerate(z[key + '_actions']):
+            o, r, d, info = env.step(int(a))
+            assert np.array_equal(o, z[key + '_obs'][k + 1]), k
+            assert r == z[key + '_reward'][k] and d == z[key + '_done'][k]
+        assert d
+    finally:
+        ParamTestEnv.change_obs_mode('section')
+
+
 def test_capi_exports_every_declared_symbol():
     """The shared library loads without a GPU and exports exactly what include/paintrl.h declares."""
     header = open(os.path.join(REPO, 'include', 'paintrl.h')).read()

@@ -9,6 +9,18 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def head_commit():
+    """The commit the profiles were measured on: collect them right after committing (the GPU box gets a snapshot of
+    the working tree, so HEAD is what ran unless the tree was dirty -- then the suffix says so)."""
+    import subprocess
+    try:
+        h = subprocess.check_output(['git', '-C', REPO, 'rev-parse', '--short', 'HEAD'], text=True).strip()
+        dirty = subprocess.check_output(['git', '-C', REPO, 'status', '--porcelain', '--', 'paintrl_amd', 'bench.py', 'include'], text=True).strip()
+        return h + ('+dirty' if dirty else '')
+    except Exception:  # noqa: BLE001
+        return 'unknown'
+
+
 def counters(d, kernel='step_kernel'):
     acc, waves = {}, None
     files = sorted(glob.glob(d + '/**/*counter_collection.csv', recursive=True), key=os.path.getmtime)
@@ -49,7 +61,7 @@ def main():
         pw = {k: v / waves for k, v in merged.items()}
         f64 = sum(pw.get(k, 0) for k in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64',
                                         'SQ_INSTS_VALU_TRANS_F64'))
-        sq[mode] = {'waves': waves, 'valu_per_wave': pw.get('SQ_INSTS_VALU'), 'valu_f64_per_wave': f64,
+        sq[mode] = {'measured_at_commit': head_commit(), 'valu_trans_f64_per_wave': pw.get('SQ_INSTS_VALU_TRANS_F64'), 'waves': waves, 'valu_per_wave': pw.get('SQ_INSTS_VALU'), 'valu_f64_per_wave': f64,
                     'salu_per_wave': pw.get('SQ_INSTS_SALU'), 'vmem_rd_per_wave': pw.get('SQ_INSTS_VMEM_RD'),
                     'vmem_wr_per_wave': pw.get('SQ_INSTS_VMEM_WR'), 'smem_per_wave': pw.get('SQ_INSTS_SMEM'),
                     'lds_per_wave': pw.get('SQ_INSTS_LDS'), 'branch_per_wave': pw.get('SQ_INSTS_BRANCH'),
@@ -70,7 +82,7 @@ def main():
     known = 65536 * 158 * 8.0
     if cf and cw:
         fcorr, wcorr = known / (cf['FETCH_SIZE'] * 1024.0), known / (cw['WRITE_SIZE'] * 1024.0)
-        out = {'round': tag, 'calibration': {'kernel': 'copy_mask_kernel (tools/hbm_calibration.py)', 'known_bytes_each_way': known,
+        out = {'round': tag, 'measured_at_commit': head_commit(), 'calibration': {'kernel': 'copy_mask_kernel (tools/hbm_calibration.py)', 'known_bytes_each_way': known,
                                              'FETCH_SIZE_KB': cf['FETCH_SIZE'], 'WRITE_SIZE_KB': cw['WRITE_SIZE'],
                                              'fetch_correction': fcorr, 'write_correction': wcorr,
                                              'note': 'gfx950 FETCH_SIZE reads 1/2 of the bytes of a coalesced stream '
@@ -87,6 +99,9 @@ def main():
                                                 'dispatches_averaged': [nf.get('FETCH_SIZE'), nw.get('WRITE_SIZE')]}
                 out['bytes_per_launch_%s' % mode] = rd + wr
         json.dump(out, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+    for name in ('valu_rate.json', 'valu_rate.txt'):
+        if os.path.isfile(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
     print('profiles/ updated from', src)
 
 
