@@ -413,15 +413,15 @@ static void ball_query(const OrPart *p, double radius, const double *c, uint64_t
     }
 }
 
-/* rob:280-285 _paint + bpw:562-566 paint: cone beams -> nearest sample per hit.
+/* rob:280-285 _paint + bpw:562-566 paint: cone beams -> nearest sample per hit, in beam order (`list`, one entry per
+ * beam that hits: a sample under several beams appears several times, as in pixel_kd_tree.query(points, k=1)[1]).
  * returns number of beam hits (0 => the reference returns early without touching last-shot state) */
-static int cone_query(const OrPart *p, const double *pose, const double *quat, uint64_t *cur) {
+static int cone_query(const OrPart *p, const double *pose, const double *quat, uint64_t *cur, int *list) {
     int hits = 0;
     for (int b = 0; b < p->n_beams; ++b) {
         double dst[3], t, hit[3];
         transform_point(pose, quat, p->beams + 3 * b, dst);
         if (ray_closest(p, pose, dst, &t, hit) < 0) continue;
-        ++hits;
         int best = 0;
         double best_d = INFINITY;
         for (int s = 0; s < p->n_samples; ++s) {
@@ -431,8 +431,48 @@ static int cone_query(const OrPart *p, const double *pose, const double *quat, u
             if (d2 < best_d) { best_d = d2; best = s; }
         }
         cur[best >> 6] |= (uint64_t)1 << (best & 63);
+        if (list) list[hits] = best;
+        ++hits;
     }
     return hits;
+}
+
+/* COLOR_MODE = 'HSI' under the cone beams (bpw:562-566 paint -> bpw:419-434 change_pixels with the list of nearest
+ * samples, duplicates and all): r = the largest distance of a listed sample to the shot centre; then IN LIST ORDER every
+ * entry deposits quantity = int(25 (1 - (d / r)^2)) + 1 on its sample unless the byte is 0 at that moment (uint8
+ * arithmetic, wrapping) and adds quantity / 255 to the succeed counter -- a sample under k beams receives k deposits.
+ * The float sum runs in beam order here, the reference's own order. */
+static double apply_paint_hsi_list(const OrPart *p, int words, uint64_t *painted, uint64_t *last, const uint64_t *cur,
+                                   uint64_t *uni, uint8_t *thick, const double *c, const int *list, int n) {
+    double r = -1.0, succeeded = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double *x = p->sample_pos + 3 * list[k];
+        double dx = c[0] - x[0], dy = c[1] - x[1], dz = c[2] - x[2];
+        double d = sqrt((dx * dx + dy * dy) + dz * dz);
+        if (d > r) r = d;
+    }
+    for (int k = 0; k < n; ++k) {
+        const int s = list[k];
+        const double *x = p->sample_pos + 3 * s;
+        double dx = c[0] - x[0], dy = c[1] - x[1], dz = c[2] - x[2];
+        double d = sqrt((dx * dx + dy * dy) + dz * dz);
+        double q = d / r;
+        int quantity = (int)(25 * (1 - q * q)) + 1;
+        if (thick[s] != 0) {
+            thick[s] = (uint8_t)(thick[s] - quantity);
+            succeeded += quantity / 255.0;
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        const int s = list[k];
+        if (thick[s] == 255) painted[s >> 6] |= (uint64_t)1 << (s & 63);
+        else painted[s >> 6] &= ~((uint64_t)1 << (s & 63));
+    }
+    for (int w = 0; w < words; ++w) {
+        uni[w] |= cur[w] & ~last[w];
+        last[w] = cur[w];
+    }
+    return succeeded;
 }
 
 /* bpw:844-851 */
@@ -640,8 +680,21 @@ void or_step(const OrPart *p, const OrConfig *c, OrEnv *env, uint64_t *painted_a
                     succeeded += apply_paint_hsi(p, words, painted, last, cur, uni, thick_all + (size_t)i * p->n_samples, center);
                 else
                     succeeded += apply_paint(words, painted, last, cur, uni);
-            } else if (cone_query(p, pos, quat, cur) > 0) {
-                succeeded += apply_paint(words, painted, last, cur, uni);
+            } else {
+                int *list = c->color_mode == COLOR_HSI ? (int *)malloc(sizeof(int) * (size_t)(p->n_beams > 0 ? p->n_beams : 1)) : NULL;
+                const int hits = cone_query(p, pos, quat, cur, list);
+                if (hits > 0) {
+                    if (c->color_mode == COLOR_HSI) {
+                        static const double tip[3] = {0.0, 0.0, 0.1};
+                        double center[3];
+                        transform_point(pos, quat, tip, center);    /* rob:277-278, 285 */
+                        succeeded += apply_paint_hsi_list(p, words, painted, last, cur, uni, thick_all + (size_t)i * p->n_samples,
+                                                          center, list, hits);
+                    } else {
+                        succeeded += apply_paint(words, painted, last, cur, uni);
+                    }
+                }
+                free(list);
             }
         }
         int pixel_counter = 0;

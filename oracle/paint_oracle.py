@@ -132,7 +132,7 @@ class Oracle(object):
                  n_discrete=4, termination_mode='late', turning_penalty=False, overlap_penalty=False,
                  paint_method='fast', max_episode_len=245, expected_episode_len=245, switch_threshold=0.9,
                  max_possible_point=9148, start_points=None, threads=1, paint_radius=None, step_size=0.051,
-                 color_mode='RGB'):
+                 color_mode='RGB', beams=None):
         self.lib = _load()
         t = tables
         self.tables = t
@@ -166,7 +166,7 @@ class Oracle(object):
                     tri_normal=_f64(t.tri_normal[front_ids]),
                     col_v0=_f64(t.col_v0), col_e1=_f64(t.col_e1), col_e2=_f64(t.col_e2),
                     grid_lo=_f64(t.grid_lo), grid_hi=_f64(t.grid_hi), start_pos=sp, start_quat=sq,
-                    beams=_f64(t.beams))
+                    beams=_f64(t.beams if beams is None else beams).reshape(-1, 3))
         n_kd = len(getattr(t, 'kd_split_dim', ()))
         if n_kd:                                   # the reference's stale vertex tree (part_tables.stale_kd_query)
             compact = -np.ones(t.vertices.shape[0], dtype=np.int64)
@@ -202,8 +202,6 @@ class Oracle(object):
         c.paint_radius = float(getattr(t, 'paint_radius', 0.051) if paint_radius is None else paint_radius)
         c.step_size = float(step_size)
         c.color_mode = {'RGB': 0, 'HSI': 1}[color_mode]
-        if color_mode == 'HSI' and paint_method != 'fast':
-            raise NotImplementedError("COLOR_MODE='HSI' is restated for PAINT_METHOD='fast' only")
         self._act = discrete_action_table(n_discrete, step_size)
         c.act_delta1, c.act_delta2, c.act_angle = (_ptr(a) for a in self._act)
         self.cfg = c

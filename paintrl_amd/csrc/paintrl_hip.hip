@@ -618,8 +618,6 @@ int check_config(const PrlConfig *c) {
     if (c->termination_mode < 0 || c->termination_mode > 2) return fail(PRL_E_INVALID, "termination_mode");
     if (c->paint_method != PRL_PAINT_FAST && c->paint_method != PRL_PAINT_NORMAL) return fail(PRL_E_INVALID, "paint_method");
     if (c->color_mode != PRL_COLOR_RGB && c->color_mode != PRL_COLOR_HSI) return fail(PRL_E_INVALID, "color_mode");
-    if (c->color_mode == PRL_COLOR_HSI && c->paint_method != PRL_PAINT_FAST)
-        return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for PAINT_METHOD 'fast'");
     if (c->max_episode_len < 1 || c->expected_episode_len < 1) return fail(PRL_E_INVALID, "episode lengths");
     if (!(c->paint_radius > 0) || !(c->step_size > 0)) return fail(PRL_E_INVALID, "paint_radius and step_size must be positive");
     return PRL_OK;

@@ -21,7 +21,7 @@ FAR = 1.0e15             # coordinate of padding samples
 class DeviceTables(object):
     """Numpy arrays in device layout + the ctypes struct that points at them."""
 
-    def __init__(self, tables, obs_grad=4, start_points=None):
+    def __init__(self, tables, obs_grad=4, start_points=None, beams=None):
         t = tables
         a1, a2 = t.a1, t.a2
         self.tables = t
@@ -248,7 +248,9 @@ class DeviceTables(object):
         self.start_pos = np.asarray([p[0] for p in start_points], dtype=np.float64).reshape(-1, 3)
         self.start_quat = np.asarray([pt.pose_orn_quaternion(p[1]) for p in start_points],
                                      dtype=np.float64).reshape(-1, 4)
-        self.beams = np.ascontiguousarray(t.beams, dtype=np.float64)
+        # cone beams of PAINT_METHOD 'normal': the part's uniform lattice (rob:23-35), or the caller's table -- COLOR_MODE
+        # 'HSI' draws its own (part_tables.beta_plain, rob:38-69)
+        self.beams = np.ascontiguousarray(t.beams if beams is None else beams, dtype=np.float64).reshape(-1, 3)
 
     # ------------------------------------------------------------------
     def c_struct(self):

@@ -718,6 +718,36 @@ def cone_beams(density):
     return np.asarray(out, dtype=np.float64).reshape(-1, 3)
 
 
+def beta_plain(density, beta=2, expected_points=450, uniform=None):
+    """robot._get_beta_plain (rob:38-69): the beam table of COLOR_MODE 'HSI' -- rings of one beam pitch, the i-th of
+    ``circles`` holding round(450 w_i / sum w) beams, w_i = (1 - (i / circles)^2)^(beta - 1), at equal angles and at a
+    radius drawn with ``uniform(lower, upper)`` per beam.  The reference draws from Python's ``random`` module
+    (``from random import uniform``, rob:4): with the default ``uniform`` and the same ``random.seed`` this returns the
+    reference's own table; any other source gives a table of the same law (the table is data: PartTables.beams)."""
+    import random
+    uniform = uniform or random.uniform
+    ratio = 0.2 / 0.5
+    radius = 0.25 * ratio
+    resolution = 1.8 / math.sqrt(density)
+    plane = 0.2
+    circles = math.ceil(radius / resolution)
+    distribution, total = {}, 0
+    for i in range(1, circles + 1):
+        distribution[i] = (1 - (i / circles) ** 2) ** (beta - 1)
+        total += distribution[i]
+    for i in distribution:
+        distribution[i] = round(expected_points * distribution[i] / total)
+    out = []
+    for i in range(1, circles + 1):
+        lower, upper = (i - 1) * resolution, i * resolution
+        angle_resolution = 2 * math.pi / distribution[i] if distribution[i] else 0
+        for j in range(distribution[i]):
+            r = uniform(lower, upper)
+            theta = j * angle_resolution
+            out.append((r * np.cos(theta), r * np.sin(theta), plane))          # rob:143-146 pol2cart
+    return np.asarray(out, dtype=np.float64).reshape(-1, 3)
+
+
 # ----------------------------------------------------------------------------
 # on-disk table format (SURVEY.md 8f-2): one .npz per part
 # ----------------------------------------------------------------------------

@@ -43,6 +43,7 @@ class Robot(object):
     PAINT_PER_ACTION = 5                 # compile-time constant of the kernel
     NOT_ON_PART_TERMINATE_STEPS = 1000
     PAINT_METHOD = 'fast'                # 'fast' (ball query, bpw:568-570) | 'normal' (cone beams, rob:280-285)
+    BETA = 2                             # rob:169: the beta of the thickness profile (COLOR_MODE 'HSI' beam table)
 
     def __init__(self, env):
         self._env = env
@@ -125,8 +126,12 @@ class PaintGymEnv(spaces.Env):
         self._tables = load_part_tables(path, collision_mode, self.OBS_GRAD)
         self._start_points = _pt.start_points(self._tables, self.START_POINT_MODE)
         n_disc = self.action_space.n if self.ACTION_MODE != 'continuous' else 4
+        # rob:244-249 set_up_paint_params: COLOR_MODE 'RGB' casts the uniform lattice of beams, 'HSI' the beta-profile rings
+        # whose radii are drawn with random.uniform (rob:38-69) -- from Python's `random`, like the reference
+        self._paint_plain = _pt.beta_plain(self._tables.density, Robot.BETA) if self.COLOR_MODE == 'HSI' else None
         self._batch = BatchedPaintEnv(
-            DeviceTables(self._tables, obs_grad=self.OBS_GRAD, start_points=self._start_points), 1, device=device,
+            DeviceTables(self._tables, obs_grad=self.OBS_GRAD, start_points=self._start_points, beams=self._paint_plain),
+            1, device=device,
             obs_mode=self.OBS_MODE, obs_grad=self.OBS_GRAD, action_mode=self.ACTION_MODE,
             action_dim=self.ACTION_SHAPE if self.ACTION_MODE == 'continuous' else 1, n_discrete=n_disc,
             termination_mode=self.TERMINATION_MODE, turning_penalty=self.TURNING_PENALTY,

@@ -145,8 +145,43 @@ def hsi_door():
     save_episodes(os.path.join(HERE, 'episodes_door_hsi.npz'), eps)
 
 
+def hsi_cone_door():
+    """COLOR_MODE='HSI' with PAINT_METHOD='normal' (rob:38-69 beta-profile cone + bpw:384-434, 562-566): the beam table is
+    drawn with random.uniform when the env is constructed (rob:244-249), so the generator seeds `random` first and the
+    table is recorded with the episodes (it is data).  A beam cone paints the sample nearest to every hit, once per hit:
+    a sample under several beams receives several deposits in one shot."""
+    import random
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    random.seed(4242)
+    drv = RefDriver(root, 0, extra={'COLOR_MODE': 'HSI'})
+    beams = np.array(drv.env.robot._paint_plain, dtype=np.float64)
+    eps = {}
+
+    def run(name, seed, policy, max_steps, want_idx):
+        ep = drv.episode(seed, policy, max_steps=max_steps, want_idx=want_idx)
+        part = drv.part
+        ep['final_thick'] = np.array([int(part.texels[part.get_texel(*p)]) for p in drv.pix], dtype=np.uint8)
+        ep['beams'] = beams
+        cfg = json.loads(str(ep['cfg']))
+        cfg['color_mode'] = 'HSI'
+        cfg['beams_seed'] = 4242
+        ep['cfg'] = json.dumps(cfg)
+        eps[name] = ep
+
+    drv.configure('section', 4, 'anchor', paint_method='normal')
+    run('g15_hsi_cone_serpentine', 8, zigzag_policy_grid(), 40, 0)
+    run('g15_hsi_cone_random', 101, random_policy(11), 30, 2)
+    drv.configure('grid', 4, 'all', overlap=True, paint_method='normal')
+    run('g15_hsi_cone_grid_overlap', 203, random_policy(43), 25, None)
+    save_episodes(os.path.join(HERE, 'episodes_door_hsi_cone.npz'), eps)
+    print('beams', beams.shape, 'density', drv.part.get_density())
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['digests', 'big', 'door_rr']
+    if 'hsi_cone' in what:
+        hsi_cone_door()
     if 'hsi' in what:
         hsi_door()
     if 'sparse' in what:

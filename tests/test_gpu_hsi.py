@@ -87,8 +87,6 @@ def test_hsi_bytes_wrap_and_auto_reset():
 def test_hsi_limits_are_reported():
     from paintrl_amd import _lib
     tables = synthetic_tables('door_test')
-    with pytest.raises(_lib.PaintRLError, match='HSI'):
-        _env(tables, 4, color_mode='HSI', paint_method='normal')
     big = synthetic_tables('door_rr_big', tex_size=(320, 320))
     with pytest.raises(_lib.PaintRLError, match='HSI'):
         _env(big, 4, color_mode='HSI')
@@ -119,3 +117,41 @@ def test_hsi_replays_reference_episode(name):
     replay(step, reset, ep, exact=False, atol=TOL)
     assert np.array_equal(env.thickness(0), ep['final_thick'])
     env.close()
+
+
+def test_hsi_under_cone_beams_matches_oracle():
+    """COLOR_MODE='HSI' with PAINT_METHOD='normal' (rob:38-69 beta-profile beam table + bpw:419-434 on the
+    list of nearest samples): a sample under k beams receives k deposits per shot.  Bytes, status bits, observations,
+    done flags and poses exact; rewards to 1e-12 (the reference sums in beam order, the device in lane order)."""
+    import random
+    from paintrl_amd import part_tables
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    random.seed(7)
+    beams = part_tables.beta_plain(tables.density)
+    assert beams.shape == (450, 3)
+    n, steps = 48, 8
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    kw = dict(color_mode='HSI', paint_method='normal', obs_mode='grid', overlap_penalty=True)
+    env = BatchedPaintEnv(DeviceTables(tables, start_points=sp, beams=beams), n, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, beams=beams, **kw)
+    rng = np.random.RandomState(5)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    multi = 0
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=TOL) and np.allclose(i.cpu().numpy(), ii, rtol=0, atol=TOL)
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        assert np.array_equal(env.thickness(), orc.thick), 'thickness bytes, step %d' % k
+        multi += int((orc.thick < 255 - 26).sum())                    # more than one deposit's worth gone from a byte
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    assert multi > 100
+    env.close()
+

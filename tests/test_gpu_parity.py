@@ -9,11 +9,11 @@ from test_oracle_golden import CASES, PART, replay
 pytestmark = pytest.mark.gpu
 
 
-def _gpu_env(tables, n, start_points, **kw):
+def _gpu_env(tables, n, start_points, beams=None, **kw):
     from paintrl_amd.batched_env import BatchedPaintEnv
     from paintrl_amd.device_tables import DeviceTables
     obs_grad = kw.get('obs_grad', 4)
-    return BatchedPaintEnv(DeviceTables(tables, obs_grad=obs_grad, start_points=start_points), n, **kw)
+    return BatchedPaintEnv(DeviceTables(tables, obs_grad=obs_grad, start_points=start_points, beams=beams), n, **kw)
 
 
 DEVICE_CASES = CASES
@@ -25,8 +25,8 @@ def test_gpu_replays_reference_episode(tag, name):
     cfg = ep['cfg']
     tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
     hsi = cfg.get('color_mode', 'RGB') == 'HSI'
-    env = _gpu_env(tables, 1, start_points_for(tables, cfg['start_mode']), color_mode=cfg.get('color_mode', 'RGB'),
-                   **env_kwargs_from_cfg(cfg))
+    env = _gpu_env(tables, 1, start_points_for(tables, cfg['start_mode']), beams=ep.get('beams'),
+                   color_mode=cfg.get('color_mode', 'RGB'), **env_kwargs_from_cfg(cfg))
     continuous = cfg['action_mode'] == 'continuous'
 
     def reset(idx):

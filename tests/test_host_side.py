@@ -244,3 +244,17 @@ def test_stale_kd_tree_walk_equals_scipy_on_moved_rows():
         qq = np.ascontiguousarray(q, dtype=np.float64)
         v = lib.or_nearest_vertex(C.byref(orc.part), qq.ctypes.data_as(C.POINTER(C.c_double)))
         assert side_ids[v] == w
+
+
+def test_beta_plain_is_the_reference_table():
+    """part_tables.beta_plain restates rob:38-69: with the random stream in the state the reference's constructor has it
+    in (six draws after random.seed(4242)) it returns the recorded table bit for bit."""
+    import random
+    from paintrl_amd import part_tables
+    from conftest import load_episodes, synthetic_tables
+    ep = load_episodes('door_hsi_cone')['g15_hsi_cone_random']
+    tables = synthetic_tables('door_test')
+    random.seed(4242)
+    for _ in range(6):
+        random.random()
+    assert np.array_equal(part_tables.beta_plain(tables.density), ep['beams'])

@@ -10,11 +10,11 @@ import os
 
 from conftest import GOLDEN
 
-TAGS = [t for t in ('door', 'sheet', 'sheet_tool', 'door_big', 'door_hsi', 'sparse', 'door_term', 'sheet_term')
+TAGS = [t for t in ('door', 'sheet', 'sheet_tool', 'door_big', 'door_hsi', 'sparse', 'door_term', 'sheet_term', 'door_hsi_cone')
         if os.path.isfile(os.path.join(GOLDEN, 'episodes_%s.npz' % t))]
 CASES = [(tag, n) for tag in TAGS for n in sorted(load_episodes(tag))]
 PART = {'door': 'door_test', 'sheet': 'square', 'sheet_tool': 'square', 'door_big': 'door_rr_big', 'door_hsi': 'door_test',
-        'sparse': 'test', 'door_term': 'door_test', 'sheet_term': 'square'}
+        'sparse': 'test', 'door_term': 'door_test', 'sheet_term': 'square', 'door_hsi_cone': 'door_test'}
 
 
 def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
@@ -46,7 +46,7 @@ def test_oracle_replays_reference_episode(tag, name):
     tables = synthetic_tables(PART[tag], cfg.get('paint_radius', 0.051))
     hsi = cfg.get('color_mode', 'RGB') == 'HSI'
     orc = oracle.Oracle(tables, 1, start_points=start_points_for(tables, cfg['start_mode']),
-                        color_mode=cfg.get('color_mode', 'RGB'), **env_kwargs_from_cfg(cfg))
+                        color_mode=cfg.get('color_mode', 'RGB'), beams=ep.get('beams'), **env_kwargs_from_cfg(cfg))
     continuous = cfg['action_mode'] == 'continuous'
 
     def reset(idx):
