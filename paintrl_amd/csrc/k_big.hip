@@ -13,7 +13,7 @@ namespace {
 template <int KW, bool GENSEC>
 __global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const PrlConfig *cfg, double *out) {
     const int lane = threadIdx.x & 63;
-    const int s = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int s = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     PartRef P = *(const PartDev CAS *)part;
     CfgRef C = *(const PrlConfig CAS *)cfg;
     if (s >= P.n_start) return;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, con
     if constexpr (KW == 0) {
         extern __shared__ uint64_t big_lds[];
         uint64_t *m = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * P.n_words;
-        for (int w = lane; w < P.n_words; w += 64) m[w] = 0;
+        for (int w = lane; w < P.n_words; w += 64) m[w] = hsi ? ldg(P.word_valid, w) : 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -44,14 +44,15 @@ __device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, in
     const int wave = rfl((int)(threadIdx.x >> 6));
     uint64_t *base = big_lds + (size_t)wave * copies * a.mask_stride;
     return BigMasks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, base,
-                    base + (copies > 1 ? a.mask_stride : 0), base + (copies > 2 ? 2 * a.mask_stride : 0), n_words, lane};
+                    base + (copies > 1 ? a.mask_stride : 0), base + (copies > 2 ? 2 * a.mask_stride : 0), n_words, lane,
+                    base + (copies > 3 ? 3 * a.mask_stride : 0)};
 }
 
-template <bool GENSEC, bool KD>
+template <bool GENSEC, bool KD, bool HSI>
 __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     const WaveLds wl = wave_lds<GENSEC, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const BigMasks masks = big_masks(a, env, P.n_words, lane, 3);
+    const BigMasks masks = big_masks(a, env, P.n_words, lane, HSI ? 4 : 3);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
-    const int dn = step_env<0, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+    const int dn = step_env<0, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                     new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
 template <bool GENSEC>
 __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
     const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     if (a.reset_mask && !a.reset_mask[env]) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
@@ -81,9 +82,14 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
     int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
     reset_state(P, S, start);
+    const bool hsi = C.color_mode == PRL_COLOR_HSI;                    // every byte 255, every real sample reads "painted"
     for (int w = lane; w < P.n_words; w += 64) {
-        a.painted[(size_t)env * a.mask_stride + w] = 0;
+        a.painted[(size_t)env * a.mask_stride + w] = hsi ? ldg(P.word_valid, w) : 0;
         a.last[(size_t)env * a.mask_stride + w] = 0;
+    }
+    if (hsi) {
+        uint64_t *t8 = reinterpret_cast<uint64_t *>(a.thick + (size_t)env * 64 * a.mask_stride);
+        for (int i = lane; i < 8 * P.n_words; i += 64) t8[i] = ~0ull;
     }
     store_state(a.state + (size_t)env * PRL_STATE_DOUBLES, S, lane);
     if (a.obs) {
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
 template <bool GENSEC>
 __global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
     const int lane = threadIdx.x & 63;
-    const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
     CfgRef C = *(const PrlConfig CAS *)a.cfg;
@@ -110,15 +116,159 @@ __global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
                             wave_lds<GENSEC>().cnt);
 }
 
-// Large parts: dynamic LDS = 4 waves x copies x mask_stride words.
-int launch_big(void (*kernel)(StepArgs), const StepArgs &a, int copies, hipStream_t s) {
-    const size_t lds = (size_t)4 * copies * a.mask_stride * sizeof(uint64_t);
+// PAINT_METHOD 'normal' on a large part: the finish kernel of k_cone.hip with the masks in LDS (painted, last, the union of
+// the shots' valid sets, the shot being folded, and with COLOR_MODE 'HSI' its status bits: five copies of n_words words).
+template <bool GENSEC, bool HSI>
+__global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int list_off) {
+    extern __shared__ uint64_t big_lds[];
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+    const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    const WaveLds wl = wave_lds<GENSEC, false>();
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
+    load_state_accumulators(state_rec, S);
+    const double new_angle = uni_d(a.cone_aux[2 * (size_t)env]);
+    const double pair = a.cone_aux[2 * (size_t)env + 1];
+    const int counter_before = rfl(__double2loint(pair)), facet_hint = rfl(__double2hiint(pair));
+    constexpr int COPIES = HSI ? 5 : 4;
+    uint64_t *base = big_lds + (size_t)wave * COPIES * a.mask_stride;
+    uint64_t *painted = base, *last = base + a.mask_stride, *valid = base + 2 * a.mask_stride, *row = base + 3 * a.mask_stride;
+    uint64_t *stat = base + (HSI ? 4 : 3) * a.mask_stride;
+    uint64_t *g_painted = a.painted + (size_t)env * a.mask_stride, *g_last = a.last + (size_t)env * a.mask_stride;
+    const int nw = P.n_words;
+    for (int w = lane; w < nw; w += 64) {
+        painted[w] = g_painted[w];
+        last[w] = g_last[w];
+        valid[w] = 0;
+    }
+    const int *hits = a.cone_hits + (size_t)env * PAINT_PER_ACTION * a.cone_nb;
+    int *list = reinterpret_cast<int *>(big_lds) + list_off + (size_t)wave * a.cone_nb;       // HSI: the shot's hit list
+    uint32_t n_succeeded_l = 0;
+    double succ_l = 0.0;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        for (int w = lane; w < nw; w += 64) {
+            row[w] = 0;
+            if constexpr (HSI) stat[w] = 0;
+        }
+        int beam_hits = 0;
+        if constexpr (HSI) {                                            // (k_cone.hip cone_finish_kernel holds the commentary)
+            uint8_t *thick = a.thick + (size_t)env * 64 * a.mask_stride;
+            for (int b = lane; b < a.cone_nb; b += 64) list[b] = b < P.n_beams ? hits[shot * a.cone_nb + b] : -1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double *sh = a.cone_shots + ((size_t)env * PAINT_PER_ACTION + shot) * 8;
+            const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
+            const double quat[4] = {uni_d(sh[3]), uni_d(sh[4]), uni_d(sh[5]), uni_d(sh[6])};
+            double c[3];
+            transform_point(pos, quat, 0.0, 0.0, SHOT_CENTRE_OFFSET, c);
+            double dmax_l = -1.0;
+            for (int b0 = 0; b0 < P.n_beams; b0 += 64) {
+                const int sidx = list[b0 + lane];
+                if (sidx >= 0) {
+                    const double dx = c[0] - ldg(P.samp[0], sidx), dy = c[1] - ldg(P.samp[1], sidx), dz = c[2] - ldg(P.samp[2], sidx);
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    dmax_l = dd > dmax_l ? dd : dmax_l;
+                }
+                beam_hits += __popcll(ballot64(sidx >= 0));
+            }
+            if (beam_hits > 0) {
+                const double rmax = sqrt(wave_max_d(dmax_l));
+                for (int b0 = 0; b0 < P.n_beams; b0 += 64) {
+                    const int sidx = list[b0 + lane];
+                    int mult = 0;
+                    bool first = sidx >= 0;
+                    for (int j = 0; j < P.n_beams; ++j) {
+                        const bool same = list[j] == sidx;
+                        mult += same ? 1 : 0;
+                        first = first && !(same && j < b0 + lane);
+                    }
+                    if (first) {
+                        const double dx = c[0] - ldg(P.samp[0], sidx), dy = c[1] - ldg(P.samp[1], sidx), dz = c[2] - ldg(P.samp[2], sidx);
+                        const double dd = (dx * dx + dy * dy) + dz * dz;
+                        const double q = sqrt(dd) / rmax;
+                        const int quantity = (int)(25 * (1 - q * q)) + 1;
+                        uint8_t v = thick[sidx];
+                        for (int k = 0; k < mult; ++k)
+                            if (v != 0) {
+                                v = (uint8_t)(v - quantity);
+                                succ_l += quantity / 255.0;
+                            }
+                        thick[sidx] = v;
+                        atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), 1ull << (sidx & 63));
+                        if (v == 255) atomicOr(reinterpret_cast<unsigned long long *>(&stat[sidx >> 6]), 1ull << (sidx & 63));
+                    }
+                }
+            }
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int b = 0; b < P.n_beams; b += 64) {
+                const int sidx = b + lane < P.n_beams ? hits[shot * a.cone_nb + b + lane] : -1;
+                if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), 1ull << (sidx & 63));
+                beam_hits += __popcll(ballot64(sidx >= 0));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (beam_hits > 0) {
+            for (int w = lane; w < nw; w += 64) {
+                const uint64_t cw = row[w];
+                if constexpr (HSI) {
+                    painted[w] = (painted[w] & ~cw) | stat[w];
+                } else {
+                    n_succeeded_l += __popcll(cw & ~painted[w]);
+                    painted[w] |= cw;
+                }
+                valid[w] |= cw & ~last[w];
+                last[w] = cw;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t pix_l = 0;
+    for (int w = lane; w < nw; w += 64) pix_l += __popcll(valid[w]);
+    const uint64_t sums = wave_sum_u64(((uint64_t)n_succeeded_l << 32) | pix_l);
+    const int pixel_counter = (int)(sums & 0xffffffffu);
+    double succeeded_f = (double)(int)(sums >> 32);
+    if constexpr (HSI) succeeded_f = wave_sum_d(succ_l);
+    // finish_step's view of the masks: `last` doubles as the set this step's last shot affected (what store() writes back)
+    const BigMasks masks{g_painted, g_last, painted, last, last, nw, lane, nullptr};
+    uint64_t none[KW_MAX] = {0, 0, 0, 0}, none2[KW_MAX] = {0, 0, 0, 0};
+    PROF_BEGIN();
+    const int dn = finish_step<0, GENSEC, false, HSI>(P, C, part_id, env, lane, S, state_rec, masks, none, none2, succeeded_f,
+                                                      pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl PROF_PASS);
+    store_state_live(state_rec, S, lane, dn != 0);
+}
+
+// Large parts: dynamic LDS = waves x copies x mask_stride words (+ extra bytes per wave); as many waves per workgroup (at
+// most four) as 150 KB hold.
+int big_waves(const StepArgs &a, int copies, size_t extra_per_wave) {
+    const size_t per_wave = (size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave;
+    int waves = per_wave ? (int)((150 * 1024) / per_wave) : 4;
+    return waves > 4 ? 4 : waves;
+}
+
+template <typename... Extra>
+int launch_big(void (*kernel)(StepArgs, Extra...), const StepArgs &a, int copies, size_t extra_per_wave, hipStream_t s, Extra... extra) {
+    const int waves = big_waves(a, copies, extra_per_wave);
+    if (waves < 1) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)waves * ((size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kernel, dim3((a.n_envs + 3) / 4), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3((a.n_envs + waves - 1) / waves), dim3(64 * waves), lds, s, a, extra...);
     return (int)hipGetLastError();
 }
 
@@ -127,19 +277,35 @@ int launch_big(void (*kernel)(StepArgs), const StepArgs &a, int copies, hipStrea
 PRL_HIDDEN int KFN(step)(const void *step_args, const PrlStepSel *sel, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
     const bool gs = sel->gensec != 0;
-    return launch_big(sel->kd ? (gs ? step_kernel_big<true, true> : step_kernel_big<false, true>)
-                              : (gs ? step_kernel_big<true, false> : step_kernel_big<false, false>), a, 3,
-                      static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sel->hsi)
+        return launch_big(sel->kd ? (gs ? step_kernel_big<true, true, true> : step_kernel_big<false, true, true>)
+                                  : (gs ? step_kernel_big<true, false, true> : step_kernel_big<false, false, true>), a, 4, 0, s);
+    return launch_big(sel->kd ? (gs ? step_kernel_big<true, true, false> : step_kernel_big<false, true, false>)
+                              : (gs ? step_kernel_big<true, false, false> : step_kernel_big<false, false, false>), a, 3, 0, s);
 }
 
 PRL_HIDDEN int KFN(reset)(const void *step_args, int gensec, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    return launch_big(gensec ? reset_kernel_big<true> : reset_kernel_big<false>, a, 0, static_cast<hipStream_t>(stream));
+    return launch_big(gensec ? reset_kernel_big<true> : reset_kernel_big<false>, a, 0, 0, static_cast<hipStream_t>(stream));
 }
 
 PRL_HIDDEN int KFN(observe)(const void *step_args, int gensec, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    return launch_big(gensec ? observe_kernel_big<true> : observe_kernel_big<false>, a, 1, static_cast<hipStream_t>(stream));
+    return launch_big(gensec ? observe_kernel_big<true> : observe_kernel_big<false>, a, 1, 0, static_cast<hipStream_t>(stream));
+}
+
+// the last launch of a cone-beam step (k_cone_beams.hip) for a large part
+PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *stream) {
+    const StepArgs &a = *static_cast<const StepArgs *>(step_args);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sel->hsi) {
+        const size_t list_bytes = sizeof(int) * (size_t)a.cone_nb;                  // per wave, behind all the mask copies
+        const int waves = big_waves(a, 5, list_bytes);
+        const int list_off = (int)((size_t)waves * 5 * a.mask_stride * 2);          // in ints
+        return launch_big(sel->gensec ? cone_finish_kernel_big<true, true> : cone_finish_kernel_big<false, true>, a, 5, list_bytes, s, list_off);
+    }
+    return launch_big(sel->gensec ? cone_finish_kernel_big<true, false> : cone_finish_kernel_big<false, false>, a, 4, 0, s, 0);
 }
 
 PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double *out, int n_start, int n_words, int gensec) {
@@ -154,8 +320,8 @@ PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double 
     return (int)hipGetLastError();
 }
 
-// Not built for large parts yet: the host side refuses these combinations before it gets here.
-PRL_HIDDEN int KFN(cone)(const void *, const PrlStepSel *, void *) { return (int)hipErrorNotSupported; }
+// The fused rollout kernels are not built for large parts: the host side takes those entry points launch by launch
+// (paintrl_hip.hip fused_rollout) and never gets here.
 PRL_HIDDEN int KFN(act_step)(const void *, size_t, int, void *) { return (int)hipErrorNotSupported; }
 PRL_HIDDEN int KFN(rollout_policy)(const void *, size_t, int, void *) { return (int)hipErrorNotSupported; }
 PRL_HIDDEN int KFN(rollout_fragment)(const void *, int, void *) { return (int)hipErrorNotSupported; }

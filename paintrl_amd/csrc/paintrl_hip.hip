@@ -95,6 +95,7 @@ struct PrlBatch {
     double *cone_shots = nullptr, *cone_aux = nullptr;      // PAINT_METHOD 'normal' only (StepArgs)
     int *cone_hits = nullptr, *cone_work = nullptr;
     double *cone_far = nullptr;
+    int32_t *scratch_action = nullptr;    // prl_rollout_fragment's launch-by-launch path: the bootstrap pass's discarded draw
     int cone_nb = 0, cone_tree_cap = 0;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
@@ -765,16 +766,6 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     b->kw = (b->mask_stride + 63) / 64;
     for (int i = 0; i < n_parts; ++i) b->kd = b->kd || parts[i]->dev.n_kd_nodes > 0;
     for (int i = 0; i < n_parts; ++i) b->max_beams = std::max(b->max_beams, parts[i]->dev.n_beams);
-    if (b->kw > KW_MAX && cfg->color_mode == PRL_COLOR_HSI) {
-        delete b;
-        return fail(PRL_E_UNSUPPORTED, "COLOR_MODE 'HSI' is built for parts of at most %d samples", 64 * 64 * KW_MAX);
-    }
-    if (b->kw > KW_MAX && cfg->paint_method == PRL_PAINT_NORMAL) {
-        const int words = b->mask_stride;
-        delete b;
-        return fail(PRL_E_UNSUPPORTED, "PAINT_METHOD 'normal' is built for parts of at most %d samples (this batch: %d mask words)",
-                    64 * 64 * KW_MAX, words);
-    }
     hipError_t e = hipSetDevice(b->device);
     {
         int cus = 0;
@@ -857,6 +848,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->cone_hits);
     (void)hipFree(b->cone_work);
     (void)hipFree(b->cone_far);
+    (void)hipFree(b->scratch_action);
     for (double *p : b->reset_obs) (void)hipFree(p);
     (void)hipFree(b->state);
     delete b;
@@ -991,11 +983,16 @@ static int check_rollout_batch(PrlBatch *b, const char *who) {
     if (int rc = check_device(b)) return rc;
     const PrlConfig &c = b->cfg;
     if (!c.auto_reset) return fail(PRL_E_INVALID, "%s: the batch must be created with auto_reset", who);
-    if (b->kw > KW_MAX) return fail(PRL_E_UNSUPPORTED, "%s: parts of at most %d samples", who, 64 * 64 * KW_MAX);
-    if (c.color_mode != PRL_COLOR_RGB) return fail(PRL_E_UNSUPPORTED, "%s: COLOR_MODE 'RGB'", who);
-    if (c.action_mode != PRL_ACT_DISCRETE || c.paint_method != PRL_PAINT_FAST || general_section(c))
-        return fail(PRL_E_UNSUPPORTED, "%s: discrete actions, PAINT_METHOD 'fast', and OBS_GRAD 4 for section / discrete observations", who);
+    if (c.action_mode != PRL_ACT_DISCRETE) return fail(PRL_E_UNSUPPORTED, "%s: discrete actions", who);
     return PRL_OK;
+}
+
+// The fused rollout kernels (k_rollout.hip) are built around the ball painter's step with register-resident masks and the
+// 4-sector observation; every other configuration (cone beams, COLOR_MODE 'HSI', atan2 sectors, parts beyond 16 384
+// samples) takes the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
+static bool fused_rollout(const PrlBatch *b) {
+    const PrlConfig &c = b->cfg;
+    return b->kw <= KW_MAX && c.color_mode == PRL_COLOR_RGB && c.paint_method == PRL_PAINT_FAST && !general_section(c);
 }
 
 static int check_policy(const PrlBatch *b, const PrlPolicyWeights *w, const char *who) {
@@ -1018,6 +1015,10 @@ int prl_batch_act_step(PrlBatch *b, const PrlPolicyWeights *w, const double *obs
         return fail(PRL_E_INVALID, "prl_batch_act_step: null argument");
     if (int rc = check_rollout_batch(b, "prl_batch_act_step")) return rc;
     if (int rc = check_policy(b, w, "prl_batch_act_step")) return rc;
+    if (!fused_rollout(b)) {
+        if (int rc = prl_policy_act(w, b->n_envs, obs_in, nullptr, rng_count, rng_seed, action, logp, value, nullptr, stream)) return rc;
+        return prl_batch_step(b, action, obs, reward, done, info, final_obs, nullptr, stream);
+    }
     ActStepArgs f{};
     f.s = base_args(b);
     f.s.obs = obs;
@@ -1044,6 +1045,30 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
         return fail(PRL_E_INVALID, "prl_rollout_fragment: null argument or n_steps < 1");
     if (int rc = check_rollout_batch(b, "prl_rollout_fragment")) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (w && (!logp || !value || !last_value || !rng_count))
+        return fail(PRL_E_INVALID, "prl_rollout_fragment: the policy needs logp, value, last_value and rng_count");
+    if (w)
+        if (int rc = check_policy(b, w, "prl_rollout_fragment")) return rc;
+    if (!fused_rollout(b)) {
+        // launch by launch (see fused_rollout): the rows are the same by definition
+        const size_t n = (size_t)b->n_envs, od = (size_t)obs_dim_of(b->cfg.obs_mode, b->cfg.obs_grad);
+        for (int t = 0; t < n_steps; ++t) {
+            if (w)
+                if (int rc = prl_policy_act(w, b->n_envs, obs + t * n * od, nullptr, rng_count, rng_seed, action + t * n, logp + t * n,
+                                            value + t * n, nullptr, stream))
+                    return rc;
+            if (int rc = prl_batch_step(b, action + t * n, obs + (t + 1) * n * od, reward + t * n, done + t * n, info + 2 * t * n,
+                                        final_obs ? final_obs + t * n * od : nullptr, nullptr, stream))
+                return rc;
+        }
+        if (w) {                                   // the bootstrap value; its draw is discarded
+            if (!b->scratch_action) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->scratch_action), sizeof(int32_t) * n));
+            if (int rc = prl_policy_act(w, b->n_envs, obs + (size_t)n_steps * n * od, nullptr, rng_count, rng_seed, b->scratch_action, nullptr,
+                                        last_value, nullptr, stream))
+                return rc;
+        }
+        return PRL_OK;
+    }
     if (w) {
         // policy: ONE persistent launch too (rollout_policy_kernel): the sixteen envs of a workgroup alternate policy and
         // step; after the last step the policy runs once more for the bootstrap value (its draw is discarded)

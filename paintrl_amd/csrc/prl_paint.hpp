@@ -269,4 +269,78 @@ __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds,
     succeeded = wave_sum_d(succ_l);
 }
 
+// The same for a part with more than 16 384 samples: the masks live in LDS (`painted`, `last`, `cur`: zero on entry and the
+// last shot's affected set on exit, `uni`: scratch; n_words words each).  Word updates go through lane 0.
+__device__ void paint_shots_hsi_big(PartRef P, double radius, const double *cen_lds, int lane, uint64_t *painted, uint64_t *last,
+                                    uint64_t *cur, uint64_t *uni, int n_words, uint8_t *thick, double &succeeded,
+                                    int &pixel_counter) {
+    const double r2 = radius * radius;
+    double succ_l = 0.0;
+    for (int w = lane; w < n_words; w += 64) uni[w] = 0;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        const double c0 = cen_lds[3 * shot], c1 = cen_lds[3 * shot + 1], c2 = cen_lds[3 * shot + 2];
+        const int icx = rfl(cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx));
+        const int icy = rfl(cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny));
+        const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
+        double dmax_l = -1.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double rmax = pass ? sqrt(wave_max_d(dmax_l)) : 0.0;
+            if (pass && !(rmax >= 0.0)) break;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int begin = R.begin[r], end = begin + R.count[r];
+                if (R.count[r] <= 0) continue;
+                for (int w = begin >> 6; w <= ((end - 1) >> 6); ++w) {
+                    const int s = (w << 6) + lane;
+                    const double dx = c0 - ldg(P.samp[0], s), dy = c1 - ldg(P.samp[1], s), dz = c2 - ldg(P.samp[2], s);
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const bool hit = s >= begin && s < end && dd <= r2;
+                    if (!pass) {
+                        if (hit) dmax_l = dd > dmax_l ? dd : dmax_l;
+                        continue;
+                    }
+                    const uint64_t b = ballot64(hit);
+                    if (b == 0) continue;
+                    uint8_t v = thick[s];
+                    if (hit) {
+                        const double q = sqrt(dd) / rmax;
+                        const int quantity = (int)(25 * (1 - q * q)) + 1;
+                        if (v != 0) {
+                            v = (uint8_t)(v - quantity);
+                            succ_l += quantity / 255.0;
+                            thick[s] = v;
+                        }
+                    }
+                    const uint64_t stat = ballot64(hit && v == 255);
+                    if (lane == 0) {
+                        painted[w] = (painted[w] & ~b) | stat;
+                        cur[w] |= b;                     // (a word can be visited from two rows' ranges: disjoint lanes)
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int w = lane; w < n_words; w += 64) {       // bpw:575-576: valid = affected minus the previous shot's
+            uni[w] |= cur[w] & ~last[w];
+            last[w] = cur[w];
+            cur[w] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t pix_l = 0;
+    for (int w = lane; w < n_words; w += 64) {
+        pix_l += __popcll(uni[w]);
+        cur[w] = last[w];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    pixel_counter = (int)wave_sum_u64(pix_l);
+    succeeded = wave_sum_d(succ_l);
+}
+
 }  // namespace

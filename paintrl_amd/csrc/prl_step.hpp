@@ -240,6 +240,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
         // every byte 255 again, every status bit "painted" (bpw:586, 706-707) / the LDS copies cleared
         if constexpr (HSI) reset_thickness<KW>(P, a.thick() + (size_t)env * 64 * a.mask_stride(), lane, painted);
         if constexpr (BIG) masks.clear();
+        if constexpr (BIG && HSI) masks.all_painted(P);
         for (int k = lane; k < od; k += 64) obs_row[k] = ldg(P.reset_obs, start * od + k);     // see PartDev::reset_obs
     }
     STAMP(PH_OBS);
@@ -312,7 +313,10 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
     double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
-    if constexpr (HSI) {
+    if constexpr (HSI && BIG) {
+        paint_shots_hsi_big(P, C.paint_radius, cen, lane, masks.painted, masks.last, masks.new_last, masks.extra, masks.n_words,
+                            a.thick() + (size_t)env * 64 * a.mask_stride(), succeeded_f, pixel_counter);
+    } else if constexpr (HSI) {
         paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
                             succeeded_f, pixel_counter);
     } else {
@@ -357,6 +361,7 @@ struct BigMasks {
     uint64_t *g_painted, *g_last;                 // HBM rows of this env
     uint64_t *painted, *last, *new_last;          // LDS, n_words each
     int n_words, lane;
+    uint64_t *extra;                              // a fourth LDS copy for the painters that need one (HSI: the union of valid sets)
     template <int KW>
     __device__ __forceinline__ void load(uint64_t *, uint64_t *) const {
         for (int w = lane; w < n_words; w += 64) {
@@ -373,6 +378,12 @@ struct BigMasks {
             painted[w] = 0;
             new_last[w] = 0;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void all_painted(PartRef P) const {    // COLOR_MODE 'HSI' after a reset: every real sample reads painted
+        for (int w = lane; w < n_words; w += 64) painted[w] = ldg(P.word_valid, w);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -124,22 +124,100 @@ def test_mixed_batch_of_small_and_big_parts():
     env.close()
 
 
-def test_big_part_limits_are_reported():
-    """What the large-part kernels do not cover fails loudly: cone-beam painting, the persistent fragment kernel."""
-    import torch
-    from paintrl_amd import _lib
+@pytest.mark.parametrize('kw,n,steps', [
+    (dict(paint_method='normal'), 24, 6),
+    (dict(paint_method='normal', obs_mode='grid', overlap_penalty=True), 16, 5),
+    (dict(color_mode='HSI'), 64, 20),
+    (dict(color_mode='HSI', obs_mode='section', obs_grad=6, turning_penalty=True), 48, 12),
+    (dict(color_mode='HSI', paint_method='normal', _beta=True), 12, 4),
+])
+def test_big_part_composes_with_cone_beams_and_thickness(kw, n, steps):
+    """Seven of the reference's ten parts are 'big': PAINT_METHOD 'normal' and COLOR_MODE 'HSI' run on them too (masks in
+    LDS throughout).  HSI rewards to 1e-12, everything else exact."""
+    import random
+    from paintrl_amd import part_tables
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    kw = dict(kw)
     tables = synthetic_tables('door_rr_big', tex_size=(320, 320))
-    with pytest.raises(_lib.PaintRLError, match='normal'):
-        _env(tables, 4, paint_method='normal')
-    env = _env(tables, 8, auto_reset=True)
-    env.reset()
-    T, n, od = 3, 8, env.obs_dim
-    f64 = dict(dtype=torch.float64, device=env.device)
-    with pytest.raises(_lib.PaintRLError, match='samples'):
-        env.rollout_fragment(T, torch.zeros((T + 1, n, od), **f64), None, torch.zeros((T, n), **f64),
-                             torch.zeros((T, n), dtype=torch.uint8, device=env.device), torch.zeros((T, n, 2), **f64),
-                             torch.zeros((T, n), dtype=torch.int32, device=env.device))
+    sp = start_points_for(tables, 'all')
+    beams = None
+    if kw.pop('_beta', False):
+        random.seed(3)
+        beams = part_tables.beta_plain(tables.density)
+    hsi = kw.get('color_mode') == 'HSI'
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    env = BatchedPaintEnv(DeviceTables(tables, obs_grad=kw.get('obs_grad', 4), start_points=sp, beams=beams), n, max_possible_point=mpp, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=mpp, beams=beams, **kw)
+    rng = np.random.RandomState(17)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        if hsi:
+            assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=1e-12) and np.array_equal(env.thickness(), orc.thick), 'step %d' % k
+        else:
+            assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(i.cpu().numpy(), ii), 'reward, step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    assert np.array_equal(env.parts[0].mask_to_canonical(words), np.stack([orc.painted_bits(e) for e in range(n)]))
     env.close()
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(color_mode='HSI'), dict(paint_method='normal', _small=True)])
+def test_rollout_entry_points_on_every_configuration(kw):
+    """prl_rollout_fragment (given actions, and with the policy) and prl_batch_act_step on batches the fused rollout kernels
+    are not built for -- a large part, COLOR_MODE 'HSI', cone beams: the library takes them launch by launch, rows bit for
+    bit those of prl_policy_act + prl_batch_step."""
+    import torch
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    kw = dict(kw)
+    small = kw.pop('_small', False)
+    tables = synthetic_tables('door_test') if small else synthetic_tables('door_rr_big', tex_size=(320, 320))
+    sp = start_points_for(tables, 'all')
+    n, T = 40, 6 if small else 12
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    mk = lambda: _env(tables, n, sp, auto_reset=True, seed=21, max_possible_point=mpp, **kw)     # noqa: E731
+    env_a, env_b = mk(), mk()
+    start = np.random.RandomState(1).randint(0, len(sp), size=n)
+    o0 = env_a.reset(start_idx=start).clone()
+    env_b.reset(start_idx=start)
+    dev, od = env_a.device, env_a.obs_dim
+    f64 = dict(dtype=torch.float64, device=dev)
+    obs, fin = torch.zeros((T + 1, n, od), **f64), torch.zeros((T, n, od), **f64)
+    rew, info = torch.zeros((T, n), **f64), torch.zeros((T, n, 2), **f64)
+    done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    act = torch.randint(0, 4, (T, n), generator=gen, device=dev, dtype=torch.int32)
+    obs[0].copy_(o0)
+    env_a.rollout_fragment(T, obs, fin, rew, done, info, act)
+    torch.cuda.synchronize()
+    for t in range(T):
+        o, r, d, i = env_b.step(act[t])
+        assert torch.equal(obs[t + 1], o) and torch.equal(rew[t], r) and torch.equal(done[t].bool(), d), 'row %d' % t
+    assert torch.equal(env_a.painted_words(), env_b.painted_words())
+    env_a.close()
+    env_b.close()
+    envs = [mk() for _ in range(3)]
+    torch.manual_seed(3)
+    policy = MLPPolicy(envs[0].obs_dim, 4).to(envs[0].device)
+    workers = [RolloutWorker(envs[0], policy, fragment=T, seed=5), RolloutWorker(envs[1], policy, fragment=T, seed=5, persistent=True),
+               RolloutWorker(envs[2], policy, fragment=T, seed=5, act_step=True)]
+    out = [w.collect() for w in workers]
+    torch.cuda.synchronize()
+    for other in (1, 2):
+        for k in out[0][0]:
+            assert torch.equal(out[0][0][k], out[other][0][k]), (other, k)
+        assert torch.equal(out[0][1], out[other][1])
+    for e in envs:
+        e.close()
 
 
 @pytest.mark.skipif(not os.path.isfile(os.path.join(GOLDEN, 'episodes_door_big.npz')), reason='fixture not generated')

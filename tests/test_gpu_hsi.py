@@ -87,9 +87,6 @@ def test_hsi_bytes_wrap_and_auto_reset():
 def test_hsi_limits_are_reported():
     from paintrl_amd import _lib
     tables = synthetic_tables('door_test')
-    big = synthetic_tables('door_rr_big', tex_size=(320, 320))
-    with pytest.raises(_lib.PaintRLError, match='HSI'):
-        _env(big, 4, color_mode='HSI')
     env = _env(tables, 4)
     with pytest.raises(_lib.PaintRLError, match='HSI'):
         env.thickness()

@@ -110,6 +110,35 @@ def test_stale_tree_composes_with_cone_beams_and_thickness(kw, n, steps):
     env.close()
 
 
+@pytest.mark.parametrize('kw,n,steps', [(dict(paint_method='normal'), 16, 5), (dict(color_mode='HSI'), 48, 15)])
+def test_stale_tree_on_a_large_part_composes_too(kw, n, steps):
+    """Both properties at once -- what the reference's door_lf / door_rf / door_rr are: a stale tree AND more than 16 384
+    samples -- under cone beams and under COLOR_MODE 'HSI'."""
+    tables = synthetic_tables('test', tex_size=(360, 360))
+    assert tables.sample_pos.shape[0] > 16384 and len(tables.kd_split_dim) > 0
+    sp = start_points_for(tables, 'all')
+    hsi = kw.get('color_mode') == 'HSI'
+    env = _env(tables, n, sp, max_possible_point=30000, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=30000, **kw)
+    rng = np.random.RandomState(23)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        if hsi:
+            assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=1e-12) and np.array_equal(env.thickness(), orc.thick)
+        else:
+            assert np.array_equal(r.cpu().numpy(), rr), 'reward, step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    env.close()
+
+
 def test_stale_tree_in_the_rollout_kernels():
     """prl_rollout_fragment (given actions and with the policy) and prl_batch_act_step on a part with the stale tree:
     rows bit for bit those of one prl_batch_step (+ prl_policy_act) launch per step."""
