@@ -11,11 +11,11 @@ namespace {
 // The observation a reset to start point s returns, for every s of one part (PartDev::reset_obs): one wave per start
 // point, run once when a batch is created.  KW = 0: LDS-resident mask (large parts).
 template <int KW, bool GENSEC>
-__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const PrlConfig *cfg, double *out) {
+__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const CfgDev *cfg, double *out) {
     const int lane = threadIdx.x & 63;
     const int s = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     PartRef P = *(const PartDev CAS *)part;
-    CfgRef C = *(const PrlConfig CAS *)cfg;
+    CfgRef C = *(const CfgDev CAS *)cfg;
     if (s >= P.n_start) return;
     const double pose[3] = {P.start_pos[3 * s], P.start_pos[3 * s + 1], P.start_pos[3 * s + 2]};
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     const WaveLds wl = wave_lds<GENSEC, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
     if (env >= a.n_envs) return;
     if (a.reset_mask && !a.reset_mask[env]) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
     const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     extern __shared__ uint64_t big_lds[];
     uint64_t *painted = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int l
     const WaveLds wl = wave_lds<GENSEC, false>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
@@ -309,14 +309,14 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
 }
 
 PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double *out, int n_start, int n_words, int gensec) {
-    void (*k)(const PartDev *, const PrlConfig *, double *) = gensec ? reset_obs_kernel<0, true> : reset_obs_kernel<0, false>;
+    void (*k)(const PartDev *, const CfgDev *, double *) = gensec ? reset_obs_kernel<0, true> : reset_obs_kernel<0, false>;
     const size_t lds = (size_t)4 * n_words * sizeof(uint64_t);
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(k, dim3((n_start + 3) / 4), dim3(256), lds, 0, static_cast<const PartDev *>(part_dev),
-                       static_cast<const PrlConfig *>(cfg_dev), out);
+                       static_cast<const CfgDev *>(cfg_dev), out);
     return (int)hipGetLastError();
 }
 

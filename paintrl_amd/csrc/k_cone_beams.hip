@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     const WaveLds wl = wave_lds<false, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         if (env < n_envs) {                                           // exactly the per-step kernel's body
             const int part_id = a.env_part ? a.env_part[env] : 0;
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-            CfgRef C = *(const PrlConfig CAS *)a.cfg;
+            CfgRef C = *(const CfgDev CAS *)a.cfg;
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
             const LdsMasks masks{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     const StepArgs CAS &a = f.s;
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             const int env = opaque_s((int)blockIdx.x) * POLICY_WAVES + wave;
             const int part_id = a.env_part ? a.env_part[env] : 0;
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-            CfgRef C = *(const PrlConfig CAS *)a.cfg;
+            CfgRef C = *(const CfgDev CAS *)a.cfg;
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
             EnvState S;
             load_state_motion(state_rec, S);

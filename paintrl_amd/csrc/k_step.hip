@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
     if (env >= a.n_envs) return;
     if (a.reset_mask && !a.reset_mask[env]) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     int start = a.start_idx ? a.start_idx[env] : draw_start(C.seed, env, S.episode, P.n_start);
     start = start < 0 ? 0 : (start >= P.n_start ? P.n_start - 1 : start);
@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void reset_kernel(StepArgs a) {
 // The observation a reset to start point s returns, for every s of one part (PartDev::reset_obs): one wave per start
 // point, run once when a batch is created.  KW = 0: LDS-resident mask (large parts).
 template <int KW, bool GENSEC>
-__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const PrlConfig *cfg, double *out) {
+__global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, const CfgDev *cfg, double *out) {
     const int lane = threadIdx.x & 63;
     const int s = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     PartRef P = *(const PartDev CAS *)part;
-    CfgRef C = *(const PrlConfig CAS *)cfg;
+    CfgRef C = *(const CfgDev CAS *)cfg;
     if (s >= P.n_start) return;
     const double pose[3] = {P.start_pos[3 * s], P.start_pos[3 * s + 1], P.start_pos[3 * s + 2]};
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
     const int env = rfl(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0};
     load_masks<KW>(a, env, P.n_words, lane, painted, last);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     const WaveLds wl = wave_lds<GENSEC, KD>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
-    CfgRef C = *(const PrlConfig CAS *)a.cfg;
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     TRACE_BEGIN();
@@ -165,7 +165,7 @@ PRL_HIDDEN int KFN(observe)(const void *step_args, int gensec, void *stream) {
 PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double *out, int n_start, int /*n_words*/, int gensec) {
     const dim3 grid((n_start + 3) / 4), block(256);
     const PartDev *p = static_cast<const PartDev *>(part_dev);
-    const PrlConfig *c = static_cast<const PrlConfig *>(cfg_dev);
+    const CfgDev *c = static_cast<const CfgDev *>(cfg_dev);
     if (gensec) hipLaunchKernelGGL((reset_obs_kernel<PRL_KW, true>), grid, block, 0, 0, p, c, out);
     else hipLaunchKernelGGL((reset_obs_kernel<PRL_KW, false>), grid, block, 0, 0, p, c, out);
     return (int)hipGetLastError();

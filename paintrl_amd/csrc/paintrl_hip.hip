@@ -88,7 +88,7 @@ struct PrlBatch {
     int max_beams = 0;             // largest cone-beam count of the parts (PAINT_METHOD 'normal')
     PrlConfig cfg{};
     PartDev *parts_dev = nullptr;
-    PrlConfig *cfg_dev = nullptr;
+    CfgDev *cfg_dev = nullptr;
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
@@ -783,8 +783,18 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     const size_t state_bytes = (size_t)n_envs * PRL_STATE_DOUBLES * sizeof(double);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->parts_dev), sizeof(PartDev) * n_parts);
     if (e == hipSuccess) e = hipMemcpy(b->parts_dev, pd.data(), sizeof(PartDev) * n_parts, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cfg_dev), sizeof(PrlConfig));
-    if (e == hipSuccess) e = hipMemcpy(b->cfg_dev, cfg, sizeof(PrlConfig), hipMemcpyHostToDevice);
+    CfgDev cd{};
+    static_cast<PrlConfig &>(cd) = *cfg;
+    for (int k = 0; k < PRL_MAX_DISCRETE; ++k) {
+        cd.act_d1[k] = cfg->act_delta1[k] / PAINT_PER_ACTION;
+        cd.act_d2[k] = cfg->act_delta2[k] / PAINT_PER_ACTION;
+    }
+    for (int k = 0; k < 8; ++k) {
+        cd.expected_reward[k] = cfg->max_possible_point[k] / (cfg->expected_episode_len * 100);
+        cd.switch_points[k] = cfg->switch_threshold * cfg->max_possible_point[k] / 100;
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cfg_dev), sizeof(CfgDev));
+    if (e == hipSuccess) e = hipMemcpy(b->cfg_dev, &cd, sizeof(CfgDev), hipMemcpyHostToDevice);
     if (e == hipSuccess && env_part_id) {
         e = hipMalloc(reinterpret_cast<void **>(&b->env_part_dev), sizeof(int) * n_envs);
         if (e == hipSuccess) e = hipMemcpy(b->env_part_dev, env_part_id, sizeof(int) * n_envs, hipMemcpyHostToDevice);

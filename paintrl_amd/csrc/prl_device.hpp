@@ -131,11 +131,19 @@ struct PartDev {
 // address space so that their fields are fetched with scalar loads (s_load through the K$) instead
 // of wave-uniform vector loads the compiler has to assume the kernel's own stores may clobber.
 typedef const PartDev CAS &PartRef;
-typedef const PrlConfig CAS &CfgRef;
+// The batch configuration as the kernels see it: the caller's PrlConfig plus what prl_batch_create derives from it once,
+// with the same IEEE divisions the step would otherwise repeat per env and step (a float64 division is ~14 vector
+// instructions, its reciprocal seed 16 cycles: the dozen the step used to make were ~5 % of its vector time).
+struct CfgDev : PrlConfig {
+    double act_d1[PRL_MAX_DISCRETE], act_d2[PRL_MAX_DISCRETE];     // act_delta1 / 2 over PAINT_PER_ACTION (rob:403-409)
+    double expected_reward[8];                                      // max_possible_point / (Expected_Episode_Length * 100), rge:296
+    double switch_points[8];                                        // SWITCH_THRESHOLD * max_possible_point / 100, rge:301
+};
+typedef const CfgDev CAS &CfgRef;
 
 struct StepArgs {
     const PartDev *parts;
-    const PrlConfig *cfg;
+    const CfgDev *cfg;
     const int *env_part;          // device, or nullptr
     int n_envs, mask_stride;
     uint64_t *painted, *last;
@@ -392,9 +400,12 @@ __device__ __forceinline__ void tcp_orn_norm(const double pose[3], const double 
     transform_point(pose, quat, 0.0, 0.0, 1.0, along);
     double v0 = along[0] - pose[0], v1 = along[1] - pose[1], v2 = along[2] - pose[2];
     double norm = sqrt(dot3_np(v0, v1, v2, v0, v1, v2));
-    n[0] = v0 / norm;
-    n[1] = v1 / norm;
-    n[2] = v2 / norm;
+    // the three quotients in three lanes at once (wave-uniform inputs): one division sequence instead of three
+    const int lane = threadIdx.x & 63;
+    const double q = (lane == 0 ? v0 : (lane == 1 ? v1 : v2)) / norm;
+    n[0] = bcast_d(q, 0);
+    n[1] = bcast_d(q, 1);
+    n[2] = bcast_d(q, 2);
 }
 
 __device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {

@@ -79,20 +79,23 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
     }
 }
 
-// bpw:965-978 get_normalized_pose
+// bpw:965-978 get_normalized_pose.  The two quotients are formed in two lanes at once (wave-uniform inputs: lane 0 the
+// position along axis a1 within its grid row, lane 1 along axis a2) and handed round: one division sequence, not two.
 __device__ __forceinline__ void normalized_pose(PartRef P, CfgRef C, const double pose[3], double &x1, double &x2,
                                                 double &np0, double &np1) {
     const double r = C.paint_radius;
     x1 = sel3(pose[0], pose[1], pose[2], P.a1);
     x2 = sel3(pose[0], pose[1], pose[2], P.a2);
-    const double in2 = (x2 - P.r2min + r) / (P.r2max - P.r2min + 2 * r);
     const int gi = grid_index_2(P, x2);
     const double lo = P.grid_lo[gi], hi = P.grid_hi[gi];
-    double in1;
-    if (hi - lo == 0) in1 = 0;
-    else in1 = (x1 - lo + r) / (hi - lo + 2 * r);
-    np0 = clip01(in1);
-    np1 = clip01(in2);
+    const bool second = (threadIdx.x & 63) == 1;
+    const double num = second ? x2 - P.r2min + r : x1 - lo + r;
+    const double den = second ? P.r2max - P.r2min + 2 * r : hi - lo + 2 * r;
+    double q = num / den;
+    if (!second && hi - lo == 0) q = 0;
+    q = clip01(q);
+    np0 = bcast_d(q, 0);
+    np1 = bcast_d(q, 1);
 }
 
 // bpw:1126-1139 grid observation, 16 cells starting at c0: adds popcount(painted word & cell mask) of word w into
@@ -306,14 +309,12 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         section4_accumulate<KW>(P, x1, x2, painted, 0, lane, tot_l, und_l);
         tot_l = wave_sum_u64(tot_l);
         und_l = wave_sum_u64(und_l);
-        if (lane == 0) {
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t t = (uint32_t)((tot_l >> (16 * q)) & 0xffff);
-                const uint32_t u = (uint32_t)((und_l >> (16 * q)) & 0xffff);
-                out[q] = t == 0 ? 0.0 : (double)u / (double)t;
-            }
-            section_pose_tail(mode, 4, np0, np1, out);
+        if (lane < 4) {                             // the four ratios in four lanes: one division sequence
+            const uint32_t t = (uint32_t)((tot_l >> (16 * lane)) & 0xffff);
+            const uint32_t u = (uint32_t)((und_l >> (16 * lane)) & 0xffff);
+            out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
         }
+        if (lane == 0) section_pose_tail(mode, 4, np0, np1, out);
     }
 }
 
@@ -387,12 +388,12 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], const
         t23 = wave_sum_u64(t23);
         u01 = wave_sum_u64(u01);
         u23 = wave_sum_u64(u23);
-        if (lane == 0) {
-            const uint32_t t[4] = {(uint32_t)t01, (uint32_t)(t01 >> 32), (uint32_t)t23, (uint32_t)(t23 >> 32)};
-            const uint32_t u[4] = {(uint32_t)u01, (uint32_t)(u01 >> 32), (uint32_t)u23, (uint32_t)(u23 >> 32)};
-            for (int q = 0; q < 4; ++q) out[q] = t[q] == 0 ? 0.0 : (double)u[q] / (double)t[q];
-            section_pose_tail(mode, 4, np0, np1, out);
+        if (lane < 4) {
+            const uint64_t tp = lane < 2 ? t01 : t23, up = lane < 2 ? u01 : u23;
+            const uint32_t t = (uint32_t)((lane & 1) ? tp >> 32 : tp), u = (uint32_t)((lane & 1) ? up >> 32 : up);
+            out[lane] = t == 0 ? 0.0 : (double)u / (double)t;
         }
+        if (lane == 0) section_pose_tail(mode, 4, np0, np1, out);
     }
 }
 

@@ -6,19 +6,20 @@
 
 namespace {
 
-// rge:342-347 _preprocess_action + rob:390-398 + rob:352-358: action -> (delta axis 1, delta axis 2, turning angle)
-__device__ __forceinline__ void decode_discrete_action(CfgRef C, int act, double &delta1, double &delta2, double &new_angle) {
+// rge:342-347 _preprocess_action + rob:390-398, 403-409 + rob:352-358: action -> (move per sub-shot along axis 1, along
+// axis 2, turning angle).  The moves are the action's deltas over PAINT_PER_ACTION: from the batch's tables for discrete
+// actions (CfgDev), divided here for continuous ones.
+__device__ __forceinline__ void decode_discrete_action(CfgRef C, int act, double &d1, double &d2, double &new_angle) {
     act = rfl(act);                                  // wave-uniform: the table is read with scalar loads
     act = act < 0 ? 0 : (act >= C.n_discrete ? C.n_discrete - 1 : act);
-    delta1 = C.act_delta1[act];
-    delta2 = C.act_delta2[act];
+    d1 = C.act_d1[act];
+    d2 = C.act_d2[act];
     new_angle = C.act_angle[act];
 }
 
-__device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int env, double &delta1, double &delta2,
-                                              double &new_angle) {
+__device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int env, double &d1, double &d2, double &new_angle) {
     if (C.action_mode == PRL_ACT_DISCRETE) {
-        decode_discrete_action(C, reinterpret_cast<const int *>(actions)[env], delta1, delta2, new_angle);
+        decode_discrete_action(C, reinterpret_cast<const int *>(actions)[env], d1, d2, new_angle);
     } else {
         const double *av = reinterpret_cast<const double *>(actions) + (size_t)env * C.action_dim;
         double a0 = av[0], a1 = C.action_dim > 1 ? av[1] : 0.0;
@@ -41,9 +42,10 @@ __device__ __forceinline__ void decode_action(CfgRef C, const void *actions, int
                 dy = mx * sin(phi);
             }
         }
-        delta1 = uni_d(dx * C.step_size);
-        delta2 = uni_d(dy * C.step_size);
+        const double delta1 = uni_d(dx * C.step_size), delta2 = uni_d(dy * C.step_size);
         new_angle = uni_d(delta1 != 0 ? atan(fabs(delta2 / delta1)) : PI / 2);
+        d1 = uni_d(delta1 / PAINT_PER_ACTION);
+        d2 = uni_d(delta2 / PAINT_PER_ACTION);
     }
 }
 
@@ -69,14 +71,14 @@ struct ShotCtx {
     int facet_hint, last_tri;
 };
 
-__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double delta1, double delta2, ShotCtx &X) {
+__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double d1, double d2, ShotCtx &X) {
     X.cur_pose[0] = S.pose[0];
     X.cur_pose[1] = S.pose[1];
     X.cur_pose[2] = S.pose[2];
     tcp_orn_norm(S.pose, S.quat, X.cur_norm);
     // (the per-shot deltas and the turning angle are read rarely: those do live in scalar registers)
-    X.d1 = uni_d(delta1 / PAINT_PER_ACTION);
-    X.d2 = uni_d(delta2 / PAINT_PER_ACTION);
+    X.d1 = uni_d(d1);
+    X.d2 = uni_d(d2);
     // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
     X.facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
     // The tool quaternion is a function of the tool normal alone (rob:93-100), so it is not carried through the
@@ -175,27 +177,25 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
     const double angle_diff = fabs(new_angle - S.last_angle);        // rob:357
     S.last_angle = new_angle;
     S.facet_hint = facet_hint;
-    const double rate = pixel_counter ? succeeded_f / (double)pixel_counter : 0.0;           // rob:425-426
     if (S.terminate_counter - counter_before >= PAINT_PER_ACTION && pixel_counter == 0) S.terminate = 1;
 
     // ---- reward, penalty, termination   rge:321-340, 289-304
     const double rew = succeeded_f / 100;
     S.total_reward += rew;
     double pen = 0.2;
-    if (C.overlap_penalty) pen += 0.1 * (1 - rate);
+    if (C.overlap_penalty) pen += 0.1 * (1 - (pixel_counter ? succeeded_f / (double)pixel_counter : 0.0));           // rob:425-426
     if (C.turning_penalty) pen += 0.1 * (angle_diff / PI);
     const double actual = rew - pen;
     S.step_counter += 1;
     const double max_pts = C.max_possible_point[part_id & 7];
     const int finished = max_pts > S.total_reward * 100 ? 0 : 1;
-    const double avg = S.total_reward / S.step_counter;
-    const double expected = max_pts / (C.expected_episode_len * 100);
-    int dn;
-    if (avg < expected && C.termination_mode != PRL_TERM_LATE &&
-        (C.termination_mode == PRL_TERM_EARLY || S.total_reward < C.switch_threshold * max_pts / 100))
-        dn = 1;
-    else
-        dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
+    int dn = 0;
+    if (C.termination_mode != PRL_TERM_LATE) {       // (the average is only looked at in the 'early' / 'hybrid' modes)
+        const double avg = S.total_reward / S.step_counter;
+        dn = avg < C.expected_reward[part_id & 7] &&
+             (C.termination_mode == PRL_TERM_EARLY || S.total_reward < C.switch_points[part_id & 7]);
+    }
+    if (!dn) dn = finished || S.terminate || S.step_counter > C.max_episode_len - 1;
     if (!dn) S.total_return += actual;
     STAMP(PH_APPLY);
 
@@ -269,7 +269,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
 // KD: parts of the batch may carry the reference's stale vertex kd-tree (prl_search.hpp nearest_vertex_kd).
 template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, typename MaskIO, typename RowIO>
 __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
-                                        const double *state_rec, const MaskIO &masks, double delta1, double delta2,
+                                        const double *state_rec, const MaskIO &masks, double d1, double d2,
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
     // KW = 0: a part with more than 16 384 samples; its masks stay in LDS (MaskIO = BigMasks) for the whole step
     constexpr bool BIG = KW == 0;
@@ -280,7 +280,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
     ShotCtx X;
-    shots_begin(P, S, delta1, delta2, X);
+    shots_begin(P, S, d1, d2, X);
     new_angle = uni_d(new_angle);
     double *cen = wl.cen;
 #if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
