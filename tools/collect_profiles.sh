@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/; tools/summarise_profiles.py (run in the build container afterwards) turns it into profiles/<tag>_*.
 # Counter passes carry --pmc only (no --kernel-trace / --stats with them); the program after `--` is python3 itself.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -22,10 +22,17 @@ $B --policy mlp --no-cpu-baseline > "$OUT/bench_mlp.json" 2>> "$OUT/bench.err"
 $B --policy fragment --no-cpu-baseline > "$OUT/bench_fragment.json" 2>> "$OUT/bench.err"
 $B --policy random-fragment --no-cpu-baseline > "$OUT/bench_random_fragment.json" 2>> "$OUT/bench.err"
 $B --streams 2 --no-cpu-baseline > "$OUT/bench_streams2.json" 2>> "$OUT/bench.err"
-$B --paint-method normal --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/bench_normal.json" 2>> "$OUT/bench.err"
+$B --paint-method normal --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/bench_normal.json" 2>> "$OUT/bench.err"
+echo "== batch-size sweep (one wave per CU ... four per SIMD: the step's latency chain against its throughput)"
+for n in 256 1024 2048 3072 4096; do
+  $B --envs $n --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_envs$n.json" 2>> "$OUT/bench.err"
+done
+echo "== issue cost of the vector instruction classes (tools/microbench/valu_rate.hip)"
+timeout -k 5 200 "$ROOT/tools/microbench/valu_rate" "$OUT/valu_rate.json" > "$OUT/valu_rate.txt" 2>&1
 echo "== kernel trace"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- $B --no-cpu-baseline > "$OUT/trace.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$OUT/trace_grid" --output-format csv -- $B --obs-mode grid --no-cpu-baseline > "$OUT/trace_grid.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- $B --no-cpu-baseline > "$OUT/trace.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_grid" --output-format csv -- $B --obs-mode grid --no-cpu-baseline > "$OUT/trace_grid.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_normal" --output-format csv -- $B --paint-method normal --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/trace_normal.log" 2>&1
 echo "== SQ / TA counters"
 G1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH"
 G2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH"
@@ -35,16 +42,16 @@ for MODE in section grid; do
   i=0
   for G in "$G1" "$G2" "$G3" "$G4"; do
     i=$((i+1))
-    rocprofv3 --pmc $G -d "$OUT/pmc_${MODE}_$i" --output-format csv -- $W --obs-mode $MODE --steps 100 > "$OUT/pmc_${MODE}_$i.log" 2>&1 || echo "pmc $MODE pass $i failed"
+    timeout -k 10 300 rocprofv3 --pmc $G -d "$OUT/pmc_${MODE}_$i" --output-format csv -- $W --obs-mode $MODE --steps 100 > "$OUT/pmc_${MODE}_$i.log" 2>&1 || echo "pmc $MODE pass $i failed"
   done
 done
 echo "== HBM bytes (FETCH_SIZE and WRITE_SIZE in separate passes) + calibration on copy_mask_kernel"
 for MODE in section grid; do
-  rocprofv3 --pmc FETCH_SIZE -d "$OUT/hbm_fetch_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_fetch_$MODE.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d "$OUT/hbm_write_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_write_$MODE.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/hbm_fetch_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_fetch_$MODE.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/hbm_write_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_write_$MODE.log" 2>&1
 done
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/cal_fetch" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/cal_write" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/cal_fetch" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/cal_write" --output-format csv -- python3 "$ROOT/tools/hbm_calibration.py" > "$OUT/cal_write.log" 2>&1
 # keep what is merged back small: counter CSVs of 100-200 dispatches are fine, the per-dispatch kernel trace is not
 find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 du -sh "$OUT"
