@@ -52,8 +52,15 @@ constexpr int CONE_JOINT_FROM = PRL_CONE_JOINT_FROM;
 // edge of facet `prev` (-1: the walk starts here): Moller-Trumbore on the facet record, arithmetic as in mt_rec.
 // Returns 1 = entered at an interior point (t, exact closest hit), 2 = proven miss, 0 = keep walking (`next` = the
 // facet across the most violated edge, or -1), -1 = give up (degenerate / behind).
-__device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const double o[3], double d0, double d1, double d2,
-                                              double dd, double &t_out, int &rank_out, int &next, bool &solid) {
+struct WalkStep {
+    int code, next;               // see cone_walk_step
+    bool solid;                   // the facet is entered at more than a grazing angle
+    double t;                     // code 1: the hit's parameter
+    int rank;                     // code 1: the facet's reference index
+};
+__device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, const double o[3], double d0, double d1, double d2,
+                                                   double dd) {
+    WalkStep out{-1, -1, false, INFINITY, 0};
     const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
     const int i6 = i * 6;
     const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4),
@@ -64,8 +71,7 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const 
     const double p1 = d2 * e20 - d0 * e22;
     const double p2 = d0 * e21 - d1 * e20;
     const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-    next = -1;
-    if (!(fabs(det) >= RAY_EPS_DET)) return -1;
+    if (!(fabs(det) >= RAY_EPS_DET)) return out;
     const double inv = 1.0 / det;
     const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
     const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
@@ -75,7 +81,8 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const 
     const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
     const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
     const bool front = orient * det > 0;                      // the beam meets this facet's plane from outside
-    solid = front && det * det >= CONE_MIN_COS2 * dd * nn;    // ... at more than a grazing angle
+    const bool solid = front && det * det >= CONE_MIN_COS2 * dd * nn;
+    out.solid = solid;    // ... at more than a grazing angle
     if (!solid) {
         // The walk has reached the hull's horizon (or grazes).  Two certificates that the beam misses the whole set, by
         // more than any tolerance of the triangle tests -- then no search is needed:
@@ -84,7 +91,10 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const 
         const double so = ((s0 * n0 + s1 * n1) + s2 * n2) * orient;                     // origin, outward if > 0
         const double se = so + ((d0 * n0 + d1 * n1) + d2 * n2) * orient;                // end point
         const double clear = CONE_MISS_MARGIN * CONE_MISS_MARGIN * nn;                  // (distance margin)^2 |n|^2
-        if (so > 0 && se > 0 && so * so > clear && se * se > clear) return 2;
+        if (so > 0 && se > 0 && so * so > clear && se * se > clear) {
+            out.code = 2;
+            return out;
+        }
         // (b) the edge the walk just crossed is a SILHOUETTE edge of the hull as seen along the beam: the facet it left
         // faces the beam (`prev` is only passed for a facet the beam enters at more than a grazing angle), this one
         // faces away.  The plane through such an edge that contains the beam's direction supports the hull (its
@@ -104,27 +114,40 @@ __device__ __forceinline__ int cone_walk_step(PartRef P, int i, int prev, const 
                 const double m0 = g1 * d2 - g2 * d1, m1 = g2 * d0 - g0 * d2, m2 = g0 * d1 - g1 * d0;               // edge x beam
                 const double side_o = (a0 * m0 + a1 * m1) + a2 * m2, side_p = (c0 * m0 + c1 * m1) + c2 * m2;
                 const double mm = (m0 * m0 + m1 * m1) + m2 * m2;
-                if (side_o * side_p < 0 && side_o * side_o > CONE_MISS_MARGIN * CONE_MISS_MARGIN * mm) return 2;
+                if (side_o * side_p < 0 && side_o * side_o > CONE_MISS_MARGIN * CONE_MISS_MARGIN * mm) {
+                    out.code = 2;
+                    return out;
+                }
             }
         }
-        if (!front) return prev < 0 ? -2 : -3;               // (the codes only matter to the statistics of diagnostic builds)
+        if (!front) {
+            out.code = prev < 0 ? -2 : -3;                   // (the codes only matter to the statistics of diagnostic builds)
+            return out;
+        }
         // a facet met at a grazing angle decides nothing, but the walk may pass through it
     }
-    if (!(t >= 0.0)) return -4;                              // behind the origin
+    if (!(t >= 0.0)) {                                       // behind the origin
+        out.code = -4;
+        return out;
+    }
     if (u >= m && v >= m && (u + v) <= 1.0 - m) {
-        if (!solid) return -5;                               // a grazing entry decides nothing (the walk may pass through such facets)
+        if (!solid) {                                        // a grazing entry decides nothing (the walk may pass through such facets)
+            out.code = -5;
+            return out;
+        }
         // entered at an interior point: the closest hit of the whole set (ray_closest_wave's single-facet criterion);
         // beyond the beam's end point it means the beam stops short of the part: a miss
-        if (!(t <= 1.0)) return 2;
-        t_out = t;
-        rank_out = ldg(P.col_rank, i);
-        return 1;
+        out.code = (t <= 1.0) ? 1 : 2;
+        out.t = t;
+        out.rank = ldg(P.col_rank, i);
+        return out;
     }
     // outside the triangle (or within the edge margin): cross the edge that is violated most
     const double w = 1.0 - u - v;
     const int e = (u <= v && u <= w) ? 0 : ((v <= w) ? 1 : 2);         // 0: u smallest, 1: v, 2: w = 1 - u - v
-    next = ldg(P.col_enbr, 3 * i + e);
-    return 0;
+    out.next = ldg(P.col_enbr, 3 * i + e);
+    out.code = 0;
+    return out;
 }
 
 // The general closest-hit search for up to 64 rays at once, one per lane (`need`), all from the same origin o: what
@@ -204,9 +227,13 @@ __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], c
             CONE_STAT(13, 1);
             CONE_STAT(15, __popcll(ballot64(state == 0)));
             if (state == 0) {
-                int next;
-                bool solid;
-                const int r = cone_walk_step(P, f, prev, pos, d0, d1, d2, dd, t, rk, next, solid);
+                const WalkStep ws = cone_walk_step(P, f, prev, pos, d0, d1, d2, dd);
+                const int r = ws.code, next = ws.next;
+                const bool solid = ws.solid;
+                if (r == 1) {
+                    t = ws.t;
+                    rk = ws.rank;
+                }
                 CONE_STAT(5, __popcll(ballot64(r == -1)));
                 CONE_STAT(6, __popcll(ballot64(r == -2)));
                 CONE_STAT(7, __popcll(ballot64(r == -3)));
