@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int l
     uint64_t none[KW_MAX] = {0, 0, 0, 0}, none2[KW_MAX] = {0, 0, 0, 0};
     PROF_BEGIN();
     const int dn = finish_step<0, GENSEC, false, HSI>(P, C, part_id, env, lane, S, state_rec, masks, none, none2, succeeded_f,
-                                                      pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl PROF_PASS);
+                                                      pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl, nullptr PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
 

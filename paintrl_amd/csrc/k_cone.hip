@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
     const WaveLds wl{nullptr, nullptr, s_cnt[GENSEC ? wave : 0], nullptr, nullptr};
     PROF_BEGIN();
     const int dn = finish_step<KW, GENSEC, false, HSI>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
-                                                       pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl PROF_PASS);
+                                                       pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl, nullptr PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
 

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC, KD>();
+    // the last-shot masks in LDS rows (prl_paint.hpp RowWords) where it pays: four mask words per lane on a part with the
+    // stale tree -- the reference's own sheet -- spilled 63 vector registers without (77.7 -> 72.4 us on the synthetic
+    // coarse sheet; the other kernels are a per cent faster with the masks in registers)
+    const WaveLds wl = wave_lds<GENSEC, KD, (KD && !HSI && KW == 4) ? KW : 0, WAVES>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;

@@ -199,16 +199,18 @@ struct WaveLds {
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
     int *cnt;           // [128], only with the atan2-sector observation
     double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
-    uint64_t *mask;     // (unused)
+    uint64_t *lastrow;  // [2][64 * KW]: the last-shot mask and its successor while the ball painter runs (step_kernel; nullptr:
+                        // both stay in registers)
 };
-template <bool GENSEC, bool KD = false>
+template <bool GENSEC, bool KD = false, int LASTROW_KW = 0, int WAVES = MAX_WAVES_PER_WG>
 __device__ __forceinline__ WaveLds wave_lds() {
-    __shared__ int s_cand[MAX_WAVES_PER_WG][64];
-    __shared__ double s_centres[MAX_WAVES_PER_WG][PAINT_PER_ACTION * 3 + 1];
-    __shared__ int s_cnt[GENSEC ? MAX_WAVES_PER_WG : 1][128];
-    __shared__ double s_kd[KD ? MAX_WAVES_PER_WG : 1][KD ? KD_HEAP * 5 : 1];
+    __shared__ int s_cand[WAVES][64];
+    __shared__ double s_centres[WAVES][PAINT_PER_ACTION * 3 + 1];
+    __shared__ int s_cnt[GENSEC ? WAVES : 1][128];
+    __shared__ double s_kd[KD ? WAVES : 1][KD ? KD_HEAP * 5 : 1];
+    __shared__ uint64_t s_last[LASTROW_KW ? WAVES : 1][LASTROW_KW ? 2 * 64 * LASTROW_KW : 1];
     const int w = rfl((int)(threadIdx.x >> 6));
-    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], nullptr};
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], LASTROW_KW ? s_last[w] : nullptr};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

@@ -66,6 +66,32 @@ struct RegWords {
     }
 };
 
+// The same with the last-shot mask and its successor in this wave's LDS rows (step_kernel): sixteen vector registers less
+// while the painter runs -- the widest masks (four words per lane: the reference's sheet) spilled 11 - 63 without -- and an LDS
+// read instead of a lane broadcast per word.  `new_last` must be zero on entry.
+template <int KW>
+struct RowWords {
+    uint64_t *painted;            // [KW_MAX] registers of the caller
+    const uint64_t *last;         // LDS, word w at [w]
+    uint64_t *new_last;           // LDS
+    int lane;
+    __device__ __forceinline__ void get(int w, uint64_t &pw, uint64_t &lw) const {
+        const int owner = w & 63, slot = w >> 6;
+        pw = 0;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == slot) pw = bcast_u64(painted[k], owner);
+        lw = last[w];
+    }
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+        const int owner = w & 63, slot = w >> 6;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (k == slot && lane == owner) painted[k] = pw;
+        if (lane == 0) new_last[w] = lw;
+    }
+};
+
 // ... larger ones (the 480 x 480 textures: up to ~70 000 samples) keep them in LDS for the length of the kernel.
 struct LdsWords {
     uint64_t *painted;            // [n_words] in LDS

@@ -170,7 +170,9 @@ template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, typename MaskIO, typenam
 __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                            const double *state_rec, const MaskIO &masks, uint64_t painted[KW_MAX],
                                            uint64_t last[KW_MAX], double succeeded_f, int pixel_counter, int counter_before,
-                                           double new_angle, int facet_hint, const RowIO &a, const WaveLds &wl PROF_ARG) {
+                                           double new_angle, int facet_hint, const RowIO &a, const WaveLds &wl,
+                                           const uint64_t *last_row = nullptr PROF_ARG) {
+    // last_row: where the masks' last-shot words wait in LDS instead of `last` (step_env with WaveLds::lastrow), or nullptr
     constexpr bool BIG = KW == 0;
     PRIO_YOUNG_DECL();
     if constexpr (LATE_ACC) load_state_accumulators(state_rec, S);
@@ -244,6 +246,10 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
         for (int k = lane; k < od; k += 64) obs_row[k] = ldg(P.reset_obs, start * od + k);     // see PartDev::reset_obs
     }
     STAMP(PH_OBS);
+    if (last_row && !do_reset) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) last[k] = last_row[lane + 64 * k];
+    }
     masks.template store<KW>(painted, last);
     return dn;
 }
@@ -308,7 +314,21 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     shots_end(P, S, X);
     PRIO_YOUNG_OLD(2, 1);
-    if constexpr (!BIG) masks.template load<KW>(painted, last);
+    // the last-shot mask waits in this wave's LDS rows where the kernel provides them (wl.lastrow), not in registers
+    const bool rows = !BIG && !HSI && wl.lastrow != nullptr;
+    if constexpr (!BIG) {
+        masks.template load<KW>(painted, last);
+        if (rows) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                wl.lastrow[lane + 64 * k] = last[k];
+                wl.lastrow[64 * KW + lane + 64 * k] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
     STAMP(PH_LOAD);
     // bpw:568-577 fast_paint + _paint for the five shots
     int succeeded = 0, pixel_counter = 0;
@@ -326,6 +346,14 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else if (rows) {
+#if !defined(PRL_CUT) || PRL_CUT < 2
+            paint_shots_union(P, C.paint_radius, cen, lane, RowWords<KW>{painted, wl.lastrow, wl.lastrow + 64 * KW, lane}, succeeded,
+                              pixel_counter);
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the row, its owners read it back later
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
 #if !defined(PRL_CUT) || PRL_CUT < 2
@@ -339,7 +367,8 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     }
     STAMP(PH_BALL);
     return finish_step<KW, GENSEC, LATE_ACC, HSI>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
-                                                  pixel_counter, counter_before, new_angle, X.facet_hint, a, wl PROF_PASS);
+                                                  pixel_counter, counter_before, new_angle, X.facet_hint, a, wl,
+                                                  rows ? wl.lastrow + 64 * KW : nullptr PROF_PASS);
 }
 
 // Output rows of the per-step kernel: the launch's StepArgs, read from the kernel-argument segment when used.
