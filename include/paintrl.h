@@ -113,7 +113,8 @@ typedef struct {
     int32_t n_start;
     const double *start_pos;         /* [n_start][3] */
     const double *start_quat;        /* [n_start][4] */
-    /* cone beams for PAINT_METHOD='normal' (rob:23-35) */
+    /* cone beams for PAINT_METHOD='normal': the uniform lattice of rob:23-35, or for COLOR_MODE 'HSI' the beta-profile rings of
+       rob:38-69 (paintrl_amd.part_tables.beta_plain); any table of beam end points in the tool frame will do */
     int32_t n_beams;
     const double *beams;             /* [n_beams][3] */
 } PrlPartTables;
@@ -236,25 +237,30 @@ int prl_policy_act(const PrlPolicyWeights *weights, int n, const double *obs, co
  * reset wrote; it may be the same buffer as obs only if the caller no longer needs it: rows are read before they are
  * written, by the same workgroup).  action i32[N], logp f32[N], value f32[N] out; the remaining arguments are
  * prl_batch_step's.  Results are bit for bit those of prl_policy_act (in-kernel sampling stream: rng_count u32[N],
- * rng_seed) followed by prl_batch_step.  The batch must have auto_reset, discrete actions, PAINT_METHOD 'fast'. */
+ * rng_seed) followed by prl_batch_step.  The batch must have auto_reset and discrete actions.  ONE launch for the ball
+ * painter (PAINT_METHOD 'fast', COLOR_MODE 'RGB', 4-sector / grid / simple observation) on parts of at most 16 384
+ * samples; any other configuration is served by the two launches this call is defined to equal. */
 int prl_batch_act_step(PrlBatch *batch, const PrlPolicyWeights *weights, const double *obs_in, uint32_t *rng_count,
                        uint64_t rng_seed, int32_t *action, float *logp, float *value, double *obs, double *reward,
                        uint8_t *done, double *info, double *final_obs /* or NULL */, void *stream);
 
 /* A whole rollout fragment -- what one RLlib rollout worker does between two learner updates
  * (paint_ppo.py:170-195, sample_batch_size steps of policy forward + env.step) -- enqueued by ONE call, no host code of
- * the caller between the steps.  The batch must have been created with auto_reset, discrete actions and
- * PAINT_METHOD 'fast'.  All buffers are device pointers, row-major [t][env]:
+ * the caller between the steps.  The batch must have been created with auto_reset and discrete actions.  All buffers
+ * are device pointers, row-major [t][env]:
  *   obs        f64[n_steps + 1][N][obs_dim]   row 0: observations before the first step (input), row t + 1: after step t
  *   final_obs  f64[n_steps][N][obs_dim] or NULL: terminal observation of envs that finished in step t
  *   reward f64[n_steps][N], done u8[n_steps][N], info f64[n_steps][N][2]
  *   action     i32[n_steps][N]: written when `weights` is given, otherwise READ (replay / scripted / random actions)
  *   logp, value f32[n_steps][N], last_value f32[N] (value estimate of row n_steps), rng_count u32[N]: policy only
- * ONE persistent launch either way, sixteen envs per workgroup.  Given actions (weights == NULL): every wave walks its
+ * ONE persistent launch either way, sixteen envs per workgroup (the configurations of prl_batch_act_step's one launch).
+ * Given actions (weights == NULL): every wave walks its
  * env through all n_steps on its own (no barrier, no launch boundary: a slow step delays nobody), coverage masks in LDS
  * throughout.  With `weights`: the sixteen waves of a workgroup alternate the policy (together) and the step (each its
  * env) and meet only at the policy's barriers; after the last step the policy runs once more for last_value (its draw
- * is discarded).  The rows are bit for bit what n_steps rounds of prl_policy_act + prl_batch_step produce. */
+ * is discarded).  The rows are bit for bit what n_steps rounds of prl_policy_act + prl_batch_step produce -- and for the
+ * configurations the persistent kernels are not built for (cone beams, COLOR_MODE 'HSI', atan2 sectors, parts beyond 16 384
+ * samples) that is how the call is carried out: launch by launch, still with no host code of the caller in between. */
 int prl_rollout_fragment(PrlBatch *batch, const PrlPolicyWeights *weights /* or NULL */, int n_steps, double *obs,
                          double *final_obs, double *reward, uint8_t *done, double *info, int32_t *action, float *logp,
                          float *value, float *last_value, uint32_t *rng_count, uint64_t rng_seed, void *stream);

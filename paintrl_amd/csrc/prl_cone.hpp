@@ -1,18 +1,21 @@
 // prl_cone.hpp -- PAINT_METHOD 'normal': the cone beams of one shot, one beam per lane (rob:251-285, bpw:562-566).
-// Part of the single translation unit paintrl_hip.hip (device code, anonymous namespace); see that file for the
-// overall design.  Compile with -ffp-contract=off.
+// Device code of the cone-beam kernels (k_cone_beams.hip describes the four launches of a step); anonymous namespace.
+// Compile with -ffp-contract=off.
 //
-// A shot casts n_beams (104-140) rays from the tool position to the points of a lattice on the plane 0.2 ahead
-// (rob:23-35); every ray that hits the part paints the sample nearest to its hit point.  The first version ran the
-// wave-wide ray search and the wave-wide nearest-sample search once per beam, one after the other (3.1 ms per batched
-// step).  Here a wave takes 64 beams at a time, one per lane:
-//   * rays: on a convex collision set (hull mode) a lane WALKS the hull surface: it tests its ray against one
-//     facet (starting from the facet the tool's own ray hit), and while the ray meets that facet's plane outside the
-//     triangle it steps across the violated edge to the neighbouring facet (three edge neighbours per facet, derived
-//     on upload).  A facet that is ENTERED at a point clear of its edges ends the walk with the exact closest hit of
-//     the whole set -- the criterion of ray_closest_wave's single-facet path, same arithmetic.  Lanes that do not
-//     get there in a few steps (edge and vertex hits, misses, rays leaving the hull) take the wave-wide search.
-//   * nearest samples: nearest_sample_lane below, one hit point per lane; the hit bits meet in the wave's LDS mask row.
+// A shot casts n_beams (104-140 on the reference's parts, 450 with COLOR_MODE 'HSI') rays from the tool position to the
+// points of a table on the plane 0.2 ahead (rob:23-35, 38-69); every ray that hits the part paints the sample nearest to its
+// hit point.  A wave takes 64 beams at a time (a "trip"), one per lane:
+//   * rays: on a convex collision set (hull mode) a lane WALKS the hull surface (cone_walk_lanes): it tests its ray against
+//     one facet -- starting from the facet the front-facet grid names for the middle of the beam --, and while the ray meets
+//     that facet's plane outside the triangle it steps across the violated edge to the neighbouring facet (three edge
+//     neighbours per facet, derived on upload).  A facet that is ENTERED at a point clear of its edges ends the walk with the
+//     exact closest hit of the whole set -- the criterion of ray_closest_wave's single-facet path, same arithmetic.  A walk
+//     that reaches the hull's horizon ends with a PROVEN miss (cone_walk_step: both ends beyond a facet plane, or the
+//     silhouette-edge certificate).  What is left over (edge and vertex hits, grazing entries, walks that run out of steps)
+//     is searched by the general code: cone_rays_lanes, for the rest kernel.
+//   * nearest samples: one hit point per lane on the fine sample grid -- nearest_sample_lane_f32 (float records, the
+//     contenders confirmed in float64) in the beams kernel, nearest_sample_lane (float64 records) in the general code; hit
+//     points three rings of cells do not settle walk the box pyramid (nearest_sample_tree): exact at any distance.
 #pragma once
 
 namespace {
