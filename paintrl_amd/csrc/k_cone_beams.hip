@@ -23,8 +23,14 @@
 namespace {
 
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
-constexpr int REST_WGS = 1024;       // workgroups of the work-list kernels (grid-stride over their lists): every trip of a
-constexpr int FAR_WGS = 1024;        // typical step gets its own wave
+#ifndef PRL_REST_WGS
+#define PRL_REST_WGS 384
+#endif
+// Workgroups of the rest kernel per role, grid-stride over their lists, the roles interleaved (even / odd workgroups): with
+// the lanes' tree stacks in LDS (47 KB a workgroup on the door) a CU holds three workgroups, the chip 768 -- a larger grid
+// queues behind itself and the second role would only start when the first is through (2 x 1024: 100 us, of waves that
+// take 20-40 us each).
+constexpr int REST_WGS = PRL_REST_WGS, FAR_WGS = PRL_REST_WGS;
 
 template <bool KD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
@@ -34,6 +40,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {                             // the work lists of this step start empty
         a.cone_work[0] = 0;
         a.cone_work[1] = 0;
+        a.cone_work[3] = 0;
     }
     if (env >= a.n_envs) return;
     const WaveLds wl = wave_lds<false, KD>();
@@ -89,6 +96,12 @@ __device__ __forceinline__ bool beam_item(const StepArgs CAS &a, int item, int &
     return env < a.n_envs;
 }
 
+// cone_work: [0] trips in the trip list, [1] entries of the far list, [2] its capacity, [3] rays in the ray list, then the
+// trip list (capacity: every trip) and the ray list (item << 6 | lane; CONE_JOINT_FROM per trip at most)
+__device__ __forceinline__ int *ray_list(const StepArgs CAS &a) {
+    return a.cone_work + 4 + (size_t)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
+}
+
 #ifndef PRL_BEAM_OCC
 #define PRL_BEAM_OCC 7
 #endif
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     if (b0 >= P.n_beams) return;
+    CONE_TIME_BEGIN();
     // the shot's record was written by the previous launch: constant here, fetched with scalar loads
     const double CAS *sh = (const double CAS *)(a.cone_shots + ((size_t)env * PAINT_PER_ACTION + shot) * 8);
     const double pos[3] = {sh[0], sh[1], sh[2]}, quat[4] = {sh[3], sh[4], sh[5], sh[6]};
@@ -108,11 +122,13 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     double bh[3];
     cone_trip_fast(P, pos, quat, b0, lane, state, bh, sidx);
     const int dest = (env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane;
-    const uint64_t far = ballot64(sidx == -2);
+    const uint64_t far = ballot64(sidx == -2), left = ballot64(state == 3);
     int far_base = 0;
-    bool redo = ballot64(state == 3) != 0;                 // a ray the walk left over: the whole trip through the general code
+    // rays the walk left over: a few go to the ray list one by one, more than that (a collision set that is not convex:
+    // all of them) send the whole trip through the general code
+    bool redo = (int)__popcll(left) > CONE_JOINT_FROM;
     if (!redo && far) {
-        // hit points far from every sample: one entry each in the far list (the far kernel takes 64 of them per wave)
+        // hit points far from every sample: one entry each in the far list (the far role takes 64 of them per wave)
         if (lane == 0) far_base = atomicAdd(a.cone_work + 1, (int)__popcll(far));
         far_base = rfl(far_base);
         redo = far_base + (int)__popcll(far) > a.cone_work[2];          // the list is full: the general code settles them too
@@ -122,21 +138,29 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
         if (lane == 0) a.cone_work[4 + atomicAdd(a.cone_work, 1)] = item;
         // a reservation that ran over the end of the far list: the entries of it that do lie inside are marked void (the
         // far role of cone_rest_kernel walks the list up to its capacity)
-        if (far && ballot64(state == 3) == 0) {
+        if (far && (int)__popcll(left) <= CONE_JOINT_FROM) {
             const int slot = far_base + lane;
             if (lane < (int)__popcll(far) && slot < a.cone_work[2])
                 reinterpret_cast<f64x2 *>(a.cone_far)[2 * (size_t)slot + 1] = f64x2{0.0, __hiloint2double(0, -1)};
         }
+        CONE_TIME_END(2);
         return;
+    }
+    if (left) {
+        int ray_base = 0;
+        if (lane == 0) ray_base = atomicAdd(a.cone_work + 3, (int)__popcll(left));
+        ray_base = rfl(ray_base);
+        if (state == 3) ray_list(a)[ray_base + (int)__popcll(left & ((1ull << lane) - 1))] = (item << 6) | lane;
     }
     if (sidx == -2) {
         const int slot = far_base + (int)__popcll(far & ((1ull << lane) - 1));
         f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * (size_t)slot;
         e[0] = f64x2{bh[0], bh[1]};
         e[1] = f64x2{bh[2], __hiloint2double(part_id, dest)};
-    } else if (b0 + lane < P.n_beams) {
+    } else if (state != 3 && b0 + lane < P.n_beams) {
         a.cone_hits[dest] = sidx;
     }
+    CONE_TIME_END(2);
 }
 
 // The hit points the beams kernel could not settle within three rings of the fine grid, 64 per wave whatever trip, shot
@@ -156,10 +180,12 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     int *stack = s_tree + threadIdx.x;                                  // entry k of this lane: stack[256 k]
-    if (blockIdx.x < FAR_WGS) {
+    const int role_wg = rfl(blockIdx.x >> 1);
+    if ((blockIdx.x & 1) == 0) {
         int n_far = rfl(a.cone_work[1]);
         n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);  // (entries beyond the capacity went to the trip list)
-        for (int i0 = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; i0 < n_far; i0 += 64 * 4 * FAR_WGS) {
+        for (int i0 = rfl(role_wg * 4 + (threadIdx.x >> 6)) * 64; i0 < n_far; i0 += 64 * 4 * FAR_WGS) {
+            CONE_TIME_BEGIN();
             const bool in = i0 + lane < n_far;
             const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + lane : i0);
             const f64x2 e0 = e[0], e1 = e[1];
@@ -176,15 +202,17 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
                 nearest_sample_far<256>(P, pt, lane, sidx, stack, tree_cap);
                 if (mine) a.cone_hits[dest] = sidx;
             }
+            CONE_TIME_END(0);
         }
         return;
     }
     const WaveLds wl = wave_lds<false, false>();
     const int n_work = rfl(a.cone_work[0]);
-    for (int i = rfl((blockIdx.x - FAR_WGS) * 4 + (threadIdx.x >> 6)); i < n_work; i += 4 * REST_WGS) {
+    for (int i = rfl(role_wg * 4 + (threadIdx.x >> 6)); i < n_work; i += 4 * REST_WGS) {
         const int item = rfl(a.cone_work[4 + i]);
         int env, shot, b0;
         if (!beam_item(a, item, env, shot, b0)) continue;
+        CONE_TIME_BEGIN();
         PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
         const double *sh = a.cone_shots + ((size_t)env * PAINT_PER_ACTION + shot) * 8;
         const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
@@ -192,6 +220,38 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
         const int hint = rfl(__double2loint(sh[7]));
         const int sidx = cone_trip<256>(P, pos, quat, b0, (hint >= 0 && hint < P.n_col_pad) ? hint : -1, lane, wl.cand, stack, tree_cap);
         if (b0 + lane < P.n_beams) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane] = sidx;
+        CONE_TIME_END(1);
+    }
+    // the ray list: one leftover ray per wave -- the wave-wide closest-hit search of the tool's own ray, then the nearest
+    // sample of its hit point (every lane the same query; lane 0's answer counts)
+    const int n_rays = rfl(a.cone_work[3]);
+    const int *rays = ray_list(a);
+    for (int i = rfl(role_wg * 4 + (threadIdx.x >> 6)); i < n_rays; i += 4 * REST_WGS) {
+        const int entry = rfl(rays[i]);
+        const int item = entry >> 6, L = entry & 63;
+        int env, shot, b0;
+        if (!beam_item(a, item, env, shot, b0)) continue;
+        CONE_TIME_BEGIN();
+        PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+        const double *sh = a.cone_shots + ((size_t)env * PAINT_PER_ACTION + shot) * 8;
+        const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
+        const double quat[4] = {uni_d(sh[3]), uni_d(sh[4]), uni_d(sh[5]), uni_d(sh[6])};
+        int hint = rfl(__double2loint(sh[7]));
+        hint = (hint >= 0 && hint < P.n_col_pad) ? hint : -1;
+        const int bm = b0 + L;
+        double dst[3] = {pos[0], pos[1], pos[2]};
+        transform_point(pos, quat, ldg(P.beams, 3 * bm), ldg(P.beams, 3 * bm + 1), ldg(P.beams, 3 * bm + 2), dst);
+        int sidx = -1;
+        if (!beam_outside_outline_wave(P, pos, dst, lane)) {
+            double tw, hw[3];
+            if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
+                sidx = nearest_sample_lane_f32(P, hw, true);
+                if (lane != 0) sidx = -1;
+                nearest_sample_far<256>(P, hw, lane, sidx, stack, tree_cap);
+            }
+        }
+        if (lane == 0) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
+        CONE_TIME_END(1);
     }
 }
 
@@ -228,10 +288,12 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
 
 #if defined(PRL_CONE_TRACE) && defined(PRL_DIAG_EXPORT)
 // diagnostic build only: read and clear the beams kernel's path counters (prl_cone.hpp CONE_STAT)
-extern "C" int prl_debug_cone_stats(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cone_stat), sizeof(unsigned long long) * 16) != hipSuccess) return PRL_E_HIP;
-    unsigned long long zero[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cone_stat), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
+extern "C" int prl_debug_cone_stats(unsigned long long *out) {       // out[32 + 96]: counters, wave-time histograms
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cone_stat), sizeof(unsigned long long) * 32) != hipSuccess) return PRL_E_HIP;
+    if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_cone_hist), sizeof(unsigned long long) * 96) != hipSuccess) return PRL_E_HIP;
+    unsigned long long zero[96] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cone_stat), zero, sizeof(unsigned long long) * 32) != hipSuccess) return PRL_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cone_hist), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;
 }
 #endif

@@ -481,9 +481,22 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_nx = nx;
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
+        {   // a sample near every cell (its own first record, or that of the nearest cell with samples, breadth first)
+            std::vector<int> seed((size_t)nx * ny, -1), queue;
+            queue.reserve(seed.size());
+            for (int c = 0; c < nx * ny; ++c)
+                if (start[c + 1] > start[c]) seed[c] = start[c], queue.push_back(c);
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int c = queue[h], cx = c % nx, cy = c / nx;
+                const int nb[4] = {cx > 0 ? c - 1 : -1, cx < nx - 1 ? c + 1 : -1, cy > 0 ? c - nx : -1, cy < ny - 1 ? c + nx : -1};
+                for (int k = 0; k < 4; ++k)
+                    if (nb[k] >= 0 && seed[nb[k]] < 0) seed[nb[k]] = seed[c], queue.push_back(nb[k]);
+            }
+            UP(fg_seed, seed.data(), seed.size());
+        }
         UP(fg_rec, rec.data(), rec.size());
         {
-            std::vector<float> rec32(real.size() * 4);
+            std::vector<float> rec32((real.size() + 4) * 4, 0.0f);       // (four records of padding: the scan reads ahead)
             for (size_t j = 0; j < real.size(); ++j) {
                 for (int k = 0; k < 3; ++k) rec32[j * 4 + k] = (float)rec[j * 4 + k];
                 int32_t pair[2];
@@ -814,8 +827,15 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_hits), sizeof(int) * PAINT_PER_ACTION * (size_t)b->cone_nb * n_envs);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * (items + 4));
-        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * (items + 4));
+        // counters, the trip list (every trip fits) and the ray list (PRL_CONE_JOINT_FROM = 5 rays per trip at most, as
+        // item << 6 | lane): k_cone_beams.hip
+        if (items >= ((size_t)1 << 25)) {
+            rc = fail(PRL_E_INVALID, "%zu beam trips per step: more than the cone-beam work lists index", items);
+            prl_batch_destroy(b);
+            return rc;
+        }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * (6 * items + 4));
+        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * (6 * items + 4));
         // hit points handed to the far search: 64 per env and step (a typical step has a dozen; a full list sends the
         // rest through the general code)
         const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 64, 4096), (size_t)1 << 26);

@@ -23,14 +23,33 @@ namespace {
 // -DPRL_CONE_TRACE (tools/cone_stats.py): how many beams take which path, summed over a run (global counters, read back
 // through prl_debug_cone_stats of the k_cone_beams unit).  The product build defines none of this.
 #ifdef PRL_CONE_TRACE
-__device__ unsigned long long g_cone_stat[16];
+__device__ unsigned long long g_cone_stat[32];
+#if PRL_CONE_TRACE == 2                          // the wave times alone (the counters' atomics stretch them tenfold)
+#define CONE_STAT(k, v)
+#else
 #define CONE_STAT(k, v)                                                              \
     do {                                                                             \
         const unsigned long long v_ = (unsigned long long)(v);                       \
         if ((threadIdx.x & 63) == 0 && v_) atomicAdd(&g_cone_stat[k], v_);           \
     } while (0)
+#endif
+// wave times (s_memrealtime ticks of 10 ns) as a histogram: slot k / 3 (0 far-list, 1 trip-list waves of the rest
+// kernel, 2 beams kernel), bucket = floor(log2(ticks)); ONE atomic per wave
+__device__ unsigned long long g_cone_hist[3 * 32];
+#define CONE_TIME_BEGIN() const unsigned long long cone_t0_ = __builtin_amdgcn_s_memrealtime()
+#define CONE_TIME_END(k)                                                             \
+    do {                                                                             \
+        const unsigned long long dt_ = __builtin_amdgcn_s_memrealtime() - cone_t0_;  \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_cone_hist[(k) * 32 + (63 - __builtin_clzll(dt_ | 1))], 1ull); \
+    } while (0)
 #else
 #define CONE_STAT(k, v)
+#define CONE_TIME_BEGIN() \
+    do {                  \
+    } while (0)
+#define CONE_TIME_END(k) \
+    do {                 \
+    } while (0)
 #endif
 
 #ifndef PRL_WALK_STEPS
@@ -262,6 +281,34 @@ __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], c
     return state;
 }
 
+// The outline test of cone_rays_lanes for ONE beam (pos -> dst, the same on every lane), the edges of the outline over the
+// lanes: whether the beam passes beside the part (then it misses every triangle).
+__device__ __forceinline__ bool beam_outside_outline_wave(PartRef P, const double pos[3], const double dst[3], int lane) {
+    if (P.n_outline <= 0) return false;
+    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
+    const double oz = sel3(pos[0], pos[1], pos[2], P.a0), dz = sel3(d0, d1, d2, P.a0);
+    const double lo = P.slab_lo - CONE_MISS_MARGIN, hi = P.slab_hi + CONE_MISS_MARGIN;
+    double ta = 0.0, tb = 1.0;
+    if (dz != 0.0) {
+        const double t0 = (lo - oz) / dz, t1 = (hi - oz) / dz;
+        ta = fmax(0.0, fmin(t0, t1) - 1e-9);
+        tb = fmin(1.0, fmax(t0, t1) + 1e-9);
+        if (ta > tb) return true;                             // never inside the slab
+    } else if (oz < lo || oz > hi) {
+        return true;
+    }
+    const double o1 = sel3(pos[0], pos[1], pos[2], P.a1), o2 = sel3(pos[0], pos[1], pos[2], P.a2);
+    const double e1 = sel3(d0, d1, d2, P.a1), e2 = sel3(d0, d1, d2, P.a2);
+    const double ax = o1 + ta * e1, ay = o2 + ta * e2, bx = o1 + tb * e1, by = o2 + tb * e2;
+    const f64x2 GAS *ol = reinterpret_cast<const f64x2 GAS *>(P.outline);
+    for (int base = 0; base < P.n_outline; base += 64) {      // (the table is padded to a multiple of 64 rows)
+        const f64x2 pq = ldg(ol, 2 * (base + lane)), nq = ldg(ol, 2 * (base + lane) + 1);
+        const double sa = nq.x * (ax - pq.x) + nq.y * (ay - pq.y), sb = nq.x * (bx - pq.x) + nq.y * (by - pq.y);
+        if (ballot64(base + lane < P.n_outline && sa > CONE_MISS_MARGIN && sb > CONE_MISS_MARGIN) != 0) return true;
+    }
+    return false;
+}
+
 // The rays of beams b0 + lane: hit[3] of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray (where
 // the wave-wide searches of leftover rays start).
 __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
@@ -407,93 +454,124 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
 }
 
 // ---------------------------------------------------------------- the same query on float records (the beams kernel)
-// The beams kernel is bound by the bytes its lanes gather through the CU's L1 (rocprofv3: TA busy 85 %), and most of
-// them are the 32-byte float64 records of this query.  Here the block is scanned on 16-byte records (x y z rounded to
-// float | device position) keeping the three nearest in float; only the ones that float arithmetic cannot tell from the
-// nearest are then measured in float64 (one, as a rule), so the answer is the float64 one bit for bit:
-//   a coordinate c, |c| <= M, rounds to float with error <= 2^-24 M; a difference of two such floats is exact before its
-//   own rounding, so each float difference is off by E <= 2^-23 M (1 + 2^-24); the float squared distance (three
-//   products, two sums, each rounded) is then off by at most  band(d) = 3.5 d E + 3 E^2 + 2^-22 d^2  for a distance d.
-// A record is a contender if its float distance minus its band does not exceed the nearest's plus its band.  Three
-// contenders: there may be a fourth -- the lane reports -2 and the far kernel's tree walk answers exactly.  Rings and
-// the acceptance test (on the exact distance) as in nearest_sample_lane.
+// The beams kernel is bound by the loads its lanes gather through the CU's L1 (rocprofv3: TA busy 73-85 %) and by vector
+// issue; most of both went into this query.  Three measures, the answer stays the float64 one bit for bit:
+//  * the block is scanned on 16-byte records (x y z rounded to float) keeping the three nearest in float; only the ones
+//    that float arithmetic cannot tell from the nearest are then measured in float64 (one, as a rule):
+//      a coordinate c, |c| <= M, rounds to float with error <= 2^-24 M; a difference of two such floats is exact before its
+//      own rounding, so each float difference is off by E <= 2^-23 M (1 + 2^-24); the float squared distance (three
+//      products, two sums, each rounded) is then off by at most  band(d) = 3.5 d E + 3 E^2 + 2^-22 d^2  for a distance d.
+//    A record is a contender if its float distance minus its band does not exceed the nearest's plus its band.  Three
+//    contenders: there may be a fourth -- the lane reports -2 and the rest kernel's tree walk answers exactly.
+//  * the three nearest are kept as KEYS: the float distance's bit pattern (non-negative floats order like unsigned
+//    integers) with its ten low mantissa bits replaced by the record's place in the scan (row of the block, offset in
+//    the row) -- three integer min / median instructions per record instead of three compares and six selects.  A key
+//    stands for a distance in [t, t (1 + 2^-13)), t = the key with the ten bits cleared; the contender test allows for it.
+//  * the first block is the 2 x 2 cells around the point (the cell's quadrant picks them): every sample outside it is more
+//    than half a cell away, so a nearest sample within 0.5 fg_accept is final -- ~16 records instead of the ~36 of the
+//    3 x 3 block.  Then rings and the acceptance test (on the exact distance) as in nearest_sample_lane.
 __device__ __forceinline__ float nn_band(float d2, float E) {
     const float d = __builtin_sqrtf(d2) * 1.0001f + 1e-12f;
     return 3.5f * d * E + 3.0f * E * E + 2.4e-7f * d2 + 1e-30f;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#ifndef PRL_NN_EMPTY_NEXT
+#define PRL_NN_EMPTY_NEXT 1          // (4 = straight to the tree: beams 233 -> 245 us, rest 90 -> 94)
+#endif
+#define NN_KEY_INF 0x7f800000u                  // +inf as a key
+#define NN_KEY_PLACE 0x3ffu                     // place in the scan: row << 7 | offset in the row
+#define NN_KEY_SLACK 1.000123f                  // > 1 + 2^-13
+
+// the float64 distance of the record a key names (rows of the block start at cell (cx0, cy0 + row)), with rank and position
+__device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int cx0, int cy0, const double pt[3], double &dd, int &rank,
+                                               int &pos) {
+    const int row = (int)((key >> 7) & 7u), off = (int)(key & 127u);
+    const int i = ldg(P.fg_start, (cy0 + row) * P.fg_nx + cx0) + off;
+    const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
+    const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
+    const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
+    dd = (dx * dx + dy * dy) + dz * dz;
+    rank = __double2loint(rb.y);
+    pos = __double2hiint(rb.y);
 }
 
 __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
+    const double f1 = (h1 - P.fg_o1) * P.fg_inv - (double)icx, f2 = (h2 - P.fg_o2) * P.fg_inv - (double)icy;   // place in the cell
+    const bool in_cell = f1 >= 0.0 && f1 < 1.0 && f2 >= 0.0 && f2 < 1.0;      // (cell_coord clamps far outside the grid)
     const f32x4 GAS *rec = reinterpret_cast<const f32x4 GAS *>(P.fg_rec32);
     const float qx = (float)pt[0], qy = (float)pt[1], qz = (float)pt[2];
     const double mq = fmax(fmax(fabs(pt[0]), fabs(pt[1])), fmax(fabs(pt[2]), P.samp_absmax));
     const float E = (float)(mq * 1.1920929e-7 * 1.001);              // 2^-23 M, rounded up
     int result = want ? -2 : -1;
     bool open = want && mq < 1.0e6;
-    int r = 1;
-    for (int pass = 0; pass < 3; ++pass) {
+    int r = in_cell ? 0 : 1;                                          // 0: the 2 x 2 block, r >= 1: r rings
+    for (int pass = 0; pass < 4; ++pass) {
         if (open && r > 3) open = false;                              // (stays -2)
         if (ballot64(open) == 0) break;
-        const int rmax = -wave_min_i(open ? -r : 0);                  // wave-uniform trip count, per-lane ranges
-        float d1 = INFINITY, d2 = INFINITY, d3 = INFINITY;
-        int p1 = -1, p2 = -1, p3 = -1;
-        const int cx0 = icx - r < 0 ? 0 : icx - r, cx1 = icx + r > P.fg_nx - 1 ? P.fg_nx - 1 : icx + r;
-        for (int dy = -rmax; dy <= rmax; ++dy) {
-            const int cy = icy + dy;
-            const bool row_ok = open && dy >= -r && dy <= r && cy >= 0 && cy < P.fg_ny && cx0 <= cx1;
-            const int b = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx0) : 0;
-            const int e = row_ok ? ldg(P.fg_start, cy * P.fg_nx + cx1 + 1) : 0;
-            for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4) {
+        int cx0 = r ? icx - r : (f1 < 0.5 ? icx - 1 : icx), cx1 = r ? icx + r : cx0 + 1;
+        int cy0 = r ? icy - r : (f2 < 0.5 ? icy - 1 : icy), cy1 = r ? icy + r : cy0 + 1;
+        cx0 = cx0 < 0 ? 0 : cx0, cx1 = cx1 > P.fg_nx - 1 ? P.fg_nx - 1 : cx1;
+        cy0 = cy0 < 0 ? 0 : cy0, cy1 = cy1 > P.fg_ny - 1 ? P.fg_ny - 1 : cy1;
+        const int rows = (open && cx0 <= cx1 && cy0 <= cy1) ? cy1 - cy0 + 1 : 0;
+        const int nrows = -wave_min_i(-rows);                         // wave-uniform trip count, per-lane ranges
+        unsigned k1 = NN_KEY_INF, k2 = NN_KEY_INF, k3 = NN_KEY_INF;
+        bool wide = false;
+        for (int j = 0; j < nrows; ++j) {
+            const bool row_ok = j < rows;
+            const int b = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx0) : 0;
+            int e = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx1 + 1) : 0;
+            if (e - b > 128) wide = true, e = b;                      // (more than a key can place: the tree decides)
+            unsigned place = (unsigned)j << 7;
+            for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4, place += 4) {
+                const int ib = i0 < e ? i0 : b;                       // (a lane that is through stays in range)
                 f32x4 rc[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rc[q] = ldg(rec, i0 + q < e ? i0 + q : (e > b ? e - 1 : 0));   // (in range)
+                for (int q = 0; q < 4; ++q) rc[q] = ldg(rec, ib + q); // (the table is padded by four records)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float ex = rc[q].x - qx, ey = rc[q].y - qy, ez = rc[q].z - qz;
-                    const float dd = i0 + q < e ? __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) : INFINITY;
-                    const int ps = __float_as_int(rc[q].w);
-                    // keep the three nearest (d1 <= d2 <= d3)
-                    const bool lt3 = dd < d3, lt2 = dd < d2, lt1 = dd < d1;
-                    d3 = lt2 ? d2 : (lt3 ? dd : d3);
-                    p3 = lt2 ? p2 : (lt3 ? ps : p3);
-                    d2 = lt1 ? d1 : (lt2 ? dd : d2);
-                    p2 = lt1 ? p1 : (lt2 ? ps : p2);
-                    d1 = lt1 ? dd : d1;
-                    p1 = lt1 ? ps : p1;
+                    const float dd = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                    const unsigned key = i0 + q < e ? ((__float_as_uint(dd) & ~NN_KEY_PLACE) | (place + q)) : NN_KEY_INF;
+                    k3 = umed3(k2, k3, key);                          // keep the three smallest (k1 <= k2 <= k3)
+                    k2 = umed3(k1, k2, key);
+                    k1 = k1 < key ? k1 : key;
                 }
             }
         }
         // float64 for the contenders
         double best_d = INFINITY;
         int best_rank = 0x7fffffff, best_pos = -1;
-        const float lim1 = d1 + nn_band(d1, E);
-        const bool c2 = open && p2 >= 0 && d2 - nn_band(d2, E) <= lim1, c3 = open && p3 >= 0 && d3 - nn_band(d3, E) <= lim1;
-        if (open && p1 >= 0) {
-            const double dx = ldg(P.samp[0], p1) - pt[0], dy = ldg(P.samp[1], p1) - pt[1], dz = ldg(P.samp[2], p1) - pt[2];
-            best_d = (dx * dx + dy * dy) + dz * dz;
-            best_pos = p1;
-        }
+        const float t1 = __uint_as_float(k1 & ~NN_KEY_PLACE) * NN_KEY_SLACK;
+        const float lim1 = t1 + nn_band(t1, E);
+        const float t2 = __uint_as_float(k2 & ~NN_KEY_PLACE), t3 = __uint_as_float(k3 & ~NN_KEY_PLACE);
+        const bool c2 = open && k2 < NN_KEY_INF && t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1;
+        const bool c3 = open && k3 < NN_KEY_INF && t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1;
+        if (open && k1 < NN_KEY_INF) nn_key_measure(P, k1, cx0, cy0, pt, best_d, best_rank, best_pos);
         if (ballot64(c2) != 0) {
             if (c2) {
-                best_rank = ldg(P.samp_rank, p1);
-                const double dx = ldg(P.samp[0], p2) - pt[0], dy = ldg(P.samp[1], p2) - pt[1], dz = ldg(P.samp[2], p2) - pt[2];
-                const double dd = (dx * dx + dy * dy) + dz * dz;
-                const int rk = ldg(P.samp_rank, p2);
+                double dd;
+                int rk, ps;
+                nn_key_measure(P, k2, cx0, cy0, pt, dd, rk, ps);
                 if (dd < best_d || (dd == best_d && rk < best_rank)) {
                     best_d = dd;
-                    best_pos = p2;
+                    best_pos = ps;
                 }
             }
         }
-        const double lim = r * P.fg_accept;
-        if (open && c3) {
+        const double lim = r ? r * P.fg_accept : 0.5 * P.fg_accept;
+        if (open && (c3 || wide)) {
             open = false;                                            // three the float distances cannot order: the tree decides
         } else if (open && best_pos >= 0 && best_d <= lim * lim) {
             result = best_pos;
             open = false;
         } else if (open) {
-            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : 2 * r + 2;
+            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : (r ? 2 * r + 2 : PRL_NN_EMPTY_NEXT);
             r = need > r ? need : r + 1;
         }
     }
@@ -521,12 +599,32 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     double best_d = INFINITY;
     int best_rank = 0x7fffffff, best_pos = -1, sp = 0;
+    if (want) {
+        // the first bound: a sample of the point's own cell column, or of the nearest column that has one (fg_seed).  The
+        // walk below then never descends into a node farther than that -- a dozen visits instead of forty.
+        int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
+        int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
+        cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
+        const int i = ldg(P.fg_seed, cy * P.fg_nx + cx);
+        if (i >= 0) {
+            const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
+            const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
+            const double dd = (dx * dx + dy * dy) + dz * dz;
+            if (dd == dd) {                              // (a NaN point finds nothing, as before)
+                best_d = dd;
+                best_rank = __double2loint(rb.y);
+                best_pos = __double2hiint(rb.y);
+            }
+        }
+    }
     if (want) {                                          // the root: level py_levels - 1 is one node
         stack[0] = (int)((unsigned)(P.py_levels - 1) << 28);
         stack[cap * TREE_STRIDE] = 0;                    // its bound (float bits): 0
         sp = 1;
     }
     while (ballot64(sp > 0) != 0) {
+        CONE_STAT(19, 1);
         if (sp > 0) {
             --sp;
             const int node = stack[sp * TREE_STRIDE];

@@ -36,24 +36,31 @@ def main():
     steps = int(os.environ.get('PRL_TRACE_STEPS', '20'))
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
-    acts = torch.randint(0, 4, (40 + steps, n), generator=gen, device='cuda', dtype=torch.int32)
+    warm = int(os.environ.get('PRL_WARM_STEPS', '40'))       # (the env population drifts: 2000 for the bench's late steps)
+    acts = torch.randint(0, 4, (warm + steps, n), generator=gen, device='cuda', dtype=torch.int32)
     env = BatchedPaintEnv(DeviceTables(tables), n, auto_reset=True, seed=5678, paint_method='normal')
     env.reset()
-    for s in range(40):
+    for s in range(warm):
         env.step_raw(acts[s])
     torch.cuda.synchronize()
-    out = np.zeros(16, dtype=np.uint64)
+    out = np.zeros(128, dtype=np.uint64)
     lib.prl_debug_cone_stats(out.ctypes.data)
-    for s in range(40, 40 + steps):
+    for s in range(warm, warm + steps):
         env.step_raw(acts[s])
     torch.cuda.synchronize()
     assert lib.prl_debug_cone_stats(out.ctypes.data) == 0
     env.close()
-    per = out.astype(np.float64) / (steps * n)
-    print('per env-step (%d envs, %d steps; beams kernel + rest kernel together):' % (n, steps))
+    per = out[:32].astype(np.float64) / (steps * n)
+    print('after %d steps,' % warm, 'per env-step (%d envs, %d steps; beams kernel + rest kernel together):' % (n, steps))
+    per = np.concatenate([per, np.zeros(16)])[:32]
     for k, nm in enumerate(NAMES):
         if nm != '-':
             print('  %-40s %10.3f' % (nm, per[k]))
+    for k, nm in enumerate(('far-list waves of the rest kernel', 'trip-list waves of the rest kernel', 'waves of the beams kernel')):
+        h = out[32 + 32 * k:64 + 32 * k].astype(np.int64)
+        print('  %s: %.3f per env-step; by time (us, lower edge of the bucket: waves per launch)' % (nm, h.sum() / (steps * n)))
+        print('     ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
+    print('  tree-walk loop trips per far-list wave %.1f' % (out[19] / max(out[16] + out[20], 1)))
     print('  mean walk loop trips per beam trip %.2f, mean steps per walked beam %.2f' % (out[13] / max(out[0], 1), out[15] / max(out[1], 1)))
 
 
