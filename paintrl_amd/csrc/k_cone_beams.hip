@@ -22,6 +22,7 @@
 
 namespace {
 
+constexpr int CONE_RAY_LIST_MAX = PRL_CONE_RAY_LIST_MAX;   // (prl_device.hpp: the host sizes the list)
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
 #ifndef PRL_REST_WGS
 #define PRL_REST_WGS 384
@@ -97,7 +98,7 @@ __device__ __forceinline__ bool beam_item(const StepArgs CAS &a, int item, int &
 }
 
 // cone_work: [0] trips in the trip list, [1] entries of the far list, [2] its capacity, [3] rays in the ray list, then the
-// trip list (capacity: every trip) and the ray list (item << 6 | lane; CONE_JOINT_FROM per trip at most)
+// trip list (capacity: every trip) and the ray list (item << 6 | lane; CONE_RAY_LIST_MAX per trip at most)
 __device__ __forceinline__ int *ray_list(const StepArgs CAS &a) {
     return a.cone_work + 4 + (size_t)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
 }
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     const int dest = (env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane;
     const uint64_t far = ballot64(sidx == -2), left = ballot64(state == 3);
     int far_base = 0;
-    // rays the walk left over: a few go to the ray list one by one, more than that (a collision set that is not convex:
-    // all of them) send the whole trip through the general code
-    bool redo = (int)__popcll(left) > CONE_JOINT_FROM;
+    // rays the walk left over go to the ray list one by one (a wave each in the rest kernel: microseconds); a trip where more
+    // than half the lanes are left over (a collision set that is not convex: all of them) goes through the general code whole
+    bool redo = (int)__popcll(left) > CONE_RAY_LIST_MAX;
     if (!redo && far) {
         // hit points far from every sample: one entry each in the far list (the far role takes 64 of them per wave)
         if (lane == 0) far_base = atomicAdd(a.cone_work + 1, (int)__popcll(far));
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
         if (lane == 0) a.cone_work[4 + atomicAdd(a.cone_work, 1)] = item;
         // a reservation that ran over the end of the far list: the entries of it that do lie inside are marked void (the
         // far role of cone_rest_kernel walks the list up to its capacity)
-        if (far && (int)__popcll(left) <= CONE_JOINT_FROM) {
+        if (far && (int)__popcll(left) <= CONE_RAY_LIST_MAX) {
             const int slot = far_base + lane;
             if (lane < (int)__popcll(far) && slot < a.cone_work[2])
                 reinterpret_cast<f64x2 *>(a.cone_far)[2 * (size_t)slot + 1] = f64x2{0.0, __hiloint2double(0, -1)};

@@ -311,13 +311,15 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             for (int i = 0; i < d.n_col_pad; ++i)
                 if (corner[i][0] >= 0)
                     for (int e = 0; e < 3; ++e) edge_facets[key(corner[i][ea[e]], corner[i][eb[e]])].push_back(i);
-            std::vector<int32_t> enbr((size_t)d.n_col_pad * 3, -1);
-            for (int i = 0; i < d.n_col_pad; ++i)
+            std::vector<int32_t> enbr((size_t)d.n_col_pad * 4, -1);       // three neighbours | the facet's reference index
+            for (int i = 0; i < d.n_col_pad; ++i) {
+                enbr[(size_t)i * 4 + 3] = t->col_rank[i];
                 if (corner[i][0] >= 0)
                     for (int e = 0; e < 3; ++e) {
                         const std::vector<int> &fs = edge_facets[key(corner[i][ea[e]], corner[i][eb[e]])];
-                        if (fs.size() == 2) enbr[(size_t)i * 3 + e] = fs[0] == i ? fs[1] : fs[0];
+                        if (fs.size() == 2) enbr[(size_t)i * 4 + e] = fs[0] == i ? fs[1] : fs[0];
                     }
+            }
             UP(col_enbr, enbr.data(), enbr.size());
         }
         // front-facet grid for the cone beams' walks (prl_cone.hpp): for the centre of every cell of a grid over the set's
@@ -481,17 +483,23 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_nx = nx;
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
-        {   // a sample near every cell (its own first record, or that of the nearest cell with samples, breadth first)
-            std::vector<int> seed((size_t)nx * ny, -1), queue;
+        {   // a sample near every cell (its own first record, or that of the nearest cell with samples, breadth first over
+            // the eight neighbours) and how many rings of cells away that cell is (fg_seed = ring count << 24 | record)
+            std::vector<int> seed((size_t)nx * ny, -1), gap((size_t)nx * ny, 0), queue;
             queue.reserve(seed.size());
             for (int c = 0; c < nx * ny; ++c)
                 if (start[c + 1] > start[c]) seed[c] = start[c], queue.push_back(c);
             for (size_t h = 0; h < queue.size(); ++h) {
                 const int c = queue[h], cx = c % nx, cy = c / nx;
-                const int nb[4] = {cx > 0 ? c - 1 : -1, cx < nx - 1 ? c + 1 : -1, cy > 0 ? c - nx : -1, cy < ny - 1 ? c + nx : -1};
-                for (int k = 0; k < 4; ++k)
-                    if (nb[k] >= 0 && seed[nb[k]] < 0) seed[nb[k]] = seed[c], queue.push_back(nb[k]);
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int x = cx + dx, y = cy + dy;
+                        if (x < 0 || x >= nx || y < 0 || y >= ny || seed[y * nx + x] >= 0) continue;
+                        seed[y * nx + x] = seed[c], gap[y * nx + x] = gap[c] + 1, queue.push_back(y * nx + x);
+                    }
             }
+            for (size_t c = 0; c < seed.size(); ++c)            // (a table beyond 16 M samples: no seeds)
+                seed[c] = real.size() < ((size_t)1 << 24) ? (seed[c] & 0xffffff) | (std::min(gap[c], 127) << 24) : -1;
             UP(fg_seed, seed.data(), seed.size());
         }
         UP(fg_rec, rec.data(), rec.size());
@@ -517,6 +525,10 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
                 for (int c = 0; c < cnx * cny; ++c) {
                     float *b = lv + (size_t)c * 8;
                     b[0] = b[1] = b[2] = INFINITY, b[4] = b[5] = b[6] = -INFINITY, b[3] = b[7] = 0.0f;
+                    if (l == 0) {                    // the spare floats of a cell's box: its record range (int bits)
+                        std::memcpy(&b[3], &start[c], sizeof(int32_t));
+                        std::memcpy(&b[7], &start[c + 1], sizeof(int32_t));
+                    }
                 }
                 if (l == 0) {
                     for (size_t j = 0; j < real.size(); ++j) {
@@ -822,20 +834,20 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess && cfg->paint_method == PRL_PAINT_NORMAL) {
         // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
         b->cone_nb = ((b->max_beams + 63) / 64) * 64;
-        for (int i = 0; i < n_parts; ++i) b->cone_tree_cap = std::max(b->cone_tree_cap, 3 * parts[i]->dev.py_levels + 2);
+        for (int i = 0; i < n_parts; ++i) b->cone_tree_cap = std::max(b->cone_tree_cap, 3 * parts[i]->dev.py_levels + 2);      // = tree_stack_cap
         const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
         e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_hits), sizeof(int) * PAINT_PER_ACTION * (size_t)b->cone_nb * n_envs);
-        // counters, the trip list (every trip fits) and the ray list (PRL_CONE_JOINT_FROM = 5 rays per trip at most, as
+        // counters, the trip list (every trip fits) and the ray list (PRL_CONE_RAY_LIST_MAX rays per trip at most, as
         // item << 6 | lane): k_cone_beams.hip
         if (items >= ((size_t)1 << 25)) {
             rc = fail(PRL_E_INVALID, "%zu beam trips per step: more than the cone-beam work lists index", items);
             prl_batch_destroy(b);
             return rc;
         }
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * (6 * items + 4));
-        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * (6 * items + 4));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * ((1 + PRL_CONE_RAY_LIST_MAX) * items + 4));
+        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * ((1 + PRL_CONE_RAY_LIST_MAX) * items + 4));
         // hit points handed to the far search: 64 per env and step (a typical step has a dozen; a full list sends the
         // rest through the general code)
         const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 64, 4096), (size_t)1 << 26);

@@ -87,6 +87,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
     const int i6 = i * 6;
     const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4),
                 r5 = ldg(r, i6 + 5);
+    const i32x4 nb = ldg(reinterpret_cast<const i32x4 GAS *>(P.col_enbr), i);      // neighbours | rank: the same round trip
     const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
     const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
     const double p0 = d1 * e22 - d2 * e21;
@@ -123,8 +124,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
         // normal lies between the two facets' outward normals), so a LINE that runs on its outer side, more than the
         // margin away, misses the hull -- most beams that miss pass beside the part and end exactly like this.
         if (!front && prev >= 0 && orient * det < 0 && det * det >= CONE_SIL_MIN_COS2 * dd * nn) {
-            const int b0 = ldg(P.col_enbr, 3 * i), b1 = ldg(P.col_enbr, 3 * i + 1), b2 = ldg(P.col_enbr, 3 * i + 2);
-            const int k = b0 == prev ? 0 : (b1 == prev ? 1 : (b2 == prev ? 2 : -1));
+            const int k = nb.x == prev ? 0 : (nb.y == prev ? 1 : (nb.z == prev ? 2 : -1));
             if (k >= 0) {
                 // edge k of this facet (part_fill: 0 = v0 .. v0 + e2, 1 = v0 .. v0 + e1, 2 = v0 + e1 .. v0 + e2): a point
                 // of it relative to the beam's origin, its direction, and the facet's third corner relative to that point
@@ -161,13 +161,13 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
         // beyond the beam's end point it means the beam stops short of the part: a miss
         out.code = (t <= 1.0) ? 1 : 2;
         out.t = t;
-        out.rank = ldg(P.col_rank, i);
+        out.rank = nb.w;
         return out;
     }
     // outside the triangle (or within the edge margin): cross the edge that is violated most
     const double w = 1.0 - u - v;
     const int e = (u <= v && u <= w) ? 0 : ((v <= w) ? 1 : 2);         // 0: u smallest, 1: v, 2: w = 1 - u - v
-    out.next = ldg(P.col_enbr, 3 * i + e);
+    out.next = e == 0 ? nb.x : (e == 1 ? nb.y : nb.z);
     out.code = 0;
     return out;
 }
@@ -479,18 +479,13 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-#ifndef PRL_NN_EMPTY_NEXT
-#define PRL_NN_EMPTY_NEXT 1          // (4 = straight to the tree: beams 233 -> 245 us, rest 90 -> 94)
-#endif
 #define NN_KEY_INF 0x7f800000u                  // +inf as a key
 #define NN_KEY_PLACE 0x3ffu                     // place in the scan: row << 7 | offset in the row
 #define NN_KEY_SLACK 1.000123f                  // > 1 + 2^-13
 
-// the float64 distance of the record a key names (rows of the block start at cell (cx0, cy0 + row)), with rank and position
-__device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int cx0, int cy0, const double pt[3], double &dd, int &rank,
-                                               int &pos) {
-    const int row = (int)((key >> 7) & 7u), off = (int)(key & 127u);
-    const int i = ldg(P.fg_start, (cy0 + row) * P.fg_nx + cx0) + off;
+// the float64 distance of the record a key names (row `row` of the block starts at record b_row), with rank and position
+__device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int b_row, const double pt[3], double &dd, int &rank, int &pos) {
+    const int i = b_row + (int)(key & 127u);
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
     const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
@@ -511,21 +506,37 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     int result = want ? -2 : -1;
     bool open = want && mq < 1.0e6;
     int r = in_cell ? 0 : 1;                                          // 0: the 2 x 2 block, r >= 1: r rings
+    // how many rings of cells lie between the point's cell and the nearest cell that has samples at all (fg_seed): a
+    // search that finds its first block empty starts there -- or, beyond three rings, leaves the point to the tree at
+    // once (a hit on the hull over a window of the part)
+    const int gcx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), gcy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
+    const int seed = open ? ldg(P.fg_seed, gcy * P.fg_nx + gcx) : 0;
+    const int gap = (seed >= 0 && icx == gcx && icy == gcy) ? seed >> 24 : 0;
     for (int pass = 0; pass < 4; ++pass) {
         if (open && r > 3) open = false;                              // (stays -2)
         if (ballot64(open) == 0) break;
         int cx0 = r ? icx - r : (f1 < 0.5 ? icx - 1 : icx), cx1 = r ? icx + r : cx0 + 1;
         int cy0 = r ? icy - r : (f2 < 0.5 ? icy - 1 : icy), cy1 = r ? icy + r : cy0 + 1;
+        // the block's border is this far from the point, in cells, wherever it is not the grid's own (0.5 .. 1 for the
+        // 2 x 2 block, r for r rings): every sample outside the block is farther than that
+        const double reach = r ? (double)r : fmin(fmin(f1 < 0.5 ? f1 + 1.0 : f1, f1 < 0.5 ? 1.0 - f1 : 2.0 - f1),
+                                                  fmin(f2 < 0.5 ? f2 + 1.0 : f2, f2 < 0.5 ? 1.0 - f2 : 2.0 - f2));
         cx0 = cx0 < 0 ? 0 : cx0, cx1 = cx1 > P.fg_nx - 1 ? P.fg_nx - 1 : cx1;
         cy0 = cy0 < 0 ? 0 : cy0, cy1 = cy1 > P.fg_ny - 1 ? P.fg_ny - 1 : cy1;
         const int rows = (open && cx0 <= cx1 && cy0 <= cy1) ? cy1 - cy0 + 1 : 0;
         const int nrows = -wave_min_i(-rows);                         // wave-uniform trip count, per-lane ranges
+        // the record ranges of the first two rows travel together (the 2 x 2 block has no more)
+        const int b0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx0) : 0, e0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx1 + 1) : 0;
+        const int b1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx0) : 0, e1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx1 + 1) : 0;
         unsigned k1 = NN_KEY_INF, k2 = NN_KEY_INF, k3 = NN_KEY_INF;
         bool wide = false;
         for (int j = 0; j < nrows; ++j) {
             const bool row_ok = j < rows;
-            const int b = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx0) : 0;
-            int e = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx1 + 1) : 0;
+            int b = j == 0 ? b0 : b1, e = j == 0 ? e0 : e1;
+            if (j > 1) {
+                b = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx0) : 0;
+                e = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx1 + 1) : 0;
+            }
             if (e - b > 128) wide = true, e = b;                      // (more than a key can place: the tree decides)
             unsigned place = (unsigned)j << 7;
             for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4, place += 4) {
@@ -552,26 +563,37 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
         const float t2 = __uint_as_float(k2 & ~NN_KEY_PLACE), t3 = __uint_as_float(k3 & ~NN_KEY_PLACE);
         const bool c2 = open && k2 < NN_KEY_INF && t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1;
         const bool c3 = open && k3 < NN_KEY_INF && t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1;
-        if (open && k1 < NN_KEY_INF) nn_key_measure(P, k1, cx0, cy0, pt, best_d, best_rank, best_pos);
-        if (ballot64(c2) != 0) {
-            if (c2) {
-                double dd;
-                int rk, ps;
-                nn_key_measure(P, k2, cx0, cy0, pt, dd, rk, ps);
-                if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                    best_d = dd;
-                    best_pos = ps;
+        const bool m1 = open && k1 < NN_KEY_INF, m2 = c2 && !c3;
+        if (ballot64(m1) != 0) {
+            // (rows past the second: their first record is looked up again)
+            const int row1 = (int)((k1 >> 7) & 7u), row2 = (int)((k2 >> 7) & 7u);
+            int s1 = row1 == 0 ? b0 : b1, s2 = row2 == 0 ? b0 : b1;
+            if (ballot64((m1 && row1 > 1) || (m2 && row2 > 1)) != 0) {
+                if (m1 && row1 > 1) s1 = ldg(P.fg_start, (cy0 + row1) * P.fg_nx + cx0);
+                if (m2 && row2 > 1) s2 = ldg(P.fg_start, (cy0 + row2) * P.fg_nx + cx0);
+            }
+            if (m1) nn_key_measure(P, k1, s1, pt, best_d, best_rank, best_pos);
+            if (ballot64(m2) != 0) {
+                if (m2) {
+                    double dd;
+                    int rk, ps;
+                    nn_key_measure(P, k2, s2, pt, dd, rk, ps);
+                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        best_d = dd;
+                        best_pos = ps;
+                    }
                 }
             }
         }
-        const double lim = r ? r * P.fg_accept : 0.5 * P.fg_accept;
+        const double lim = reach * P.fg_accept;
         if (open && (c3 || wide)) {
             open = false;                                            // three the float distances cannot order: the tree decides
         } else if (open && best_pos >= 0 && best_d <= lim * lim) {
             result = best_pos;
             open = false;
         } else if (open) {
-            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : (r ? 2 * r + 2 : PRL_NN_EMPTY_NEXT);
+            // the ring that will settle it: the best so far names it; an empty block asks the gap table
+            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : (gap > 0 ? gap : (r ? 2 * r + 2 : 1));
             r = need > r ? need : r + 1;
         }
     }
@@ -588,7 +610,8 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
 // (PartDev::py_*) depth first, nearest child first: a node is visited only if the distance from the point to its
 // bounding box (boxes rounded outward, so never more than to any sample inside) does not exceed the best found so far;
 // the samples of a cell are measured as in nearest_sample_lane (float64, equal distances to the lowest reference index).
-// ~10 node visits and a handful of cells per query whatever the distance.  `stack`: 2 x cap ints per lane in LDS (this
+// ~10 node visits and a handful of cells per query whatever the distance; a cell goes on the stack as its record range
+// (sign bit | count << 22 | first record: one dependent read less per cell).  `stack`: 2 x cap ints per lane in LDS (this
 // lane's column: stack[k * TREE_STRIDE]), cap >= tree_stack_cap(levels): a visit takes one entry off and puts at most four
 // on.  Returns the device position of the sample; -1 if not `want` or the part has no pyramid.
 __host__ __device__ constexpr int tree_stack_cap(int levels) { return 3 * levels + 2; }
@@ -606,8 +629,8 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
         int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
         cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
         cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
-        const int i = ldg(P.fg_seed, cy * P.fg_nx + cx);
-        if (i >= 0) {
+        const int sd = ldg(P.fg_seed, cy * P.fg_nx + cx), i = sd & 0xffffff;
+        if (sd >= 0) {
             const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
             const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
@@ -619,7 +642,7 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
         }
     }
     if (want) {                                          // the root: level py_levels - 1 is one node
-        stack[0] = (int)((unsigned)(P.py_levels - 1) << 28);
+        stack[0] = (P.py_levels - 1) << 24;
         stack[cap * TREE_STRIDE] = 0;                    // its bound (float bits): 0
         sp = 1;
     }
@@ -630,10 +653,16 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
             const int node = stack[sp * TREE_STRIDE];
             const float bound = __int_as_float(stack[(cap + sp) * TREE_STRIDE]);
             if ((double)bound <= best_d) {
-                const int level = (int)((unsigned)node >> 28), cy = (node >> 14) & 0x3fff, cx = node & 0x3fff;
-                if (level == 0) {
-                    const int c = cy * P.fg_nx + cx;
-                    const int b = ldg(P.fg_start, c), e = ldg(P.fg_start, c + 1);
+                const int level = (node >> 24) & 15, cy = (node >> 12) & 0xfff, cx = node & 0xfff;     // (level << 24 | cy << 12 | cx)
+                if (node < 0 || level == 0) {            // a cell: its record range in the entry, or looked up
+                    int b, e;
+                    if (node < 0) {
+                        b = node & 0x3fffff;
+                        e = b + ((node >> 22) & 0x1ff);
+                    } else {
+                        b = ldg(P.fg_start, cy * P.fg_nx + cx);
+                        e = ldg(P.fg_start, cy * P.fg_nx + cx + 1);
+                    }
                     for (int i0 = b; i0 < e; i0 += 4) {
                         f64x2 ra[4], rb[4];
 #pragma unroll
@@ -671,7 +700,11 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
                         const double ez = fmax(fmax((double)lo.z - pt[2], pt[2] - (double)hi.z), 0.0);
                         const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
                         key[q] = (in && d2 <= best_d) ? __double2float_rd(d2) : INFINITY;
-                        val[q] = (int)(((unsigned)cl << 28) | ((unsigned)py << 14) | (unsigned)px);
+                        val[q] = (cl << 24) | (py << 12) | px;
+                        if (cl == 0) {                   // a cell travels as its record range (the spare floats of its box)
+                            const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
+                            if (b < (1 << 22) && cnt < 512) val[q] = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
+                        }
                     }
                     // farthest first onto the stack, so that the nearest child is looked at next
 #pragma unroll

@@ -31,6 +31,7 @@ constexpr double SHOT_CENTRE_OFFSET = 0.1;      // rob:277-278: the shot centre 
 // a hit on this triangle makes of its normal, computed once on upload with the device's own arithmetic:
 // quat = get_pose_orn(-normal) (rob:93-100), centre_off = R(quat) (0, 0, 0.1) (rob:277-278).
 constexpr int TRI_REC = 24;
+#define PRL_CONE_RAY_LIST_MAX 32                // leftover rays of a beam trip that go to the ray list one by one (k_cone_beams.hip)
 constexpr int PY_MAX_LEVELS = 13;               // box pyramid over the fine sample grid (PartDev::py_*): grids up to 4096 cells wide
 
 // Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
@@ -46,6 +47,7 @@ typedef const uint8_t GAS *gu8_p;
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct PartDev {
     int n_samples, n_samples_pad, n_words;
@@ -64,13 +66,15 @@ struct PartDev {
     gdouble_p fg_rec;             // [n_samples][4]
     gfloat_p fg_rec32;            // [n_samples][4]: the same records as x y z rounded to float | device position (int bits)
     // box pyramid over the fine grid (derived in part_fill): level 0 = the cells, level l = 2^l x 2^l of them; a node is the
-    // bounding box of its samples as 8 floats (lo x y z, 0, hi x y z, 0; rounded outward; empty: lo = +inf, hi = -inf).
+    // bounding box of its samples as 8 floats (lo x y z, -, hi x y z, -; rounded outward; empty: lo = +inf, hi = -inf; the
+    // spare floats of a CELL hold its record range fg_start[c], fg_start[c + 1] as int bits).
     // nearest_sample_tree walks it branch and bound: exact nearest samples of points centimetres to decimetres from the
     // sampled surface (the collision hull spans windows and recesses of the part), where a ring of cells has no grip.
     int py_levels;                // 0: no pyramid
     int py_off[PY_MAX_LEVELS], py_nx[PY_MAX_LEVELS], py_ny[PY_MAX_LEVELS];      // first node / dimensions of each level
     gfloat_p py_box;
-    gint_p fg_seed;               // [fg_nx * fg_ny]: a record of the cell, or of the nearest cell that has one: the tree walk's first bound
+    gint_p fg_seed;               // [fg_nx * fg_ny]: rings of cells to the nearest cell with samples << 24 | a record of that cell
+                                  // (the tree walk's first bound; the ring search starts at that ring)
     // outline of the collision set in the principal plane (convex polygon, derived in part_fill) and its extent along
     // the third axis: a beam whose stretch inside that slab projects outside the outline misses the part (prl_cone.hpp)
     int n_outline;                // edges, 0 = no test; the table is padded to a multiple of 64 rows
@@ -105,7 +109,7 @@ struct PartDev {
     gint_p col_rank;
     int col_convex, nbr_width;
     gint_p col_nbr, col_orient;
-    gint_p col_enbr;              // convex sets: [n_col_pad][3] facet across the edge u = 0 / v = 0 / u + v = 1, or -1 (derived)
+    gint_p col_enbr;              // convex sets: [n_col_pad][4] facet across the edge u = 0 / v = 0 / u + v = 1, or -1 | col_rank (derived)
     // convex sets: the facet met by a line along axis a0 through the centre of each cell of a grid over the set's outline
     // (the one on the tool's side; cells beside the set hold their nearest neighbour's): where a cone beam's walk starts
     double hg_o1, hg_o2, hg_inv;
