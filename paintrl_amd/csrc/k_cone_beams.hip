@@ -289,10 +289,10 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
 
 #if defined(PRL_CONE_TRACE) && defined(PRL_DIAG_EXPORT)
 // diagnostic build only: read and clear the beams kernel's path counters (prl_cone.hpp CONE_STAT)
-extern "C" int prl_debug_cone_stats(unsigned long long *out) {       // out[32 + 96]: counters, wave-time histograms
+extern "C" int prl_debug_cone_stats(unsigned long long *out) {       // out[32 + 160]: counters, wave-time histograms
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cone_stat), sizeof(unsigned long long) * 32) != hipSuccess) return PRL_E_HIP;
-    if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_cone_hist), sizeof(unsigned long long) * 96) != hipSuccess) return PRL_E_HIP;
-    unsigned long long zero[96] = {0};
+    if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_cone_hist), sizeof(unsigned long long) * 160) != hipSuccess) return PRL_E_HIP;
+    unsigned long long zero[160] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_cone_stat), zero, sizeof(unsigned long long) * 32) != hipSuccess) return PRL_E_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_cone_hist), zero, sizeof zero) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;

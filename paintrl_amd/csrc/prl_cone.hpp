@@ -35,15 +35,21 @@ __device__ unsigned long long g_cone_stat[32];
 #endif
 // wave times (s_memrealtime ticks of 10 ns) as a histogram: slot k / 3 (0 far-list, 1 trip-list waves of the rest
 // kernel, 2 beams kernel), bucket = floor(log2(ticks)); ONE atomic per wave
-__device__ unsigned long long g_cone_hist[3 * 32];
+__device__ unsigned long long g_cone_hist[5 * 32];      // [3]: tree-walk loop trips per wave / 2, [4]: time of a tree walk
 #define CONE_TIME_BEGIN() const unsigned long long cone_t0_ = __builtin_amdgcn_s_memrealtime()
 #define CONE_TIME_END(k)                                                             \
     do {                                                                             \
         const unsigned long long dt_ = __builtin_amdgcn_s_memrealtime() - cone_t0_;  \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_cone_hist[(k) * 32 + (63 - __builtin_clzll(dt_ | 1))], 1ull); \
     } while (0)
+#define CONE_HIST(k, bucket)                                                         \
+    do {                                                                             \
+        const int b_ = (bucket);                                                     \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_cone_hist[(k) * 32 + (b_ < 31 ? b_ : 31)], 1ull); \
+    } while (0)
 #else
 #define CONE_STAT(k, v)
+#define CONE_HIST(k, bucket)
 #define CONE_TIME_BEGIN() \
     do {                  \
     } while (0)
@@ -646,105 +652,133 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
         stack[cap * TREE_STRIDE] = 0;                    // its bound (float bits): 0
         sp = 1;
     }
-    while (ballot64(sp > 0) != 0) {
+    // the levels' dimensions and first nodes, level k in lane k: looked up by lane permutes (a read of PartDev's arrays at a
+    // per-lane index would be one more dependent memory round trip in every node visit)
+    const int tl = (int)(threadIdx.x & 63) < PY_MAX_LEVELS ? (int)(threadIdx.x & 63) : PY_MAX_LEVELS - 1;
+    const int lv_nx = P.py_nx[tl], lv_ny = P.py_ny[tl], lv_off = P.py_off[tl];
+    bool over = false;
+    const i32x4 GAS *boxes_q = reinterpret_cast<const i32x4 GAS *>(P.py_box), *rec_q = reinterpret_cast<const i32x4 GAS *>(P.fg_rec);
+#ifdef PRL_CONE_TRACE
+    int trips_ = 0;
+    CONE_TIME_BEGIN();
+#endif
+    // One trip of the loop = one batch of eight 16-byte reads per lane, whatever its entry is: the boxes of a node's four
+    // children (lo, hi) or four records of a cell (x y | z rank-pos) -- the wave waits for memory once per trip.
+    for (;;) {
+        // entries the best so far rules out come off without a trip
+        for (;;) {
+            const int top = sp > 0 ? sp - 1 : 0;
+            const bool drop = sp > 0 && (double)__int_as_float(stack[(cap + top) * TREE_STRIDE]) > best_d;
+            if (ballot64(drop) == 0) break;
+            if (drop) --sp;
+        }
+        if (ballot64(sp > 0) == 0) break;
         CONE_STAT(19, 1);
-        if (sp > 0) {
-            --sp;
-            const int node = stack[sp * TREE_STRIDE];
-            const float bound = __int_as_float(stack[(cap + sp) * TREE_STRIDE]);
-            if ((double)bound <= best_d) {
-                const int level = (node >> 24) & 15, cy = (node >> 12) & 0xfff, cx = node & 0xfff;     // (level << 24 | cy << 12 | cx)
-                if (node < 0 || level == 0) {            // a cell: its record range in the entry, or looked up
-                    int b, e;
-                    if (node < 0) {
-                        b = node & 0x3fffff;
-                        e = b + ((node >> 22) & 0x1ff);
-                    } else {
-                        b = ldg(P.fg_start, cy * P.fg_nx + cx);
-                        e = ldg(P.fg_start, cy * P.fg_nx + cx + 1);
+#ifdef PRL_CONE_TRACE
+        ++trips_;
+#endif
+        const bool act = sp > 0;
+        const int top = act ? sp - 1 : 0;
+        int node = stack[top * TREE_STRIDE];
+        const int bound_bits = stack[(cap + top) * TREE_STRIDE];
+        if (act) --sp;
+        const int level = (node >> 24) & 15, cy = (node >> 12) & 0xfff, cx = node & 0xfff;       // (node: level << 24 | cy << 12 | cx)
+        if (act && node >= 0 && level == 0) over = true;  // a cell whose record range did not fit its entry (512 samples in a
+        if (over) sp = 0;                                 // cell, a table beyond 4 M): the caller's wave-wide search
+        const bool leaf = act && node < 0, inner = act && node >= 0 && level > 0;
+        const int lb = node & 0x3fffff, lcnt = (node >> 22) & 0x1ff;                             // a cell: first record, count
+        const int lsel = level > 0 ? (level - 1) << 2 : 0;                                       // the children's level (byte address of its lane)
+        const int cnx = __builtin_amdgcn_ds_bpermute(lsel, lv_nx), cny = __builtin_amdgcn_ds_bpermute(lsel, lv_ny),
+                  off = __builtin_amdgcn_ds_bpermute(lsel, lv_off);
+        i32x4 qa[4], qb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
+            const int n = off + ((inner && px < cnx && py < cny) ? py * cnx + px : 0);
+            const int i = lb + (q < lcnt ? q : (lcnt > 0 ? lcnt - 1 : 0));
+            const i32x4 GAS *src = leaf ? rec_q + 2 * (size_t)i : boxes_q + 2 * (size_t)n;
+            qa[q] = ldg(src, 0);
+            qb[q] = ldg(src, 1);
+        }
+        if (leaf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < lcnt) {
+                    const f64x2 ra = __builtin_bit_cast(f64x2, qa[q]), rb = __builtin_bit_cast(f64x2, qb[q]);
+                    const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const int rk = __double2loint(rb.y);
+                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        best_d = dd;
+                        best_rank = rk;
+                        best_pos = __double2hiint(rb.y);
                     }
-                    for (int i0 = b; i0 < e; i0 += 4) {
-                        f64x2 ra[4], rb[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int i = i0 + q < e ? i0 + q : e - 1;
-                            ra[q] = ldg(rec, 2 * i);
-                            rb[q] = ldg(rec, 2 * i + 1);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (i0 + q < e) {
-                                const double dx = ra[q].x - pt[0], dy = ra[q].y - pt[1], dz = rb[q].x - pt[2];
-                                const double dd = (dx * dx + dy * dy) + dz * dz;
-                                const int rk = __double2loint(rb[q].y);
-                                if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                                    best_d = dd;
-                                    best_rank = rk;
-                                    best_pos = __double2hiint(rb[q].y);
-                                }
-                            }
-                        }
-                    }
-                } else {
-                    const int cl = level - 1, cnx = P.py_nx[cl], cny = P.py_ny[cl], off = P.py_off[cl];
-                    float key[4];
-                    int val[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
-                        const bool in = px < cnx && py < cny;
-                        const int n = off + (in ? py * cnx + px : 0);
-                        const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);
-                        const double ex = fmax(fmax((double)lo.x - pt[0], pt[0] - (double)hi.x), 0.0);
-                        const double ey = fmax(fmax((double)lo.y - pt[1], pt[1] - (double)hi.y), 0.0);
-                        const double ez = fmax(fmax((double)lo.z - pt[2], pt[2] - (double)hi.z), 0.0);
-                        const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
-                        key[q] = (in && d2 <= best_d) ? __double2float_rd(d2) : INFINITY;
-                        val[q] = (cl << 24) | (py << 12) | px;
-                        if (cl == 0) {                   // a cell travels as its record range (the spare floats of its box)
-                            const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
-                            if (b < (1 << 22) && cnt < 512) val[q] = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
-                        }
-                    }
-                    // farthest first onto the stack, so that the nearest child is looked at next
-#pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int b2 = 0; b2 < 3 - a; ++b2)
-                            if (key[b2] < key[b2 + 1]) {
-                                const float tk = key[b2];
-                                key[b2] = key[b2 + 1];
-                                key[b2 + 1] = tk;
-                                const int tv = val[b2];
-                                val[b2] = val[b2 + 1];
-                                val[b2 + 1] = tv;
-                            }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (key[q] < INFINITY && sp < cap) {
-                            stack[sp * TREE_STRIDE] = val[q];
-                            stack[(cap + sp) * TREE_STRIDE] = __float_as_int(key[q]);
-                            ++sp;
-                        }
                 }
             }
+            if (lcnt > 4) {                              // the rest of the cell: back on the stack (the slot just left is free)
+                stack[sp * TREE_STRIDE] = (int)(0x80000000u | ((unsigned)(lcnt - 4) << 22) | (unsigned)(lb + 4));
+                stack[(cap + sp) * TREE_STRIDE] = bound_bits;
+                ++sp;
+            }
+        } else if (inner) {
+            const int cl = level - 1;
+            float key[4];
+            int val[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 lo = __builtin_bit_cast(f32x4, qa[q]), hi = __builtin_bit_cast(f32x4, qb[q]);
+                const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
+                const bool in = px < cnx && py < cny;
+                const double ex = fmax(fmax((double)lo.x - pt[0], pt[0] - (double)hi.x), 0.0);
+                const double ey = fmax(fmax((double)lo.y - pt[1], pt[1] - (double)hi.y), 0.0);
+                const double ez = fmax(fmax((double)lo.z - pt[2], pt[2] - (double)hi.z), 0.0);
+                const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
+                key[q] = (in && d2 <= best_d) ? __double2float_rd(d2) : INFINITY;
+                val[q] = (cl << 24) | (py << 12) | px;
+                if (cl == 0) {                           // a cell travels as its record range (the spare floats of its box)
+                    const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
+                    if (b < (1 << 22) && cnt < 512) val[q] = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
+                }
+            }
+            // farthest first onto the stack, so that the nearest child is looked at next
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 3 - a; ++b2)
+                    if (key[b2] < key[b2 + 1]) {
+                        const float tk = key[b2];
+                        key[b2] = key[b2 + 1];
+                        key[b2 + 1] = tk;
+                        const int tv = val[b2];
+                        val[b2] = val[b2 + 1];
+                        val[b2 + 1] = tv;
+                    }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (key[q] < INFINITY && sp < cap) {
+                    stack[sp * TREE_STRIDE] = val[q];
+                    stack[(cap + sp) * TREE_STRIDE] = __float_as_int(key[q]);
+                    ++sp;
+                }
         }
     }
-    return want ? best_pos : -1;
+#ifdef PRL_CONE_TRACE
+    CONE_HIST(3, trips_ / 2);
+    CONE_TIME_END(4);
+#endif
+    return want ? (over ? -2 : best_pos) : -1;
 }
 
 // What is left of a hit point's query after three rings of the fine grid: the tree walk, or (a part without the box
-// pyramid) one wave-wide search per point.  `stack` / `cap` / TREE_STRIDE as nearest_sample_tree wants them.
+// pyramid, a walk that gave up) one wave-wide search per point.  `stack` / `cap` / TREE_STRIDE as nearest_sample_tree wants them.
 template <int TREE_STRIDE>
 __device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3], int lane, int &sidx, int *stack, int cap) {
-    const bool need = sidx == -2;
-    if (ballot64(need) == 0) return;
+    if (ballot64(sidx == -2) == 0) return;
     if (P.py_levels > 0) {
-        const int s2 = nearest_sample_tree<TREE_STRIDE>(P, pt, need, stack, cap);
-        if (need) sidx = s2;
-        return;
+        const int s2 = nearest_sample_tree<TREE_STRIDE>(P, pt, sidx == -2, stack, cap);
+        if (sidx == -2) sidx = s2;
     }
-    uint64_t rest = ballot64(need);
+    uint64_t rest = ballot64(sidx == -2);               // no pyramid, or a walk that gave up
     while (rest) {
         const int L = __builtin_ctzll(rest);
         rest &= rest - 1;
