@@ -10,10 +10,10 @@
 //                       an env are independent of each other and the hardware dispatcher balances them over the chip:
 //                       with one wave per env a launch was as long as its slowest env (an env at the rim of the part, or
 //                       over a recess of it, takes several times the work of one in the middle).
-//   cone_rest_kernel    two work lists side by side: the hit points the beams kernel found centimetres to decimetres from
-//                       every sample (the hull spans windows and recesses of the part, and stands above a curved panel),
-//                       64 per wave, each lane walking the box pyramid over the samples (nearest_sample_tree); and the
-//                       few trips with a ray the walk left over, through the general searches (cone_trip).
+//   cone_rest_kernel    three work lists: the hit points the beams kernel found centimetres to decimetres from every sample
+//                       (the hull spans windows and recesses of the part, and stands above a curved panel), eight per wave
+//                       down the box pyramid over the samples (nearest_sample_bfs); the rays the walk left over, one per
+//                       wave through the wave-wide closest-hit search; and whole trips of a set that is not convex.
 //   cone_finish_kernel  (k_cone.hip, per mask width) one wave per env: the five hit lists folded shot by shot into the
 //                       coverage masks (bpw:572-577), reward, termination, observation, auto-reset.
 // The extra HBM traffic (10 MB of hit lists written and read per 4 096-env step) is 3 us at HBM speed.
@@ -25,13 +25,9 @@ namespace {
 constexpr int CONE_RAY_LIST_MAX = PRL_CONE_RAY_LIST_MAX;   // (prl_device.hpp: the host sizes the list)
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
 #ifndef PRL_REST_WGS
-#define PRL_REST_WGS 384
+#define PRL_REST_WGS 1024
 #endif
-// Workgroups of the rest kernel per role, grid-stride over their lists, the roles interleaved (even / odd workgroups): with
-// the lanes' tree stacks in LDS (47 KB a workgroup on the door) a CU holds three workgroups, the chip 768 -- a larger grid
-// queues behind itself and the second role would only start when the first is through (2 x 1024: 100 us, of waves that
-// take 20-40 us each).
-constexpr int REST_WGS = PRL_REST_WGS, FAR_WGS = PRL_REST_WGS;
+constexpr int REST_WGS = PRL_REST_WGS;   // workgroups of the rest kernel, grid-stride over its lists: what the chip holds at once (four a CU)
 
 template <bool KD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
@@ -164,31 +160,28 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     CONE_TIME_END(2);
 }
 
-// The hit points the beams kernel could not settle within three rings of the fine grid, 64 per wave whatever trip, shot
-// and env they come from: every lane runs the block search at the radius its own cell asks for (prl_cone.hpp
-// nearest_sample_lane<true>: 10-20 cells over the window of a door, where a lane of the beams kernel would drag the 60
-// settled lanes of its trip through as many rows).
-// What the beams kernel left, in ONE launch (the two lists are short and their items long chains of dependent reads: side
-// by side they take as long as the slower of the two):
-//   workgroups [0, FAR_WGS): the hit points three rings of the fine grid did not settle, 64 per wave whatever trip, shot
-//     and env they come from -- every lane walks the box pyramid over the samples for its own point (prl_cone.hpp
-//     nearest_sample_tree);
-//   workgroups [FAR_WGS, FAR_WGS + REST_WGS): the trips with a ray the walk left over, one per wave, through the general
-//     code (prl_cone.hpp cone_trip).
-// Dynamic LDS: the lanes' tree stacks, 2 x tree_cap ints each.
-__global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) {
-    extern __shared__ int s_tree[];
+// What the beams kernel left, in ONE launch; every wave takes its share of the three lists in turn (they are short, and their
+// items chains of dependent reads: what counts is that every item finds a wave at once):
+//   the far list   hit points three rings of the fine grid did not settle, whatever trip, shot and env they come from:
+//                  eight per wave, eight lanes each, level by level down the box pyramid over the samples (prl_cone.hpp
+//                  nearest_sample_bfs);
+//   the trip list  trips with more leftover rays than the ray list takes (a collision set that is not convex: every trip),
+//                  one per wave, through the general code (prl_cone.hpp cone_trip);
+//   the ray list   single leftover rays, one per wave: the wave-wide closest-hit search of the tool's own ray, then the
+//                  nearest sample of its hit point.
+__global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
+    __shared__ int s_bfs[4 * BFS_LDS_INTS];
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
-    int *stack = s_tree + threadIdx.x;                                  // entry k of this lane: stack[256 k]
-    const int role_wg = rfl(blockIdx.x >> 1);
-    if ((blockIdx.x & 1) == 0) {
+    int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
+    const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * REST_WGS;
+    {
         int n_far = rfl(a.cone_work[1]);
         n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);  // (entries beyond the capacity went to the trip list)
-        for (int i0 = rfl(role_wg * 4 + (threadIdx.x >> 6)) * 64; i0 < n_far; i0 += 64 * 4 * FAR_WGS) {
+        for (int i0 = wave * 8; i0 < n_far; i0 += 8 * n_waves) {
             CONE_TIME_BEGIN();
-            const bool in = i0 + lane < n_far;
-            const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + lane : i0);
+            const bool in = i0 + (lane >> 3) < n_far;
+            const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + (lane >> 3) : i0);
             const f64x2 e0 = e[0], e1 = e[1];
             const double pt[3] = {e0.x, e0.y, e1.x};
             const int dest = __double2loint(e1.y), part = __double2hiint(e1.y);
@@ -199,17 +192,15 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
                 const bool mine = have && part == p;
                 todo &= ~ballot64(mine);
                 PartRef P = *(const PartDev CAS *)(a.parts + p);
-                int sidx = mine ? -2 : -1;
-                nearest_sample_far<256>(P, pt, lane, sidx, stack, tree_cap);
-                if (mine) a.cone_hits[dest] = sidx;
+                const int sidx = nearest_sample_groups(P, pt, mine, lane, fr);
+                if (mine && (lane & 7) == 0) a.cone_hits[dest] = sidx;
             }
             CONE_TIME_END(0);
         }
-        return;
     }
     const WaveLds wl = wave_lds<false, false>();
     const int n_work = rfl(a.cone_work[0]);
-    for (int i = rfl(role_wg * 4 + (threadIdx.x >> 6)); i < n_work; i += 4 * REST_WGS) {
+    for (int i = wave; i < n_work; i += n_waves) {
         const int item = rfl(a.cone_work[4 + i]);
         int env, shot, b0;
         if (!beam_item(a, item, env, shot, b0)) continue;
@@ -219,15 +210,13 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
         const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
         const double quat[4] = {uni_d(sh[3]), uni_d(sh[4]), uni_d(sh[5]), uni_d(sh[6])};
         const int hint = rfl(__double2loint(sh[7]));
-        const int sidx = cone_trip<256>(P, pos, quat, b0, (hint >= 0 && hint < P.n_col_pad) ? hint : -1, lane, wl.cand, stack, tree_cap);
+        const int sidx = cone_trip(P, pos, quat, b0, (hint >= 0 && hint < P.n_col_pad) ? hint : -1, lane, wl.cand, fr);
         if (b0 + lane < P.n_beams) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane] = sidx;
         CONE_TIME_END(1);
     }
-    // the ray list: one leftover ray per wave -- the wave-wide closest-hit search of the tool's own ray, then the nearest
-    // sample of its hit point (every lane the same query; lane 0's answer counts)
     const int n_rays = rfl(a.cone_work[3]);
     const int *rays = ray_list(a);
-    for (int i = rfl(role_wg * 4 + (threadIdx.x >> 6)); i < n_rays; i += 4 * REST_WGS) {
+    for (int i = wave; i < n_rays; i += n_waves) {
         const int entry = rfl(rays[i]);
         const int item = entry >> 6, L = entry & 63;
         int env, shot, b0;
@@ -246,9 +235,8 @@ __global__ __launch_bounds__(256) void cone_rest_kernel(StepArgs, int tree_cap) 
         if (!beam_outside_outline_wave(P, pos, dst, lane)) {
             double tw, hw[3];
             if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
-                sidx = nearest_sample_lane_f32(P, hw, true);
-                if (lane != 0) sidx = -1;
-                nearest_sample_far<256>(P, hw, lane, sidx, stack, tree_cap);
+                sidx = nearest_sample_lane_f32(P, hw, true);            // (every lane the same query)
+                if (sidx == -2) sidx = nearest_sample_groups(P, hw, lane < 8, lane, fr);
             }
         }
         if (lane == 0) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
@@ -278,12 +266,7 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
-    const size_t lds = sizeof(int) * 2 * 256 * (size_t)a.cone_tree_cap;
-    if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cone_rest_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(cone_rest_kernel, dim3(FAR_WGS + REST_WGS), dim3(256), lds, s, a, a.cone_tree_cap);
+    hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 

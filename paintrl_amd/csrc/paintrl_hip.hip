@@ -96,7 +96,7 @@ struct PrlBatch {
     int *cone_hits = nullptr, *cone_work = nullptr;
     double *cone_far = nullptr;
     int32_t *scratch_action = nullptr;    // prl_rollout_fragment's launch-by-launch path: the bootstrap pass's discarded draw
-    int cone_nb = 0, cone_tree_cap = 0;
+    int cone_nb = 0;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
@@ -680,7 +680,6 @@ StepArgs base_args(PrlBatch *b) {
     a.cone_work = b->cone_work;
     a.cone_far = b->cone_far;
     a.cone_nb = b->cone_nb;
-    a.cone_tree_cap = b->cone_tree_cap;
     return a;
 }
 
@@ -834,7 +833,6 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess && cfg->paint_method == PRL_PAINT_NORMAL) {
         // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
         b->cone_nb = ((b->max_beams + 63) / 64) * 64;
-        for (int i = 0; i < n_parts; ++i) b->cone_tree_cap = std::max(b->cone_tree_cap, 3 * parts[i]->dev.py_levels + 2);      // = tree_stack_cap
         const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
         e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);

@@ -15,7 +15,7 @@
 //     is searched by the general code: cone_rays_lanes, for the rest kernel.
 //   * nearest samples: one hit point per lane on the fine sample grid -- nearest_sample_lane_f32 (float records, the
 //     contenders confirmed in float64) in the beams kernel, nearest_sample_lane (float64 records) in the general code; hit
-//     points three rings of cells do not settle walk the box pyramid (nearest_sample_tree): exact at any distance.
+//     points three rings of cells do not settle go down the box pyramid (nearest_sample_bfs): exact at any distance.
 #pragma once
 
 namespace {
@@ -35,7 +35,7 @@ __device__ unsigned long long g_cone_stat[32];
 #endif
 // wave times (s_memrealtime ticks of 10 ns) as a histogram: slot k / 3 (0 far-list, 1 trip-list waves of the rest
 // kernel, 2 beams kernel), bucket = floor(log2(ticks)); ONE atomic per wave
-__device__ unsigned long long g_cone_hist[5 * 32];      // [3]: tree-walk loop trips per wave / 2, [4]: time of a tree walk
+__device__ unsigned long long g_cone_hist[5 * 32];
 #define CONE_TIME_BEGIN() const unsigned long long cone_t0_ = __builtin_amdgcn_s_memrealtime()
 #define CONE_TIME_END(k)                                                             \
     do {                                                                             \
@@ -400,7 +400,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 // A sample outside the block is more than r cells away in the principal plane: the best of the block is the answer
 // once it lies within r * 0.99 * cell; a block whose best does not settle the query names the radius that will.  Returns
 // the device position of the sample, -1 if not `want`, or -2 if three rings do not settle it (a hit point centimetres off
-// the sampled surface): the caller asks nearest_sample_tree.
+// the sampled surface): the caller asks nearest_sample_far.
 __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3], bool want) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
@@ -612,25 +612,46 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
 // ---------------------------------------------------------------- nearest sample by branch and bound (any distance)
 // The same query where the ring argument has no grip: the collision hull spans the windows and recesses of a part, and
 // stands decimetres above a curved panel, so a hit point can lie 3 - 30 cm from the nearest sample; a block of cells
-// whose radius reaches that far holds thousands of samples.  Here every lane walks the box pyramid over the fine grid
-// (PartDev::py_*) depth first, nearest child first: a node is visited only if the distance from the point to its
-// bounding box (boxes rounded outward, so never more than to any sample inside) does not exceed the best found so far;
-// the samples of a cell are measured as in nearest_sample_lane (float64, equal distances to the lowest reference index).
-// ~10 node visits and a handful of cells per query whatever the distance; a cell goes on the stack as its record range
-// (sign bit | count << 22 | first record: one dependent read less per cell).  `stack`: 2 x cap ints per lane in LDS (this
-// lane's column: stack[k * TREE_STRIDE]), cap >= tree_stack_cap(levels): a visit takes one entry off and puts at most four
-// on.  Returns the device position of the sample; -1 if not `want` or the part has no pyramid.
-__host__ __device__ constexpr int tree_stack_cap(int levels) { return 3 * levels + 2; }
-template <int TREE_STRIDE>
-__device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3], bool want, int *stack, int cap) {
-    if (P.py_levels <= 0) return -1;
+// whose radius reaches that far holds thousands of samples.  The box pyramid over the fine grid (PartDev::py_*) answers
+// at any distance: only nodes whose bounding box (rounded outward, so never farther than any sample inside) lies within
+// the best distance known are opened; the samples of the cells that remain are measured as in nearest_sample_lane
+// (float64, equal distances to the lowest reference index).
+//
+// EIGHT LANES PER POINT, level by level (eight points a wave, group g = lanes 8 g .. 8 g + 7).  The walk of a point is a
+// chain of dependent reads and a lone wave issues an instruction every five cycles, so what counts is the number of
+// steps, not the lanes they keep busy: a depth-first walk with one point per lane took 20 loop trips of ~1.7 us for
+// the slowest of its 64 lanes (rest kernel 84 us); level by level a point takes one trip per level:
+//   * the first bound is a sample of the point's own cell column, or of the nearest column that has one (fg_seed);
+//   * per level, the lanes of the group share the children of the group's open nodes (its FRONTIER, in LDS); a child
+//     within the bound joins the next frontier; the farthest corner of a child that holds samples is a bound too
+//     (there is a sample at least that near), taken from the next level on;
+//   * the cells that remain carry their record range in the spare floats of their box; the lanes share them and the
+//     group's best is reduced over its lanes.
+// `fr`: the wave's 2 x 8 x BFS_CAP ints of LDS.  A frontier that outgrows BFS_CAP gives up: -2, the caller asks
+// nearest_sample_wave (exact as well).  Returns (in every lane of the group) the device position of the sample; -1 if not
+// `want`.
+constexpr int BFS_CAP = 32;
+constexpr int BFS_LDS_INTS = 2 * 8 * BFS_CAP;
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double group8_min(double v) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3], bool want, int lane, int *fr) {
+    if (P.py_levels <= 0) return want ? -2 : -1;
+    const int g = lane >> 3, m = lane & 7;
+    int *cur = fr + g * BFS_CAP, *nxt = fr + (8 + g) * BFS_CAP;
     const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.py_box);
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     double best_d = INFINITY;
-    int best_rank = 0x7fffffff, best_pos = -1, sp = 0;
+    int best_rank = 0x7fffffff, best_pos = -1;
     if (want) {
-        // the first bound: a sample of the point's own cell column, or of the nearest column that has one (fg_seed).  The
-        // walk below then never descends into a node farther than that -- a dozen visits instead of forty.
         int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
         int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
         cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
@@ -640,165 +661,163 @@ __device__ __forceinline__ int nearest_sample_tree(PartRef P, const double pt[3]
             const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
             const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd == dd) {                              // (a NaN point finds nothing, as before)
+            if (dd == dd) {                              // (a NaN point finds nothing)
                 best_d = dd;
                 best_rank = __double2loint(rb.y);
                 best_pos = __double2hiint(rb.y);
             }
         }
     }
-    if (want) {                                          // the root: level py_levels - 1 is one node
-        stack[0] = (P.py_levels - 1) << 24;
-        stack[cap * TREE_STRIDE] = 0;                    // its bound (float bits): 0
-        sp = 1;
-    }
-    // the levels' dimensions and first nodes, level k in lane k: looked up by lane permutes (a read of PartDev's arrays at a
-    // per-lane index would be one more dependent memory round trip in every node visit)
-    const int tl = (int)(threadIdx.x & 63) < PY_MAX_LEVELS ? (int)(threadIdx.x & 63) : PY_MAX_LEVELS - 1;
-    const int lv_nx = P.py_nx[tl], lv_ny = P.py_ny[tl], lv_off = P.py_off[tl];
+    double bound = best_d;
+    int nf = want ? 1 : 0;
     bool over = false;
-    const i32x4 GAS *boxes_q = reinterpret_cast<const i32x4 GAS *>(P.py_box), *rec_q = reinterpret_cast<const i32x4 GAS *>(P.fg_rec);
-#ifdef PRL_CONE_TRACE
-    int trips_ = 0;
-    CONE_TIME_BEGIN();
-#endif
-    // One trip of the loop = one batch of eight 16-byte reads per lane, whatever its entry is: the boxes of a node's four
-    // children (lo, hi) or four records of a cell (x y | z rank-pos) -- the wave waits for memory once per trip.
-    for (;;) {
-        // entries the best so far rules out come off without a trip
-        for (;;) {
-            const int top = sp > 0 ? sp - 1 : 0;
-            const bool drop = sp > 0 && (double)__int_as_float(stack[(cap + top) * TREE_STRIDE]) > best_d;
-            if (ballot64(drop) == 0) break;
-            if (drop) --sp;
+    if (want && m == 0) cur[0] = (P.py_levels - 1) << 24;            // the root (node: level << 24 | cy << 12 | cx)
+    lds_wave_sync();
+    for (int level = P.py_levels - 1; level >= 1; --level) {         // (wave-uniform: the level tables are scalar reads)
+        const int cl = level - 1, cnx = P.py_nx[cl], cny = P.py_ny[cl], off = P.py_off[cl];
+        int nn = 0;
+        double tight = INFINITY;
+        const int rounds = -wave_min_i(-((nf * 4 + 7) >> 3));
+        for (int r = 0; r < rounds; ++r) {
+            CONE_STAT(19, 1);
+            const int c = r * 8 + m;
+            const bool has = c < nf * 4;
+            const int node = cur[has ? c >> 2 : 0];
+            const int q = c & 3, px = 2 * (node & 0xfff) + (q & 1), py = 2 * ((node >> 12) & 0xfff) + (q >> 1);
+            const bool in = has && px < cnx && py < cny;
+            const int n = off + (in ? py * cnx + px : 0);
+            const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);
+            const double ax = (double)lo.x - pt[0], bx = pt[0] - (double)hi.x, ay = (double)lo.y - pt[1], by = pt[1] - (double)hi.y,
+                         az = (double)lo.z - pt[2], bz = pt[2] - (double)hi.z;
+            const double ex = fmax(fmax(ax, bx), 0.0), ey = fmax(fmax(ay, by), 0.0), ez = fmax(fmax(az, bz), 0.0);
+            const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
+            const bool keep = in && d2 <= bound;
+            if (keep && lo.x <= hi.x) {                              // the farthest corner of a box that holds samples
+                const double fx = fmax(fabs(ax), fabs(bx)), fy = fmax(fabs(ay), fabs(by)), fz = fmax(fabs(az), fabs(bz));
+                tight = fmin(tight, ((fx * fx + fy * fy) + fz * fz) * (1.0 + 1.0e-12));
+            }
+            int word = (cl << 24) | (py << 12) | px;
+            if (cl == 0) {                                           // a cell travels as its record range (sign bit | count << 22 | first)
+                const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
+                if (b < (1 << 22) && cnt < 512) word = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
+            }
+            const unsigned bits = (unsigned)(ballot64(keep) >> (8 * g)) & 0xffu;
+            const int slot = nn + __popc(bits & ((1u << m) - 1u));
+            if (keep && slot < BFS_CAP) nxt[slot] = word;
+            nn += __popc(bits);
         }
-        if (ballot64(sp > 0) == 0) break;
-        CONE_STAT(19, 1);
-#ifdef PRL_CONE_TRACE
-        ++trips_;
-#endif
-        const bool act = sp > 0;
-        const int top = act ? sp - 1 : 0;
-        int node = stack[top * TREE_STRIDE];
-        const int bound_bits = stack[(cap + top) * TREE_STRIDE];
-        if (act) --sp;
-        const int level = (node >> 24) & 15, cy = (node >> 12) & 0xfff, cx = node & 0xfff;       // (node: level << 24 | cy << 12 | cx)
-        if (act && node >= 0 && level == 0) over = true;  // a cell whose record range did not fit its entry (512 samples in a
-        if (over) sp = 0;                                 // cell, a table beyond 4 M): the caller's wave-wide search
-        const bool leaf = act && node < 0, inner = act && node >= 0 && level > 0;
-        const int lb = node & 0x3fffff, lcnt = (node >> 22) & 0x1ff;                             // a cell: first record, count
-        const int lsel = level > 0 ? (level - 1) << 2 : 0;                                       // the children's level (byte address of its lane)
-        const int cnx = __builtin_amdgcn_ds_bpermute(lsel, lv_nx), cny = __builtin_amdgcn_ds_bpermute(lsel, lv_ny),
-                  off = __builtin_amdgcn_ds_bpermute(lsel, lv_off);
-        i32x4 qa[4], qb[4];
+        over = over || nn > BFS_CAP;
+        lds_wave_sync();
+        int *t = cur;
+        cur = nxt;
+        nxt = t;
+        nf = over ? 0 : nn;
+        bound = fmin(bound, group8_min(tight));
+    }
+    // the cells that remain (a grid of one cell: the root itself), shared by the lanes of the group
+    {
+        const int rounds = -wave_min_i(-((nf + 7) >> 3));
+        for (int r = 0; r < rounds; ++r) {
+            const int c = r * 8 + m;
+            const bool has = c < nf;
+            const int word = cur[has ? c : 0];
+            int b = word & 0x3fffff, cnt = has ? (word >> 22) & 0x1ff : 0;
+            if (ballot64(has && word >= 0) != 0) {                    // (a range that did not fit its entry: looked up)
+                if (has && word >= 0) {
+                    const int cell = ((word >> 12) & 0xfff) * P.fg_nx + (word & 0xfff);
+                    b = ldg(P.fg_start, cell);
+                    cnt = ldg(P.fg_start, cell + 1) - b;
+                }
+            }
+            for (int i0 = 0; ballot64(i0 < cnt) != 0; i0 += 4) {
+                CONE_STAT(19, 1);
+                f64x2 ra[4], rb[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
-            const int n = off + ((inner && px < cnx && py < cny) ? py * cnx + px : 0);
-            const int i = lb + (q < lcnt ? q : (lcnt > 0 ? lcnt - 1 : 0));
-            const i32x4 GAS *src = leaf ? rec_q + 2 * (size_t)i : boxes_q + 2 * (size_t)n;
-            qa[q] = ldg(src, 0);
-            qb[q] = ldg(src, 1);
-        }
-        if (leaf) {
+                for (int q = 0; q < 4; ++q) {
+                    const int i = b + (i0 + q < cnt ? i0 + q : (cnt > 0 ? cnt - 1 : 0));
+                    ra[q] = ldg(rec, 2 * (cnt > 0 ? i : 0));
+                    rb[q] = ldg(rec, 2 * (cnt > 0 ? i : 0) + 1);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < lcnt) {
-                    const f64x2 ra = __builtin_bit_cast(f64x2, qa[q]), rb = __builtin_bit_cast(f64x2, qb[q]);
-                    const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    const int rk = __double2loint(rb.y);
-                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                        best_d = dd;
-                        best_rank = rk;
-                        best_pos = __double2hiint(rb.y);
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + q < cnt) {
+                        const double dx = ra[q].x - pt[0], dy = ra[q].y - pt[1], dz = rb[q].x - pt[2];
+                        const double dd = (dx * dx + dy * dy) + dz * dz;
+                        const int rk = __double2loint(rb[q].y);
+                        if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                            best_d = dd;
+                            best_rank = rk;
+                            best_pos = __double2hiint(rb[q].y);
+                        }
                     }
                 }
             }
-            if (lcnt > 4) {                              // the rest of the cell: back on the stack (the slot just left is free)
-                stack[sp * TREE_STRIDE] = (int)(0x80000000u | ((unsigned)(lcnt - 4) << 22) | (unsigned)(lb + 4));
-                stack[(cap + sp) * TREE_STRIDE] = bound_bits;
-                ++sp;
-            }
-        } else if (inner) {
-            const int cl = level - 1;
-            float key[4];
-            int val[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 lo = __builtin_bit_cast(f32x4, qa[q]), hi = __builtin_bit_cast(f32x4, qb[q]);
-                const int px = 2 * cx + (q & 1), py = 2 * cy + (q >> 1);
-                const bool in = px < cnx && py < cny;
-                const double ex = fmax(fmax((double)lo.x - pt[0], pt[0] - (double)hi.x), 0.0);
-                const double ey = fmax(fmax((double)lo.y - pt[1], pt[1] - (double)hi.y), 0.0);
-                const double ez = fmax(fmax((double)lo.z - pt[2], pt[2] - (double)hi.z), 0.0);
-                const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
-                key[q] = (in && d2 <= best_d) ? __double2float_rd(d2) : INFINITY;
-                val[q] = (cl << 24) | (py << 12) | px;
-                if (cl == 0) {                           // a cell travels as its record range (the spare floats of its box)
-                    const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
-                    if (b < (1 << 22) && cnt < 512) val[q] = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
-                }
-            }
-            // farthest first onto the stack, so that the nearest child is looked at next
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b2 = 0; b2 < 3 - a; ++b2)
-                    if (key[b2] < key[b2 + 1]) {
-                        const float tk = key[b2];
-                        key[b2] = key[b2 + 1];
-                        key[b2 + 1] = tk;
-                        const int tv = val[b2];
-                        val[b2] = val[b2 + 1];
-                        val[b2 + 1] = tv;
-                    }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (key[q] < INFINITY && sp < cap) {
-                    stack[sp * TREE_STRIDE] = val[q];
-                    stack[(cap + sp) * TREE_STRIDE] = __float_as_int(key[q]);
-                    ++sp;
-                }
         }
     }
-#ifdef PRL_CONE_TRACE
-    CONE_HIST(3, trips_ / 2);
-    CONE_TIME_END(4);
-#endif
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {                                // the group's best
+        const double od = __shfl_xor(best_d, o);
+        const int ork = __shfl_xor(best_rank, o), ops = __shfl_xor(best_pos, o);
+        if (od < best_d || (od == best_d && ork < best_rank)) {
+            best_d = od;
+            best_rank = ork;
+            best_pos = ops;
+        }
+    }
     return want ? (over ? -2 : best_pos) : -1;
 }
 
-// What is left of a hit point's query after three rings of the fine grid: the tree walk, or (a part without the box
-// pyramid, a walk that gave up) one wave-wide search per point.  `stack` / `cap` / TREE_STRIDE as nearest_sample_tree wants them.
-template <int TREE_STRIDE>
-__device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3], int lane, int &sidx, int *stack, int cap) {
-    if (ballot64(sidx == -2) == 0) return;
-    if (P.py_levels > 0) {
-        const int s2 = nearest_sample_tree<TREE_STRIDE>(P, pt, sidx == -2, stack, cap);
-        if (sidx == -2) sidx = s2;
-    }
-    uint64_t rest = ballot64(sidx == -2);               // no pyramid, or a walk that gave up
-    while (rest) {
-        const int L = __builtin_ctzll(rest);
-        rest &= rest - 1;
+// The search above for the eight points of a wave's groups, and nearest_sample_wave for a group whose frontier outgrew
+// its list (or a part without the pyramid): the position in every lane of the group.
+__device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, int lane, int *fr) {
+    int pos = nearest_sample_bfs(P, pt, want, lane, fr);
+    uint64_t ov = ballot64(want && pos == -2 && (lane & 7) == 0);
+    while (ov) {
+        const int L = __builtin_ctzll(ov);
+        ov &= ov - 1;
         const double h3[3] = {bcast_d(pt[0], L), bcast_d(pt[1], L), bcast_d(pt[2], L)};
         const int s2 = nearest_sample_wave(P, h3, lane);
-        if (lane == L) sidx = s2;
+        if ((lane >> 3) == (L >> 3)) pos = s2;
+    }
+    return pos;
+}
+
+// What is left of the hit points of a wave's lanes (one per lane, sidx == -2) after three rings of the fine grid: eight
+// of them at a time through nearest_sample_groups.
+__device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3], int lane, int &sidx, int *fr) {
+    uint64_t rest = ballot64(sidx == -2);
+    const int g = lane >> 3;
+    while (rest) {
+        uint64_t t = rest;
+        int src = -1;                                                // the g-th of the lanes left is this group's
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int L = t ? (int)__builtin_ctzll(t) : -1;
+            src = k == g ? L : src;
+            t &= t - 1;                                              // (0 stays 0)
+        }
+        const uint64_t taken = rest & ~t;
+        rest = t;
+        const bool want = src >= 0;
+        const int s = want ? src : 0;
+        const double q3[3] = {__shfl(pt[0], s), __shfl(pt[1], s), __shfl(pt[2], s)};
+        const int pos = nearest_sample_groups(P, q3, want, lane, fr);
+        const bool me = (taken >> lane) & 1;
+        const int got = __shfl(pos, me ? 8 * (int)__popcll(taken & ((1ull << lane) - 1)) : 0);
+        if (me) sidx = got;
     }
 }
 
 // One trip of a shot: the beams b0 + lane of the cone at tool pose (pos, quat) -- the device position of the sample each
 // lane's beam paints (bpw:562-566: the sample nearest to the hit point), or -1 (no such beam, or it misses the part).
-// The general code: whatever the walk leaves over is searched (cone_rays_lanes), whatever the rings do not settle is
-// walked down the tree.
-template <int TREE_STRIDE>
+// The general code: whatever the walk leaves over is searched (cone_rays_lanes), whatever the rings do not settle goes
+// down the box pyramid (`fr`: the wave's LDS for nearest_sample_bfs).
 __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                         int *cand_lds, int *stack, int cap) {
+                                         int *cand_lds, int *fr) {
     double bh[3];
     const bool hit = cone_rays_lanes(P, pos, quat, b0, hint, lane, cand_lds, bh);
     int sidx = nearest_sample_lane(P, bh, hit);
-    nearest_sample_far<TREE_STRIDE>(P, bh, lane, sidx, stack, cap);
+    nearest_sample_far(P, bh, lane, sidx, fr);
     return sidx;
 }
 

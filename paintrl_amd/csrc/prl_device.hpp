@@ -68,7 +68,7 @@ struct PartDev {
     // box pyramid over the fine grid (derived in part_fill): level 0 = the cells, level l = 2^l x 2^l of them; a node is the
     // bounding box of its samples as 8 floats (lo x y z, -, hi x y z, -; rounded outward; empty: lo = +inf, hi = -inf; the
     // spare floats of a CELL hold its record range fg_start[c], fg_start[c + 1] as int bits).
-    // nearest_sample_tree walks it branch and bound: exact nearest samples of points centimetres to decimetres from the
+    // nearest_sample_bfs walks it branch and bound: exact nearest samples of points centimetres to decimetres from the
     // sampled surface (the collision hull spans windows and recesses of the part), where a ring of cells has no grip.
     int py_levels;                // 0: no pyramid
     int py_off[PY_MAX_LEVELS], py_nx[PY_MAX_LEVELS], py_ny[PY_MAX_LEVELS];      // first node / dimensions of each level
@@ -166,7 +166,6 @@ struct StepArgs {
     int *cone_work;               // [0] = number of beam trips handed to the general search, [1] = number of hit points handed
                                   // to the far search, [2] = capacity of cone_far, [4 ..] = the trips' ids
     double *cone_far;             // [capacity][4]: hit point x y z | {i32 index into cone_hits, i32 part id}
-    int cone_tree_cap;            // stack entries per lane of the far kernel's tree walks (tree_stack_cap of the deepest pyramid)
     int cone_nb;                  // beams per shot, padded to 64 (the largest beam count of the batch's parts)
 };
 

@@ -60,11 +60,9 @@ def main():
         h = out[32 + 32 * k:64 + 32 * k].astype(np.int64)
         print('  %s: %.3f per env-step; by time (us, lower edge of the bucket: waves per launch)' % (nm, h.sum() / (steps * n)))
         print('     ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
-    h = out[32 + 96:32 + 128].astype(np.int64)
-    print('  tree walks by loop trips of the wave (trips: walks per launch): ' + '  '.join('%d: %.0f' % (2 * b, h[b] / steps) for b in range(32) if h[b]))
-    h = out[32 + 128:32 + 160].astype(np.int64)
-    print('  tree walks by time (us: walks per launch): ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
-    print('  tree-walk loop trips per far-list wave %.1f' % (out[19] / max(out[16] + out[20], 1)))
+    waves = out[32:64].astype(np.int64).sum()
+    if out[19]:
+        print('  pyramid rounds (levels and cell batches) per far-list wave: %.1f' % (out[19] / max(waves, 1)))
     print('  mean walk loop trips per beam trip %.2f, mean steps per walked beam %.2f' % (out[13] / max(out[0], 1), out[15] / max(out[1], 1)))
 
 
