@@ -1,7 +1,8 @@
 // k_cone_beams.hip -- PAINT_METHOD 'normal' (rob:251-285 + bpw:562-566): every sub-shot casts the part's cone beams
 // (104-140 rays on the reference's parts) from the tool and paints the sample nearest to each hit.
 //
-// A batched step is FOUR launches on the caller's stream, handing over through HBM buffers of the batch:
+// A batched step is FIVE launches, handing over through HBM buffers of the batch (on the caller's stream; cone_far_kernel on
+// a side stream of the batch, between two events):
 //   cone_path_kernel    one wave per env: the five sub-shots of the tool (prl_step.hpp sub_shot: ray, hook point); the
 //                       five tool poses go to cone_shots.  The tool path of a step does not depend on what the beams paint.
 //   cone_beams_kernel   one wave per beam TRIP (env, shot, 64 beams), one beam per lane: walk over the hull, nearest
@@ -25,9 +26,13 @@ namespace {
 constexpr int CONE_RAY_LIST_MAX = PRL_CONE_RAY_LIST_MAX;   // (prl_device.hpp: the host sizes the list)
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
 #ifndef PRL_REST_WGS
-#define PRL_REST_WGS 1024
+#define PRL_REST_WGS 512
 #endif
-constexpr int REST_WGS = PRL_REST_WGS;   // workgroups of the rest kernel, grid-stride over its lists: what the chip holds at once (four a CU)
+#ifndef PRL_FAR_WGS
+#define PRL_FAR_WGS 2048
+#endif
+constexpr int FAR_WGS = PRL_FAR_WGS;     // workgroups of the far kernel, grid-stride over the far list: what the chip holds at once
+constexpr int REST_WGS = PRL_REST_WGS;   // workgroups of the rest kernel, grid-stride over its lists
 
 template <bool KD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     const double pos[3] = {sh[0], sh[1], sh[2]}, quat[4] = {sh[3], sh[4], sh[5], sh[6]};
     int state, sidx;
     double bh[3];
-    cone_trip_fast(P, pos, quat, b0, lane, state, bh, sidx);
+    float far_bound;
+    cone_trip_fast(P, pos, quat, b0, lane, state, bh, sidx, far_bound);
     const int dest = (env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane;
     const uint64_t far = ballot64(sidx == -2), left = ballot64(state == 3);
     int far_base = 0;
@@ -153,51 +159,63 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
         const int slot = far_base + (int)__popcll(far & ((1ull << lane) - 1));
         f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * (size_t)slot;
         e[0] = f64x2{bh[0], bh[1]};
-        e[1] = f64x2{bh[2], __hiloint2double(part_id, dest)};
+        e[1] = f64x2{bh[2], __hiloint2double(__float_as_int(far_bound), dest)};       // (bound on the squared distance | where the answer goes)
     } else if (state != 3 && b0 + lane < P.n_beams) {
         a.cone_hits[dest] = sidx;
     }
     CONE_TIME_END(2);
 }
 
-// What the beams kernel left, in ONE launch; every wave takes its share of the three lists in turn (they are short, and their
-// items chains of dependent reads: what counts is that every item finds a wave at once):
-//   the far list   hit points three rings of the fine grid did not settle, whatever trip, shot and env they come from:
-//                  eight per wave, eight lanes each, level by level down the box pyramid over the samples (prl_cone.hpp
-//                  nearest_sample_bfs);
-//   the trip list  trips with more leftover rays than the ray list takes (a collision set that is not convex: every trip),
-//                  one per wave, through the general code (prl_cone.hpp cone_trip);
-//   the ray list   single leftover rays, one per wave: the wave-wide closest-hit search of the tool's own ray, then the
-//                  nearest sample of its hit point.
+// What the beams kernel left: three work lists, short, their items chains of dependent reads -- what counts is that every
+// item finds a wave at once.  TWO kernels, launched side by side on two streams (prl_kc_beams):
+//   cone_far_kernel   the far list: hit points three rings of the fine grid did not settle, whatever trip, shot and env they
+//                     come from: eight per wave, eight lanes each, level by level down the box pyramid over the samples
+//                     (prl_cone.hpp nearest_sample_bfs).  Few registers: eight waves a SIMD, every entry of a 4 096-env step
+//                     has its wave at once;
+//   cone_rest_kernel  the ray list: single leftover rays, one per wave: the wave-wide closest-hit search of the tool's own
+//                     ray, then the nearest sample of its hit point; and the trip list: trips with more leftover rays than
+//                     the ray list takes (a collision set that is not convex: every trip), one per wave, through the
+//                     general code (prl_cone.hpp cone_trip).
+#ifndef PRL_FAR_OCC
+#define PRL_FAR_OCC 8
+#endif
+__global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
+    __shared__ int s_bfs[4 * BFS_LDS_INTS];
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
+    const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
+    int n_far = rfl(a.cone_work[1]);
+    n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);      // (entries beyond the capacity went to the trip list)
+    for (int i0 = wave * 8; i0 < n_far; i0 += 8 * n_waves) {
+        CONE_TIME_BEGIN();
+        const bool in = i0 + (lane >> 3) < n_far;
+        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + (lane >> 3) : i0);
+        const f64x2 e0 = e[0], e1 = e[1];
+        const double pt[3] = {e0.x, e0.y, e1.x};
+        const int dest = __double2loint(e1.y);
+        const float hint = __int_as_float(__double2hiint(e1.y));
+        const bool have = in && dest >= 0;                               // (void entries: see cone_beams_kernel)
+        const int part = (have && a.env_part) ? a.env_part[dest / (PAINT_PER_ACTION * a.cone_nb)] : 0;
+        uint64_t todo = ballot64(have);
+        while (todo) {                                                   // (one trip unless the batch mixes parts)
+            const int p = __builtin_amdgcn_readlane(part, __builtin_ctzll(todo));
+            const bool mine = have && part == p;
+            todo &= ~ballot64(mine);
+            PartRef P = *(const PartDev CAS *)(a.parts + p);
+            const int sidx = nearest_sample_groups(P, pt, mine, hint, lane, fr);
+            if (mine && (lane & 7) == 0) a.cone_hits[dest] = sidx;
+        }
+        CONE_TIME_END(0);
+    }
+}
+
 __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
     __shared__ int s_bfs[4 * BFS_LDS_INTS];
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
     const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * REST_WGS;
-    {
-        int n_far = rfl(a.cone_work[1]);
-        n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);  // (entries beyond the capacity went to the trip list)
-        for (int i0 = wave * 8; i0 < n_far; i0 += 8 * n_waves) {
-            CONE_TIME_BEGIN();
-            const bool in = i0 + (lane >> 3) < n_far;
-            const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + (lane >> 3) : i0);
-            const f64x2 e0 = e[0], e1 = e[1];
-            const double pt[3] = {e0.x, e0.y, e1.x};
-            const int dest = __double2loint(e1.y), part = __double2hiint(e1.y);
-            const bool have = in && dest >= 0;                           // (void entries: see cone_beams_kernel)
-            uint64_t todo = ballot64(have);
-            while (todo) {                                               // (one trip unless the batch mixes parts)
-                const int p = __builtin_amdgcn_readlane(part, __builtin_ctzll(todo));
-                const bool mine = have && part == p;
-                todo &= ~ballot64(mine);
-                PartRef P = *(const PartDev CAS *)(a.parts + p);
-                const int sidx = nearest_sample_groups(P, pt, mine, lane, fr);
-                if (mine && (lane & 7) == 0) a.cone_hits[dest] = sidx;
-            }
-            CONE_TIME_END(0);
-        }
-    }
     const WaveLds wl = wave_lds<false, false>();
     const int n_work = rfl(a.cone_work[0]);
     for (int i = wave; i < n_work; i += n_waves) {
@@ -235,8 +253,9 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
         if (!beam_outside_outline_wave(P, pos, dst, lane)) {
             double tw, hw[3];
             if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
-                sidx = nearest_sample_lane_f32(P, hw, true);            // (every lane the same query)
-                if (sidx == -2) sidx = nearest_sample_groups(P, hw, lane < 8, lane, fr);
+                float hint;
+                sidx = nearest_sample_lane_f32(P, hw, true, hint);      // (every lane the same query)
+                if (sidx == -2) sidx = nearest_sample_groups(P, hw, lane < 8, hint, lane, fr);
             }
         }
         if (lane == 0) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
@@ -261,12 +280,21 @@ PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream
     return (int)hipGetLastError();
 }
 
-PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
+// beams, then the far kernel on the batch's side stream next to the rest kernel on the caller's (fork and join by events:
+// both are chains of dependent reads on a few thousand waves -- side by side they take as long as the longer one)
+PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream, void *side_stream, void *fork_event, void *join_event) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = static_cast<hipStream_t>(stream), side = static_cast<hipStream_t>(side_stream);
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
+    hipError_t e = hipEventRecord(static_cast<hipEvent_t>(fork_event), s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, static_cast<hipEvent_t>(fork_event), 0);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS), dim3(256), 0, side, a);
+    e = hipEventRecord(static_cast<hipEvent_t>(join_event), side);
     hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(join_event), 0);
+    if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }
 

@@ -97,6 +97,8 @@ struct PrlBatch {
     double *cone_far = nullptr;
     int32_t *scratch_action = nullptr;    // prl_rollout_fragment's launch-by-launch path: the bootstrap pass's discarded draw
     int cone_nb = 0;
+    hipStream_t cone_side = nullptr;                 // the far kernel's stream, forked from and joined to the caller's by the two events
+    hipEvent_t cone_fork = nullptr, cone_join = nullptr;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
@@ -483,23 +485,53 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_nx = nx;
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
-        {   // a sample near every cell (its own first record, or that of the nearest cell with samples, breadth first over
-            // the eight neighbours) and how many rings of cells away that cell is (fg_seed = ring count << 24 | record)
-            std::vector<int> seed((size_t)nx * ny, -1), gap((size_t)nx * ny, 0), queue;
-            queue.reserve(seed.size());
+        {   // fg_seed = ring count << 24 | record.  Ring count: how many rings of cells away the nearest cell with samples is
+            // (breadth first over the eight neighbours: exact).  Record: the sample nearest to the cell's centre in the
+            // principal plane -- of the cell itself, or of the nearest cell with samples (two raster sweeps that hand the
+            // nearest source cell from neighbour to neighbour: nearest but for rare ties in the sweep order; any sample is a
+            // correct first bound, a near one a tight one)
+            std::vector<int> gap((size_t)nx * ny, -1), queue, src((size_t)nx * ny, -1);
+            queue.reserve(gap.size());
             for (int c = 0; c < nx * ny; ++c)
-                if (start[c + 1] > start[c]) seed[c] = start[c], queue.push_back(c);
+                if (start[c + 1] > start[c]) gap[c] = 0, src[c] = c, queue.push_back(c);
             for (size_t h = 0; h < queue.size(); ++h) {
                 const int c = queue[h], cx = c % nx, cy = c / nx;
                 for (int dy = -1; dy <= 1; ++dy)
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int x = cx + dx, y = cy + dy;
-                        if (x < 0 || x >= nx || y < 0 || y >= ny || seed[y * nx + x] >= 0) continue;
-                        seed[y * nx + x] = seed[c], gap[y * nx + x] = gap[c] + 1, queue.push_back(y * nx + x);
+                        if (x < 0 || x >= nx || y < 0 || y >= ny || gap[y * nx + x] >= 0) continue;
+                        gap[y * nx + x] = gap[c] + 1, queue.push_back(y * nx + x);
                     }
             }
-            for (size_t c = 0; c < seed.size(); ++c)            // (a table beyond 16 M samples: no seeds)
-                seed[c] = real.size() < ((size_t)1 << 24) ? (seed[c] & 0xffffff) | (std::min(gap[c], 127) << 24) : -1;
+            auto dist2 = [&](int c, int s) {
+                const long long dx = c % nx - s % nx, dy = c / nx - s / nx;
+                return dx * dx + dy * dy;
+            };
+            auto relax = [&](int c, int x, int y) {
+                if (x < 0 || x >= nx || y < 0 || y >= ny) return;
+                const int s = src[y * nx + x];
+                if (s >= 0 && (src[c] < 0 || dist2(c, s) < dist2(c, src[c]))) src[c] = s;
+            };
+            for (int y = 0; y < ny; ++y) {
+                for (int x = 0; x < nx; ++x) relax(y * nx + x, x - 1, y), relax(y * nx + x, x, y - 1), relax(y * nx + x, x - 1, y - 1), relax(y * nx + x, x + 1, y - 1);
+                for (int x = nx - 1; x >= 0; --x) relax(y * nx + x, x + 1, y);
+            }
+            for (int y = ny - 1; y >= 0; --y) {
+                for (int x = nx - 1; x >= 0; --x) relax(y * nx + x, x + 1, y), relax(y * nx + x, x, y + 1), relax(y * nx + x, x + 1, y + 1), relax(y * nx + x, x - 1, y + 1);
+                for (int x = 0; x < nx; ++x) relax(y * nx + x, x - 1, y);
+            }
+            std::vector<int> seed((size_t)nx * ny, -1);
+            for (int c = 0; c < nx * ny; ++c) {
+                if (src[c] < 0 || real.size() >= ((size_t)1 << 24)) continue;      // (no sample at all; a table beyond 16 M samples: no seeds)
+                const double m1 = lo1 + (c % nx + 0.5) * cell, m2 = lo2 + (c / nx + 0.5) * cell;
+                double best = INFINITY;
+                int pick = start[src[c]];
+                for (int i = start[src[c]]; i < start[src[c] + 1]; ++i) {
+                    const double d1 = rec[(size_t)i * 4 + d.a1] - m1, d2 = rec[(size_t)i * 4 + d.a2] - m2;
+                    if (d1 * d1 + d2 * d2 < best) best = d1 * d1 + d2 * d2, pick = i;
+                }
+                seed[c] = pick | (std::min(gap[c], 127) << 24);
+            }
             UP(fg_seed, seed.data(), seed.size());
         }
         UP(fg_rec, rec.data(), rec.size());
@@ -834,7 +866,10 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
         b->cone_nb = ((b->max_beams + 63) / 64) * 64;
         const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
-        e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
+        e = hipStreamCreateWithFlags(&b->cone_side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->cone_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->cone_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_hits), sizeof(int) * PAINT_PER_ACTION * (size_t)b->cone_nb * n_envs);
         // counters, the trip list (every trip fits) and the ray list (PRL_CONE_RAY_LIST_MAX rays per trip at most, as
@@ -883,6 +918,9 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
+    if (b->cone_side) (void)hipStreamDestroy(b->cone_side);
+    if (b->cone_fork) (void)hipEventDestroy(b->cone_fork);
+    if (b->cone_join) (void)hipEventDestroy(b->cone_join);
     (void)hipFree(b->cone_shots);
     (void)hipFree(b->cone_aux);
     (void)hipFree(b->cone_hits);
@@ -945,7 +983,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     int e;
     if (normal) {                                  // tool path, beams, the beams' leftovers, fold + finish (k_cone_beams.hip)
         e = prl_kc_path(&a, sel.kd, sel.wide, stream);
-        if (!e) e = prl_kc_beams(&a, stream);
+        if (!e) e = prl_kc_beams(&a, stream, b->cone_side, b->cone_fork, b->cone_join);
         if (!e) e = PRL_KW_SWITCH(b->kw, cone)(&a, &sel, stream);
     } else {
         e = PRL_KW_SWITCH(b->kw, step)(&a, &sel, stream);

@@ -500,7 +500,8 @@ __device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int b_ro
     pos = __double2hiint(rb.y);
 }
 
-__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want) {
+__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want, float &far_bound) {
+    far_bound = INFINITY;                                             // -2: the squared distance of a sample found on the way, rounded up
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
     const double f1 = (h1 - P.fg_o1) * P.fg_inv - (double)icx, f2 = (h2 - P.fg_o2) * P.fg_inv - (double)icy;   // place in the cell
@@ -592,6 +593,7 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
             }
         }
         const double lim = reach * P.fg_accept;
+        if (open && best_pos >= 0) far_bound = fminf(far_bound, __double2float_ru(best_d));
         if (open && (c3 || wide)) {
             open = false;                                            // three the float distances cannot order: the tree decides
         } else if (open && best_pos >= 0 && best_d <= lim * lim) {
@@ -637,13 +639,13 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ double group8_min(double v) {
+__device__ __forceinline__ float group8_min(float v) {
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) v = fmin(v, __shfl_xor(v, o));
+    for (int o = 1; o < 8; o <<= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
 }
 
-__device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3], bool want, int lane, int *fr) {
+__device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
     if (P.py_levels <= 0) return want ? -2 : -1;
     const int g = lane >> 3, m = lane & 7;
     int *cur = fr + g * BFS_CAP, *nxt = fr + (8 + g) * BFS_CAP;
@@ -651,33 +653,53 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     double best_d = INFINITY;
     int best_rank = 0x7fffffff, best_pos = -1;
-    if (want) {
-        int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
-        int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
-        cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
-        cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
-        const int sd = ldg(P.fg_seed, cy * P.fg_nx + cx), i = sd & 0xffffff;
-        if (sd >= 0) {
-            const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
-            const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
-            const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd == dd) {                              // (a NaN point finds nothing)
-                best_d = dd;
-                best_rank = __double2loint(rb.y);
-                best_pos = __double2hiint(rb.y);
+    // the first bound: `hint` (the caller has seen a sample at that squared distance), or a sample of the point's own cell
+    // column, or of the nearest column that has one (fg_seed)
+    if (ballot64(want && !(hint < INFINITY)) != 0) {
+        if (want && !(hint < INFINITY)) {
+            int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
+            int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
+            cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
+            cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
+            const int sd = ldg(P.fg_seed, cy * P.fg_nx + cx), i = sd & 0xffffff;
+            if (sd >= 0) {
+                const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
+                const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                if (dd == dd) {                          // (a NaN point finds nothing)
+                    best_d = dd;
+                    best_rank = __double2loint(rb.y);
+                    best_pos = __double2hiint(rb.y);
+                }
             }
         }
     }
-    double bound = best_d;
-    int nf = want ? 1 : 0;
+    double bound = hint < INFINITY ? (double)hint : best_d;
     bool over = false;
-    if (want && m == 0) cur[0] = (P.py_levels - 1) << 24;            // the root (node: level << 24 | cy << 12 | cx)
+#ifdef PRL_CONE_TRACE
+    int rounds_ = 0, widest_ = 0;
+#endif
+    // the levels' dimensions and first nodes, level k in lane k, read once: a level's own are lane reads at a wave-uniform index
+    const int tl = lane < PY_MAX_LEVELS ? lane : PY_MAX_LEVELS - 1;
+    const int lv_nx = P.py_nx[tl], lv_ny = P.py_ny[tl], lv_off = P.py_off[tl];
+    // the walk starts with ALL nodes of the highest level that has no more than eight (the levels above it: 1 .. 8 nodes,
+    // a round trip each for nothing), node k in lane k of the group
+    int top = P.py_levels - 1;
+    while (top > 0 && P.py_nx[top - 1] * P.py_ny[top - 1] <= 8) --top;
+    const int top_nx = __builtin_amdgcn_readlane(lv_nx, top), top_n = top_nx * __builtin_amdgcn_readlane(lv_ny, top);
+    int nf = want ? top_n : 0;
+    if (want && m < top_n) cur[m] = (top << 24) | ((m / top_nx) << 12) | (m % top_nx);      // (node: level << 24 | cy << 12 | cx)
     lds_wave_sync();
-    for (int level = P.py_levels - 1; level >= 1; --level) {         // (wave-uniform: the level tables are scalar reads)
-        const int cl = level - 1, cnx = P.py_nx[cl], cny = P.py_ny[cl], off = P.py_off[cl];
+    for (int level = top; level >= 1; --level) {                     // (wave-uniform)
+        const int cl = level - 1, cnx = __builtin_amdgcn_readlane(lv_nx, cl), cny = __builtin_amdgcn_readlane(lv_ny, cl),
+                  off = __builtin_amdgcn_readlane(lv_off, cl);
         int nn = 0;
-        double tight = INFINITY;
+        float tight = INFINITY;
         const int rounds = -wave_min_i(-((nf * 4 + 7) >> 3));
+#ifdef PRL_CONE_TRACE
+        rounds_ += rounds;
+        widest_ = widest_ > nf ? widest_ : nf;
+#endif
         for (int r = 0; r < rounds; ++r) {
             CONE_STAT(19, 1);
             const int c = r * 8 + m;
@@ -694,7 +716,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
             const bool keep = in && d2 <= bound;
             if (keep && lo.x <= hi.x) {                              // the farthest corner of a box that holds samples
                 const double fx = fmax(fabs(ax), fabs(bx)), fy = fmax(fabs(ay), fabs(by)), fz = fmax(fabs(az), fabs(bz));
-                tight = fmin(tight, ((fx * fx + fy * fy) + fz * fz) * (1.0 + 1.0e-12));
+                tight = fminf(tight, __double2float_ru((fx * fx + fy * fy) + fz * fz));
             }
             int word = (cl << 24) | (py << 12) | px;
             if (cl == 0) {                                           // a cell travels as its record range (sign bit | count << 22 | first)
@@ -712,9 +734,14 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
         cur = nxt;
         nxt = t;
         nf = over ? 0 : nn;
-        bound = fmin(bound, group8_min(tight));
+        bound = fmin(bound, (double)group8_min(tight));
     }
-    // the cells that remain (a grid of one cell: the root itself), shared by the lanes of the group
+#ifdef PRL_CONE_TRACE
+    CONE_HIST(3, rounds_);                               // rounds of the levels, widest frontier (cells included) of the wave
+    widest_ = -wave_min_i(-(widest_ > nf ? widest_ : nf));
+    CONE_HIST(4, (int)__popcll(ballot64(want && !(hint < INFINITY))) / 8 + 10 * (widest_ >= 12));     // searches without a hint; + 10: a wide wave
+#endif
+    // the cells that remain (a grid of no more than eight cells: all of them), shared by the lanes of the group
     {
         const int rounds = -wave_min_i(-((nf + 7) >> 3));
         for (int r = 0; r < rounds; ++r) {
@@ -764,13 +791,13 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
             best_pos = ops;
         }
     }
-    return want ? (over ? -2 : best_pos) : -1;
+    return want ? ((over || (best_pos < 0 && hint < INFINITY)) ? -2 : best_pos) : -1;       // (a hint that found nothing: never, but exact anyway)
 }
 
 // The search above for the eight points of a wave's groups, and nearest_sample_wave for a group whose frontier outgrew
 // its list (or a part without the pyramid): the position in every lane of the group.
-__device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, int lane, int *fr) {
-    int pos = nearest_sample_bfs(P, pt, want, lane, fr);
+__device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
+    int pos = nearest_sample_bfs(P, pt, want, hint, lane, fr);
     uint64_t ov = ballot64(want && pos == -2 && (lane & 7) == 0);
     while (ov) {
         const int L = __builtin_ctzll(ov);
@@ -801,7 +828,7 @@ __device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3]
         const bool want = src >= 0;
         const int s = want ? src : 0;
         const double q3[3] = {__shfl(pt[0], s), __shfl(pt[1], s), __shfl(pt[2], s)};
-        const int pos = nearest_sample_groups(P, q3, want, lane, fr);
+        const int pos = nearest_sample_groups(P, q3, want, INFINITY, lane, fr);
         const bool me = (taken >> lane) & 1;
         const int got = __shfl(pos, me ? 8 * (int)__popcll(taken & ((1ull << lane) - 1)) : 0);
         if (me) sidx = got;
@@ -824,9 +851,11 @@ __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const d
 // The common case of cone_trip alone, for the beams kernel (k_cone_beams.hip): walk + the fine grid's three rings, nothing
 // wave-wide and nothing long.  Per lane: `state` as cone_walk_lanes returns it (3: a ray the walk left over), `bh` the
 // hit point if state = 1, `sidx` as cone_trip returns it where the lane is settled, or -2: a hit point centimetres from
-// every sample (the collision hull spans a hole or a recess of the part there).
+// every sample (the collision hull spans a hole or a recess of the part there) -- `far_bound` then bounds its squared
+// distance to the nearest sample from above (a sample the rings did see), or is +inf.
 __device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], const double quat[4], int b0, int lane,
-                                               int &state, double bh[3], int &sidx) {
+                                               int &state, double bh[3], int &sidx, float &far_bound) {
+    far_bound = INFINITY;
     double dst[3], t;
     state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
 #ifdef PRL_FORCE_GENERAL_RAY                          // diagnostic build: every trip through the rest kernel's general code
@@ -838,7 +867,7 @@ __device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], c
 #ifdef PRL_CONE_F64_RECORDS                           // (A/B switch: the float64 records in the beams kernel too)
     sidx = nearest_sample_lane(P, bh, state == 1);
 #else
-    sidx = nearest_sample_lane_f32(P, bh, state == 1);
+    sidx = nearest_sample_lane_f32(P, bh, state == 1, far_bound);
 #endif
     CONE_STAT(0, 1);
     CONE_STAT(11, __popcll(ballot64(sidx == -2)));
