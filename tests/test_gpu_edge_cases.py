@@ -385,3 +385,51 @@ def test_small_textures_use_the_one_and_two_slot_kernels(tex, kw_slots, obs_mode
         assert np.array_equal(bits[e], orc.painted_bits(e))
         assert np.array_equal(st['pose'][e], orc.state(e)['pose'])
     env.close()
+
+
+def test_cone_beam_step_on_a_side_stream_and_in_a_graph():
+    """PAINT_METHOD 'normal' forks its far kernel onto a stream of the batch and joins it again (k_cone_beams.hip): a step
+    issued on a non-default stream, and one captured into a graph and replayed, give what direct stepping gives."""
+    import torch
+    tables = synthetic_tables('door_test')
+    n, steps = 96, 6
+    rng = np.random.RandomState(77)
+    acts = torch.from_numpy(rng.randint(0, 4, size=(steps, n)).astype(np.int32)).cuda()
+    start = np.arange(n) % 4
+
+    def run(mode):
+        env = _env(tables, n, paint_method='normal', auto_reset=True, seed=11)
+        env.reset(start_idx=start)
+        out = []
+        if mode == 'direct':
+            for k in range(steps):
+                env.step_raw(acts[k])
+                out.append((env.obs.clone(), env.reward.clone(), env.done_u8.clone()))
+        elif mode == 'stream':
+            torch.cuda.synchronize()
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for k in range(steps):
+                    env.step_raw(acts[k])
+                    out.append((env.obs.clone(), env.reward.clone(), env.done_u8.clone()))
+            s.synchronize()
+        else:
+            cur = torch.zeros(n, dtype=torch.int32, device='cuda')
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()                  # (a step allocates nothing: no warm-up needed)
+            with torch.cuda.graph(g):
+                env.step_raw(cur)
+            for k in range(steps):
+                cur.copy_(acts[k])
+                g.replay()
+                out.append((env.obs.clone(), env.reward.clone(), env.done_u8.clone()))
+        torch.cuda.synchronize()
+        env.close()
+        return out
+
+    ref = run('direct')
+    for mode in ('stream', 'graph'):
+        got = run(mode)
+        for k in range(steps):
+            for x, y in zip(ref[k], got[k]):
+                assert torch.equal(x, y), (mode, k)
