@@ -1,4 +1,4 @@
-// k_cone.hip -- PAINT_METHOD 'normal': the last of a cone-beam step's four launches (k_cone_beams.hip describes all of
+// k_cone.hip -- PAINT_METHOD 'normal': the last of a cone-beam step's five launches (k_cone_beams.hip describes all of
 // them).  Compiled once per mask width (-DPRL_KW=1..4), see prl_launch.hpp.
 //
 // cone_finish_kernel, one wave per env: the five hit lists the beams kernels left in cone_hits are folded shot by shot

@@ -1,8 +1,7 @@
 // k_cone_beams.hip -- PAINT_METHOD 'normal' (rob:251-285 + bpw:562-566): every sub-shot casts the part's cone beams
 // (104-140 rays on the reference's parts) from the tool and paints the sample nearest to each hit.
 //
-// A batched step is FIVE launches, handing over through HBM buffers of the batch (on the caller's stream; cone_far_kernel on
-// a side stream of the batch, between two events):
+// A batched step is FIVE launches on the caller's stream, handing over through HBM buffers of the batch:
 //   cone_path_kernel    one wave per env: the five sub-shots of the tool (prl_step.hpp sub_shot: ray, hook point); the
 //                       five tool poses go to cone_shots.  The tool path of a step does not depend on what the beams paint.
 //   cone_beams_kernel   one wave per beam TRIP (env, shot, 64 beams), one beam per lane: walk over the hull, nearest
@@ -23,7 +22,6 @@
 
 namespace {
 
-constexpr int CONE_RAY_LIST_MAX = PRL_CONE_RAY_LIST_MAX;   // (prl_device.hpp: the host sizes the list)
 constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
 #ifndef PRL_REST_WGS
 #define PRL_REST_WGS 512
@@ -34,15 +32,77 @@ constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of th
 constexpr int FAR_WGS = PRL_FAR_WGS;     // workgroups of the far kernel, grid-stride over the far list: what the chip holds at once
 constexpr int REST_WGS = PRL_REST_WGS;   // workgroups of the rest kernel, grid-stride over its lists
 
+// The work lists the beams kernel fills (StepArgs::cone_work, cone_far).  Every trip with a far hit point or a leftover ray
+// reserves its entries with an atomic add that returns; on ONE counter those ~20 000 adds a step, from eight XCDs, queue
+// up behind each other (75 of the beams kernel's 207 us).  So the far list and the ray list are WORK_LISTS sub-lists each,
+// chosen by workgroup, with counters on cache lines of their own:
+//   cone_work: [0] trips in the trip list, [2] capacity of a far sub-list, then the trip list (capacity: every trip), the
+//   ray sub-lists (item << 6 | lane, last facet of the walk; capacity: prl_cone_ray_sub_cap), the far counters, the ray counters
+//   (one every 16 ints); cone_far: WORK_LISTS x capacity entries of 32 bytes.
+// The kernels that empty them map work chunks (eight far entries, one ray) to sub-lists by a prefix sum over the counters
+// (SubLists).
+constexpr int WORK_LISTS = PRL_CONE_WORK_LISTS;      // (prl_device.hpp: the host sizes the lists)
+__device__ __forceinline__ int cone_items(const StepArgs CAS &a) { return a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6); }
+__device__ __forceinline__ int ray_sub_cap(const StepArgs CAS &a) {
+    return prl_cone_ray_sub_cap(cone_items(a));
+}
+__device__ __forceinline__ int *ray_list(const StepArgs CAS &a) { return a.cone_work + 4 + (size_t)cone_items(a); }
+__device__ __forceinline__ int *far_counters(const StepArgs CAS &a) { return ray_list(a) + 2 * (size_t)WORK_LISTS * ray_sub_cap(a); }
+__device__ __forceinline__ int *ray_counters(const StepArgs CAS &a) { return far_counters(a) + 16 * WORK_LISTS; }
+
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// the chunks of `unit` entries of the WORK_LISTS sub-lists in one numbering: lane l holds sub-lists 4 l .. 4 l + 3
+struct SubLists {
+    int c[4], incl, excl, total, unit;
+    __device__ __forceinline__ void load(const int *counters, int cap, int unit_, int lane) {
+        static_assert(WORK_LISTS == 256, "four sub-lists a lane");
+        unit = unit_;
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = counters[16 * (4 * lane + k)];
+            c[k] = n < cap ? n : cap;                     // (reservations beyond the capacity went to the trip list)
+            mine += (c[k] + unit - 1) / unit;
+        }
+        incl = wave_scan_incl(mine, lane);
+        excl = incl - mine;
+        total = __builtin_amdgcn_readlane(incl, 63);
+    }
+    // chunk (wave-uniform, < total) -> its sub-list, its number within it, the sub-list's entry count
+    __device__ __forceinline__ void find(int chunk, int &sub, int &j, int &count) const {
+        const int L = (int)__builtin_ctzll(ballot64(chunk < incl));
+        int rem = chunk - __builtin_amdgcn_readlane(excl, L), k = 0;
+        const int c0 = __builtin_amdgcn_readlane(c[0], L), c1 = __builtin_amdgcn_readlane(c[1], L), c2 = __builtin_amdgcn_readlane(c[2], L),
+                  c3 = __builtin_amdgcn_readlane(c[3], L);
+        const int h0 = (c0 + unit - 1) / unit, h1 = (c1 + unit - 1) / unit, h2 = (c2 + unit - 1) / unit;
+        if (rem >= h0) {
+            rem -= h0, k = 1;
+            if (rem >= h1) {
+                rem -= h1, k = 2;
+                if (rem >= h2) rem -= h2, k = 3;
+            }
+        }
+        sub = 4 * L + k;
+        j = rem;
+        count = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+    }
+};
+
 template <bool KD, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                             // the work lists of this step start empty
-        a.cone_work[0] = 0;
-        a.cone_work[1] = 0;
-        a.cone_work[3] = 0;
+    if (blockIdx.x == 0) {                                                 // the work lists of this step start empty
+        if (threadIdx.x == 0) a.cone_work[0] = 0;
+        for (int i = threadIdx.x; i < 2 * WORK_LISTS; i += 64 * WAVES) far_counters(a)[16 * i] = 0;      // (far, then ray counters)
     }
     if (env >= a.n_envs) return;
     const WaveLds wl = wave_lds<false, KD>();
@@ -98,12 +158,6 @@ __device__ __forceinline__ bool beam_item(const StepArgs CAS &a, int item, int &
     return env < a.n_envs;
 }
 
-// cone_work: [0] trips in the trip list, [1] entries of the far list, [2] its capacity, [3] rays in the ray list, then the
-// trip list (capacity: every trip) and the ray list (item << 6 | lane; CONE_RAY_LIST_MAX per trip at most)
-__device__ __forceinline__ int *ray_list(const StepArgs CAS &a) {
-    return a.cone_work + 4 + (size_t)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
-}
-
 #ifndef PRL_BEAM_OCC
 #define PRL_BEAM_OCC 7
 #endif
@@ -123,41 +177,59 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
     int state, sidx;
     double bh[3];
     float far_bound;
-    cone_trip_fast(P, pos, quat, b0, lane, state, bh, sidx, far_bound);
+    int last_facet;
+    cone_trip_fast(P, pos, quat, b0, lane, state, bh, sidx, far_bound, last_facet);
     const int dest = (env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane;
+#ifdef PRL_CONE_CUT_FAR                               // (timing build, wrong results: far hit points and leftover rays count as misses)
+    if (sidx == -2) sidx = -1;
+    if (state == 3) state = 2;
+#endif
     const uint64_t far = ballot64(sidx == -2), left = ballot64(state == 3);
-    int far_base = 0;
-    // rays the walk left over go to the ray list one by one (a wave each in the rest kernel: microseconds); a trip where more
-    // than half the lanes are left over (a collision set that is not convex: all of them) goes through the general code whole
-    bool redo = (int)__popcll(left) > CONE_RAY_LIST_MAX;
+    const int n_far = (int)__popcll(far), n_left = (int)__popcll(left);
+    // (sub-list by trip, scattered: the ten trips of an env that hovers over a window of the part -- every hit point far -- go to
+    // ten sub-lists)
+    const int sub = (int)(((unsigned)item * 0x9E3779B1u) >> 24) & (WORK_LISTS - 1), far_cap = a.cone_work[2], ray_cap = ray_sub_cap(a);
+    int far_base = 0, ray_base = 0;
+    bool far_reserved = false, ray_reserved = false;
+    // A collision set that is not convex leaves every ray over: such trips go through the general code whole (the trip
+    // list).  Otherwise the leftover rays go to the ray list one by one (a wave each in the rest kernel: microseconds -- the
+    // 64 rays of a tool inside the hull as 64 waves, not as one wave's joint search of 50 us), the far hit points to the
+    // far list; a sub-list that is full sends the trip to the trip list as well.
+    bool redo = left != 0 && !P.col_convex;
+    CONE_STAT(17, redo);
     if (!redo && far) {
-        // hit points far from every sample: one entry each in the far list (the far role takes 64 of them per wave)
-        if (lane == 0) far_base = atomicAdd(a.cone_work + 1, (int)__popcll(far));
+        if (lane == 0) far_base = atomicAdd(far_counters(a) + 16 * sub, n_far);
         far_base = rfl(far_base);
-        redo = far_base + (int)__popcll(far) > a.cone_work[2];          // the list is full: the general code settles them too
+        far_reserved = true;
+        redo = far_base + n_far > far_cap;
+        CONE_STAT(14, redo);
+    }
+    if (!redo && left) {
+        if (lane == 0) ray_base = atomicAdd(ray_counters(a) + 16 * sub, n_left);
+        ray_base = rfl(ray_base);
+        ray_reserved = true;
+        redo = ray_base + n_left > ray_cap;
+        CONE_STAT(16, redo);
     }
     if (redo) {
         CONE_STAT(12, 1);
         if (lane == 0) a.cone_work[4 + atomicAdd(a.cone_work, 1)] = item;
-        // a reservation that ran over the end of the far list: the entries of it that do lie inside are marked void (the
-        // far role of cone_rest_kernel walks the list up to its capacity)
-        if (far && (int)__popcll(left) <= CONE_RAY_LIST_MAX) {
-            const int slot = far_base + lane;
-            if (lane < (int)__popcll(far) && slot < a.cone_work[2])
-                reinterpret_cast<f64x2 *>(a.cone_far)[2 * (size_t)slot + 1] = f64x2{0.0, __hiloint2double(0, -1)};
-        }
+        // a reservation that ran over the end of its sub-list: the entries of it that do lie inside are marked void (the
+        // kernels that empty the lists walk a sub-list up to its capacity)
+        if (far_reserved && lane < n_far && far_base + lane < far_cap)
+            reinterpret_cast<f64x2 *>(a.cone_far)[2 * ((size_t)sub * far_cap + far_base + lane) + 1] = f64x2{0.0, __hiloint2double(0, -1)};
+        if (ray_reserved && lane < n_left && ray_base + lane < ray_cap) ray_list(a)[2 * ((size_t)sub * ray_cap + ray_base + lane)] = -1;
         CONE_TIME_END(2);
         return;
     }
-    if (left) {
-        int ray_base = 0;
-        if (lane == 0) ray_base = atomicAdd(a.cone_work + 3, (int)__popcll(left));
-        ray_base = rfl(ray_base);
-        if (state == 3) ray_list(a)[ray_base + (int)__popcll(left & ((1ull << lane) - 1))] = (item << 6) | lane;
+    if (state == 3) {                                                    // item << 6 | lane, the facet its walk gave up on
+        int *e = ray_list(a) + 2 * ((size_t)sub * ray_cap + ray_base + (int)__popcll(left & ((1ull << lane) - 1)));
+        e[0] = (item << 6) | lane;
+        e[1] = last_facet;
     }
     if (sidx == -2) {
         const int slot = far_base + (int)__popcll(far & ((1ull << lane) - 1));
-        f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * (size_t)slot;
+        f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + slot);
         e[0] = f64x2{bh[0], bh[1]};
         e[1] = f64x2{bh[2], __hiloint2double(__float_as_int(far_bound), dest)};       // (bound on the squared distance | where the answer goes)
     } else if (state != 3 && b0 + lane < P.n_beams) {
@@ -167,17 +239,19 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
 }
 
 // What the beams kernel left: three work lists, short, their items chains of dependent reads -- what counts is that every
-// item finds a wave at once.  TWO kernels, launched side by side on two streams (prl_kc_beams):
-//   cone_far_kernel   the far list: hit points three rings of the fine grid did not settle, whatever trip, shot and env they
-//                     come from: eight per wave, eight lanes each, level by level down the box pyramid over the samples
-//                     (prl_cone.hpp nearest_sample_bfs).  Few registers: eight waves a SIMD, every entry of a 4 096-env step
-//                     has its wave at once;
+// item finds a wave at once.  Two kernels, one after the other:
 //   cone_rest_kernel  the ray list: single leftover rays, one per wave: the wave-wide closest-hit search of the tool's own
-//                     ray, then the nearest sample of its hit point; and the trip list: trips with more leftover rays than
-//                     the ray list takes (a collision set that is not convex: every trip), one per wave, through the
-//                     general code (prl_cone.hpp cone_trip).
+//                     ray; a hit point that one ring of the fine grid does not settle joins the far list.  And the trip list:
+//                     trips of a collision set that is not convex (every ray left over) and trips a full sub-list turned
+//                     away, one per wave, through the general code (prl_cone.hpp cone_trip).
+//   cone_far_kernel   the far list: hit points the rings of the fine grid did not settle, whatever trip, shot and env they
+//                     come from: eight per wave, eight lanes each, level by level down the box pyramid over the samples
+//                     (prl_cone.hpp nearest_sample_bfs).  Few registers: six waves a SIMD, every entry of a 4 096-env step
+//                     has its wave at once.
+// (Side by side on two streams they took as long as the longer one plus ~25 us of fork and join; the rays' own far points
+// searched inside the rest kernel made that the longer one.)
 #ifndef PRL_FAR_OCC
-#define PRL_FAR_OCC 8
+#define PRL_FAR_OCC 6                 // (80 registers: at 8 waves a SIMD the search spills; 45 -> 40 us)
 #endif
 __global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
     __shared__ int s_bfs[4 * BFS_LDS_INTS];
@@ -185,12 +259,15 @@ __global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
     const int lane = threadIdx.x & 63;
     int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
     const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
-    int n_far = rfl(a.cone_work[1]);
-    n_far = n_far < a.cone_work[2] ? n_far : rfl(a.cone_work[2]);      // (entries beyond the capacity went to the trip list)
-    for (int i0 = wave * 8; i0 < n_far; i0 += 8 * n_waves) {
+    const int far_cap = a.cone_work[2];
+    SubLists lists;
+    lists.load(far_counters(a), far_cap, 8, lane);
+    for (int chunk = wave; chunk < lists.total; chunk += n_waves) {
         CONE_TIME_BEGIN();
-        const bool in = i0 + (lane >> 3) < n_far;
-        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * (size_t)(in ? i0 + (lane >> 3) : i0);
+        int sub, j, count;
+        lists.find(chunk, sub, j, count);
+        const bool in = 8 * j + (lane >> 3) < count;
+        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + 8 * j + (in ? lane >> 3 : 0));
         const f64x2 e0 = e[0], e1 = e[1];
         const double pt[3] = {e0.x, e0.y, e1.x};
         const int dest = __double2loint(e1.y);
@@ -232,10 +309,14 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
         if (b0 + lane < P.n_beams) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + b0 + lane] = sidx;
         CONE_TIME_END(1);
     }
-    const int n_rays = rfl(a.cone_work[3]);
+    SubLists lists;
+    lists.load(ray_counters(a), ray_sub_cap(a), 1, lane);
     const int *rays = ray_list(a);
-    for (int i = wave; i < n_rays; i += n_waves) {
-        const int entry = rfl(rays[i]);
+    for (int i = wave; i < lists.total; i += n_waves) {
+        int sub, j, count;
+        lists.find(i, sub, j, count);
+        const int entry = rfl(rays[2 * ((size_t)sub * ray_sub_cap(a) + j)]), walk_facet = rfl(rays[2 * ((size_t)sub * ray_sub_cap(a) + j) + 1]);
+        if (entry < 0) continue;                                         // (void: its trip went to the trip list)
         const int item = entry >> 6, L = entry & 63;
         int env, shot, b0;
         if (!beam_item(a, item, env, shot, b0)) continue;
@@ -244,21 +325,45 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
         const double *sh = a.cone_shots + ((size_t)env * PAINT_PER_ACTION + shot) * 8;
         const double pos[3] = {uni_d(sh[0]), uni_d(sh[1]), uni_d(sh[2])};
         const double quat[4] = {uni_d(sh[3]), uni_d(sh[4]), uni_d(sh[5]), uni_d(sh[6])};
-        int hint = rfl(__double2loint(sh[7]));
+        int hint = walk_facet >= 0 ? walk_facet : rfl(__double2loint(sh[7]));       // where the ray's walk ended, or the tool's own facet
         hint = (hint >= 0 && hint < P.n_col_pad) ? hint : -1;
         const int bm = b0 + L;
         double dst[3] = {pos[0], pos[1], pos[2]};
         transform_point(pos, quat, ldg(P.beams, 3 * bm), ldg(P.beams, 3 * bm + 1), ldg(P.beams, 3 * bm + 2), dst);
         int sidx = -1;
+        bool pushed = false;
         if (!beam_outside_outline_wave(P, pos, dst, lane)) {
             double tw, hw[3];
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 3
+            const unsigned long long ray_t0_ = __builtin_amdgcn_s_memrealtime();
+            const int hit_ = ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand);
+            CONE_HIST(3, 63 - __builtin_clzll((__builtin_amdgcn_s_memrealtime() - ray_t0_) | 1));
+            if (hit_ >= 0) {
+#else
             if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
+#endif
                 float hint;
-                sidx = nearest_sample_lane_f32(P, hw, true, hint);      // (every lane the same query)
-                if (sidx == -2) sidx = nearest_sample_groups(P, hw, lane < 8, hint, lane, fr);
+                sidx = nearest_sample_lane_f32(P, hw, true, hint, 1);   // (every lane the same query: one ring, then the pyramid)
+                if (sidx == -2) {
+                    // a hit point far from every sample: one more entry of the far list (the far kernel runs after this one)
+                    const int sub = blockIdx.x & (WORK_LISTS - 1), far_cap = a.cone_work[2];
+                    int slot = 0;
+                    if (lane == 0) slot = atomicAdd(far_counters(a) + 16 * sub, 1);
+                    slot = rfl(slot);
+                    if (slot < far_cap) {
+                        if (lane == 0) {
+                            f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + slot);
+                            e[0] = f64x2{hw[0], hw[1]};
+                            e[1] = f64x2{hw[2], __hiloint2double(__float_as_int(hint), (int)(((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm))};
+                        }
+                        pushed = true;
+                    } else {                                             // (the sub-list is full: searched here)
+                        sidx = nearest_sample_groups(P, hw, lane < 8, hint, lane, fr);
+                    }
+                }
             }
         }
-        if (lane == 0) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
+        if (lane == 0 && !pushed) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
         CONE_TIME_END(1);
     }
 }
@@ -280,21 +385,14 @@ PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream
     return (int)hipGetLastError();
 }
 
-// beams, then the far kernel on the batch's side stream next to the rest kernel on the caller's (fork and join by events:
-// both are chains of dependent reads on a few thousand waves -- side by side they take as long as the longer one)
-PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream, void *side_stream, void *fork_event, void *join_event) {
+// beams, the rest kernel (its rays' far hit points join the far list), the far kernel
+PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    hipStream_t s = static_cast<hipStream_t>(stream), side = static_cast<hipStream_t>(side_stream);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
-    hipError_t e = hipEventRecord(static_cast<hipEvent_t>(fork_event), s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side, static_cast<hipEvent_t>(fork_event), 0);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS), dim3(256), 0, side, a);
-    e = hipEventRecord(static_cast<hipEvent_t>(join_event), side);
     hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(join_event), 0);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -17,6 +17,9 @@
 #include <new>
 #include <vector>
 
+#ifndef PRL_HG_CELL
+#define PRL_HG_CELL 0.7            // edge of a front-facet grid cell in root mean facet areas (the walk's starting facets)
+#endif
 #ifndef PRL_FINE_CELL
 #define PRL_FINE_CELL 2.0          // edge of a fine sample-grid cell in mean sample spacings (prl_cone.hpp)
 #endif
@@ -97,8 +100,6 @@ struct PrlBatch {
     double *cone_far = nullptr;
     int32_t *scratch_action = nullptr;    // prl_rollout_fragment's launch-by-launch path: the bootstrap pass's discarded draw
     int cone_nb = 0;
-    hipStream_t cone_side = nullptr;                 // the far kernel's stream, forked from and joined to the caller's by the two events
-    hipEvent_t cone_fork = nullptr, cone_join = nullptr;
     std::vector<double *> reset_obs;   // per part: [n_start][obs_dim], see PartDev::reset_obs
     int resident_envs = 0;             // envs whose waves are all resident at once (16 per CU): see STEP_WAVES_WIDE
     double *state = nullptr;
@@ -347,8 +348,8 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             d.hg_nx = d.hg_ny = 0;
             if (n_real > 0 && hi1 > lo1 && hi2 > lo2 && t->start_pos && t->n_start > 0) {
                 const bool from_above = t->start_pos[a0] >= zsum / (3.0 * n_real);          // the tool's side of the part
-                double cell = 0.7 * std::sqrt((hi1 - lo1) * (hi2 - lo2) / (double)n_real);
-                while ((hi1 - lo1) / cell > 192 || (hi2 - lo2) / cell > 192) cell *= 1.5;
+                double cell = PRL_HG_CELL * std::sqrt((hi1 - lo1) * (hi2 - lo2) / (double)n_real);
+                while ((hi1 - lo1) / cell > 768 || (hi2 - lo2) / cell > 768) cell *= 1.5;
                 const int nx = (int)std::floor((hi1 - lo1) / cell) + 1, ny = (int)std::floor((hi2 - lo2) / cell) + 1;
                 std::vector<int32_t> g((size_t)nx * ny, -1);
                 for (int i = 0; i < d.n_col_pad; ++i) {
@@ -866,25 +867,22 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         // what the cone-beam kernels of a step hand to each other (StepArgs, k_cone_beams.hip)
         b->cone_nb = ((b->max_beams + 63) / 64) * 64;
         const size_t items = (size_t)n_envs * PAINT_PER_ACTION * (b->cone_nb / 64);
-        e = hipStreamCreateWithFlags(&b->cone_side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->cone_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->cone_join, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_shots), sizeof(double) * 8 * PAINT_PER_ACTION * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_aux), sizeof(double) * 2 * n_envs);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_hits), sizeof(int) * PAINT_PER_ACTION * (size_t)b->cone_nb * n_envs);
-        // counters, the trip list (every trip fits) and the ray list (PRL_CONE_RAY_LIST_MAX rays per trip at most, as
-        // item << 6 | lane): k_cone_beams.hip
+        // counters, the trip list (every trip fits), the ray sub-lists and the sub-lists' counters: k_cone_beams.hip
         if (items >= ((size_t)1 << 25)) {
             rc = fail(PRL_E_INVALID, "%zu beam trips per step: more than the cone-beam work lists index", items);
             prl_batch_destroy(b);
             return rc;
         }
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * ((1 + PRL_CONE_RAY_LIST_MAX) * items + 4));
-        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * ((1 + PRL_CONE_RAY_LIST_MAX) * items + 4));
-        // hit points handed to the far search: 64 per env and step (a typical step has a dozen; a full list sends the
-        // rest through the general code)
-        const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 64, 4096), (size_t)1 << 26);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_far), sizeof(double) * 4 * (size_t)far_cap);
+        const size_t work_ints = 4 + items + 2 * (size_t)PRL_CONE_WORK_LISTS * prl_cone_ray_sub_cap((int)items) + 2 * 16 * PRL_CONE_WORK_LISTS;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * work_ints);
+        if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * work_ints);
+        // hit points handed to the far search: 128 per env and step over all sub-lists (a typical step has a dozen; a full
+        // sub-list sends the rest through the general code), a sub-list at least one trip's worth
+        const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 128 / PRL_CONE_WORK_LISTS, 64), (size_t)1 << 18);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_far), sizeof(double) * 4 * (size_t)far_cap * PRL_CONE_WORK_LISTS);
         if (e == hipSuccess) e = hipMemcpy(b->cone_work + 2, &far_cap, sizeof(int), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMemset(b->painted, 0, mask_bytes);
@@ -918,9 +916,6 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
     (void)hipFree(b->thick);
-    if (b->cone_side) (void)hipStreamDestroy(b->cone_side);
-    if (b->cone_fork) (void)hipEventDestroy(b->cone_fork);
-    if (b->cone_join) (void)hipEventDestroy(b->cone_join);
     (void)hipFree(b->cone_shots);
     (void)hipFree(b->cone_aux);
     (void)hipFree(b->cone_hits);
@@ -983,7 +978,7 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     int e;
     if (normal) {                                  // tool path, beams, the beams' leftovers, fold + finish (k_cone_beams.hip)
         e = prl_kc_path(&a, sel.kd, sel.wide, stream);
-        if (!e) e = prl_kc_beams(&a, stream, b->cone_side, b->cone_fork, b->cone_join);
+        if (!e) e = prl_kc_beams(&a, stream);
         if (!e) e = PRL_KW_SWITCH(b->kw, cone)(&a, &sel, stream);
     } else {
         e = PRL_KW_SWITCH(b->kw, step)(&a, &sel, stream);

@@ -1,5 +1,5 @@
 // prl_cone.hpp -- PAINT_METHOD 'normal': the cone beams of one shot, one beam per lane (rob:251-285, bpw:562-566).
-// Device code of the cone-beam kernels (k_cone_beams.hip describes the four launches of a step); anonymous namespace.
+// Device code of the cone-beam kernels (k_cone_beams.hip describes the five launches of a step); anonymous namespace.
 // Compile with -ffp-contract=off.
 //
 // A shot casts n_beams (104-140 on the reference's parts, 450 with COLOR_MODE 'HSI') rays from the tool position to the
@@ -24,7 +24,7 @@ namespace {
 // through prl_debug_cone_stats of the k_cone_beams unit).  The product build defines none of this.
 #ifdef PRL_CONE_TRACE
 __device__ unsigned long long g_cone_stat[32];
-#if PRL_CONE_TRACE == 2                          // the wave times alone (the counters' atomics stretch them tenfold)
+#if PRL_CONE_TRACE >= 2                          // the wave times alone (the counters' atomics stretch them tenfold)
 #define CONE_STAT(k, v)
 #else
 #define CONE_STAT(k, v)                                                              \
@@ -228,7 +228,8 @@ __device__ void rays_general_lanes(PartRef P, const double o[3], const double ds
 // over the hull.  Returns the lane's state: 1 = hit at parameter t (exact closest hit of the whole set), 2 = no beam, or
 // a proven miss, 3 = not settled (the caller searches).
 __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int lane,
-                                               double dst[3], double &t) {
+                                               double dst[3], double &t, int &last_facet) {
+    last_facet = -1;                                // state 3: the facet the walk gave up on (where a search of the ray may start)
     const int bm = b0 + lane;
     const bool have = bm < P.n_beams;
     dst[0] = pos[0], dst[1] = pos[1], dst[2] = pos[2];
@@ -278,6 +279,7 @@ __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], c
         }
         CONE_STAT(10, __popcll(ballot64(state == 0)));
         if (state == 0) state = 3;
+        last_facet = f;
         CONE_STAT(2, __popcll(ballot64(state == 1)));
         CONE_STAT(3, __popcll(ballot64(state == 2 && have)));
         CONE_STAT(4, __popcll(ballot64(state == 3)));
@@ -315,23 +317,12 @@ __device__ __forceinline__ bool beam_outside_outline_wave(PartRef P, const doubl
     return false;
 }
 
-// The rays of beams b0 + lane: hit[3] of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray (where
-// the wave-wide searches of leftover rays start).
-__device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
-                                int *cand_lds, double hit[3]) {
-    const bool have = b0 + lane < P.n_beams;
-    double dst[3], t;
-    int state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
-    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
-#ifdef PRL_FORCE_GENERAL_RAY
-    if (have) state = 3;
-#endif
-    hit[0] = pos[0] + t * d0;
-    hit[1] = pos[1] + t * d1;
-    hit[2] = pos[2] + t * d2;
-    // Beams beside the part.  The collision set lies inside the slab [slab_lo, slab_hi] of the third axis and, projected
-    // to the principal plane, inside its outline polygon: if the stretch of the beam inside the slab (widened by the
-    // margin) lies, projected, more than the margin outside one edge of the outline, the beam misses every triangle.
+// Beams beside the part, one per lane (`state` 3 -> 2 where proven).  The collision set lies inside the slab [slab_lo,
+// slab_hi] of the third axis and, projected to the principal plane, inside its outline polygon: if the stretch of the beam
+// inside the slab (widened by the margin) lies, projected, more than the margin outside one edge of the outline, the beam
+// misses every triangle.
+__device__ __forceinline__ void beams_outside_outline_lanes(PartRef P, const double pos[3], double d0, double d1, double d2, int &state) {
+    const int lane = threadIdx.x & 63;
     if (P.n_outline > 0 && ballot64(state == 3) != 0) {
         const double oz = sel3(pos[0], pos[1], pos[2], P.a0), dz = sel3(d0, d1, d2, P.a0);
         const double lo = P.slab_lo - CONE_MISS_MARGIN, hi = P.slab_hi + CONE_MISS_MARGIN;
@@ -360,6 +351,24 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
         }
         if (state == 3 && clear) state = 2;
     }
+}
+
+// The rays of beams b0 + lane: hit[3] of this lane's beam, returns whether it hit.  `hint`: facet of the tool's ray (where
+// the wave-wide searches of leftover rays start).
+__device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double quat[4], int b0, int hint, int lane,
+                                int *cand_lds, double hit[3]) {
+    const bool have = b0 + lane < P.n_beams;
+    double dst[3], t;
+    int last_facet;
+    int state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t, last_facet);
+    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
+#ifdef PRL_FORCE_GENERAL_RAY
+    if (have) state = 3;
+#endif
+    hit[0] = pos[0] + t * d0;
+    hit[1] = pos[1] + t * d1;
+    hit[2] = pos[2] + t * d2;
+    beams_outside_outline_lanes(P, pos, d0, d1, d2, state);
     // the stragglers (edge and vertex hits, and every miss), together
     const uint64_t todo = ballot64(state == 3);
     if (__popcll(todo) > CONE_JOINT_FROM) {
@@ -485,6 +494,9 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+#ifndef PRL_NN_MAX_RING
+#define PRL_NN_MAX_RING 3
+#endif
 #define NN_KEY_INF 0x7f800000u                  // +inf as a key
 #define NN_KEY_PLACE 0x3ffu                     // place in the scan: row << 7 | offset in the row
 #define NN_KEY_SLACK 1.000123f                  // > 1 + 2^-13
@@ -500,7 +512,7 @@ __device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int b_ro
     pos = __double2hiint(rb.y);
 }
 
-__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want, float &far_bound) {
+__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want, float &far_bound, int max_ring = PRL_NN_MAX_RING) {
     far_bound = INFINITY;                                             // -2: the squared distance of a sample found on the way, rounded up
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
@@ -520,7 +532,7 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     const int seed = open ? ldg(P.fg_seed, gcy * P.fg_nx + gcx) : 0;
     const int gap = (seed >= 0 && icx == gcx && icy == gcy) ? seed >> 24 : 0;
     for (int pass = 0; pass < 4; ++pass) {
-        if (open && r > 3) open = false;                              // (stays -2)
+        if (open && r > max_ring) open = false;                       // (stays -2)
         if (ballot64(open) == 0) break;
         int cx0 = r ? icx - r : (f1 < 0.5 ? icx - 1 : icx), cx1 = r ? icx + r : cx0 + 1;
         int cy0 = r ? icy - r : (f2 < 0.5 ? icy - 1 : icy), cy1 = r ? icy + r : cy0 + 1;
@@ -736,7 +748,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
         nf = over ? 0 : nn;
         bound = fmin(bound, (double)group8_min(tight));
     }
-#ifdef PRL_CONE_TRACE
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE != 3
     CONE_HIST(3, rounds_);                               // rounds of the levels, widest frontier (cells included) of the wave
     widest_ = -wave_min_i(-(widest_ > nf ? widest_ : nf));
     CONE_HIST(4, (int)__popcll(ballot64(want && !(hint < INFINITY))) / 8 + 10 * (widest_ >= 12));     // searches without a hint; + 10: a wide wave
@@ -852,19 +864,24 @@ __device__ __forceinline__ int cone_trip(PartRef P, const double pos[3], const d
 // wave-wide and nothing long.  Per lane: `state` as cone_walk_lanes returns it (3: a ray the walk left over), `bh` the
 // hit point if state = 1, `sidx` as cone_trip returns it where the lane is settled, or -2: a hit point centimetres from
 // every sample (the collision hull spans a hole or a recess of the part there) -- `far_bound` then bounds its squared
-// distance to the nearest sample from above (a sample the rings did see), or is +inf.
+// distance to the nearest sample from above (a sample the rings did see), or is +inf; `last_facet` (state 3): the facet
+// the walk gave up on.
 __device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], const double quat[4], int b0, int lane,
-                                               int &state, double bh[3], int &sidx, float &far_bound) {
+                                               int &state, double bh[3], int &sidx, float &far_bound, int &last_facet) {
     far_bound = INFINITY;
     double dst[3], t;
-    state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t);
+    state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t, last_facet);
+    // what the walk left over: beams that pass beside the part are settled here (a tool that has left the part: most of them)
+    beams_outside_outline_lanes(P, pos, dst[0] - pos[0], dst[1] - pos[1], dst[2] - pos[2], state);
 #ifdef PRL_FORCE_GENERAL_RAY                          // diagnostic build: every trip through the rest kernel's general code
     if (b0 + lane < P.n_beams) state = 3;
 #endif
     bh[0] = pos[0] + t * (dst[0] - pos[0]);
     bh[1] = pos[1] + t * (dst[1] - pos[1]);
     bh[2] = pos[2] + t * (dst[2] - pos[2]);
-#ifdef PRL_CONE_F64_RECORDS                           // (A/B switch: the float64 records in the beams kernel too)
+#if defined(PRL_CONE_CUT_NN)                          // (timing build, wrong results: what the beams kernel takes without the search)
+    sidx = state == 1 ? 0 : -1;
+#elif defined(PRL_CONE_F64_RECORDS)                   // (A/B switch: the float64 records in the beams kernel too)
     sidx = nearest_sample_lane(P, bh, state == 1);
 #else
     sidx = nearest_sample_lane_f32(P, bh, state == 1, far_bound);

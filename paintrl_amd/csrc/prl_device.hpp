@@ -31,7 +31,10 @@ constexpr double SHOT_CENTRE_OFFSET = 0.1;      // rob:277-278: the shot centre 
 // a hit on this triangle makes of its normal, computed once on upload with the device's own arithmetic:
 // quat = get_pose_orn(-normal) (rob:93-100), centre_off = R(quat) (0, 0, 0.1) (rob:277-278).
 constexpr int TRI_REC = 24;
-#define PRL_CONE_RAY_LIST_MAX 32                // leftover rays of a beam trip that go to the ray list one by one (k_cone_beams.hip)
+#define PRL_CONE_WORK_LISTS 256                 // sub-lists of the far list and of the ray list (k_cone_beams.hip)
+// entries of a ray sub-list: eight leftover rays per beam trip on average and a few full trips (a step has ~0.03 per trip;
+// a full sub-list sends the trip through the general code): host and device size the list alike
+__host__ __device__ constexpr int prl_cone_ray_sub_cap(int items) { return 256 + 8 * ((items + PRL_CONE_WORK_LISTS - 1) / PRL_CONE_WORK_LISTS); }
 constexpr int PY_MAX_LEVELS = 13;               // box pyramid over the fine sample grid (PartDev::py_*): grids up to 4096 cells wide
 
 // Table pointers are read from a descriptor in memory, so the compiler cannot infer their address
@@ -163,8 +166,7 @@ struct StepArgs {
     double *cone_shots;           // [n_envs][5][8]: tool pose after each sub-shot (pos, quat) | {i32 facet hint, 0}
     double *cone_aux;             // [n_envs][2]: new turning angle | {i32 off-part counter before the step, i32 facet hint}
     int *cone_hits;               // [n_envs][5][cone_nb]: device position of the sample each beam paints, or -1
-    int *cone_work;               // [0] = number of beam trips handed to the general search, [1] = number of hit points handed
-                                  // to the far search, [2] = capacity of cone_far, [4 ..] = the trips' ids
+    int *cone_work;               // counters and work lists of a cone-beam step (k_cone_beams.hip)
     double *cone_far;             // [capacity][4]: hit point x y z | {i32 index into cone_hits, i32 part id}
     int cone_nb;                  // beams per shot, padded to 64 (the largest beam count of the batch's parts)
 };

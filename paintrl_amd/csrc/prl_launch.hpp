@@ -32,7 +32,7 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
 
 // PAINT_METHOD 'normal': the tool path and the beams of a step (k_cone_beams.hip); prl_k<KW>_cone finishes it
 PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream);
-PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream, void *side_stream, void *fork_event, void *join_event);
+PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream);
 
 PRL_K_PROTOS(0)
 PRL_K_PROTOS(1)

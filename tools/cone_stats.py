@@ -60,10 +60,14 @@ def main():
         h = out[32 + 32 * k:64 + 32 * k].astype(np.int64)
         print('  %s: %.3f per env-step; by time (us, lower edge of the bucket: waves per launch)' % (nm, h.sum() / (steps * n)))
         print('     ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
+    if os.environ.get('PRL_TRACE_RAYS'):
+        h = out[32 + 96:32 + 128].astype(np.int64)
+        print('  closest-hit search of a leftover ray, by time (us: rays per launch): ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
     for k, nm in ((3, 'rounds of the pyramid levels per wave of searches'), (4, 'searches without a hint in a wave (+ 10: frontier of 12 or more)')):
         h = out[32 + 32 * k:64 + 32 * k].astype(np.int64)
         if h.sum():
             print('  %s (value: waves per launch): ' % nm + '  '.join('%d: %.0f' % (b, h[b] / steps) for b in range(32) if h[b]))
+    print('  trips to the trip list because: far sub-list full %.4f, ray sub-list full %.4f, set not convex %.4f' % (per[14], per[16], per[17]))
     waves = out[32:64].astype(np.int64).sum()
     if out[19]:
         print('  pyramid rounds (levels and cell batches) per far-list wave: %.1f' % (out[19] / max(waves, 1)))
