@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
             if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
 #endif
                 float hint;
-                sidx = nearest_sample_lane_f32(P, hw, true, hint, 1);   // (every lane the same query: one ring, then the pyramid)
+                sidx = nearest_sample_lane_f32(P, hw, true, hint);      // (every lane the same query)
                 if (sidx == -2) {
                     // a hit point far from every sample: one more entry of the far list (the far kernel runs after this one)
                     const int sub = blockIdx.x & (WORK_LISTS - 1), far_cap = a.cone_work[2];

@@ -482,9 +482,10 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
 //    integers) with its ten low mantissa bits replaced by the record's place in the scan (row of the block, offset in
 //    the row) -- three integer min / median instructions per record instead of three compares and six selects.  A key
 //    stands for a distance in [t, t (1 + 2^-13)), t = the key with the ten bits cleared; the contender test allows for it.
-//  * the first block is the 2 x 2 cells around the point (the cell's quadrant picks them): every sample outside it is more
-//    than half a cell away, so a nearest sample within 0.5 fg_accept is final -- ~16 records instead of the ~36 of the
-//    3 x 3 block.  Then rings and the acceptance test (on the exact distance) as in nearest_sample_lane.
+//  * the block is the 2 x 2 cells around the point (the cell's quadrant picks them): every sample outside it is more than
+//    half a cell away, so a nearest sample within its reach is final -- ~16 records.  Anything else (-2) is the far
+//    kernel's, with the distance found here as its first bound: rings of cells scanned here, by one or two lanes of 64,
+//    cost the wave more than the eight-lane search there (beams 139 + far 38 us with three rings, 99 + 66 with none).
 __device__ __forceinline__ float nn_band(float d2, float E) {
     const float d = __builtin_sqrtf(d2) * 1.0001f + 1e-12f;
     return 3.5f * d * E + 3.0f * E * E + 2.4e-7f * d2 + 1e-30f;
@@ -494,9 +495,6 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-#ifndef PRL_NN_MAX_RING
-#define PRL_NN_MAX_RING 3
-#endif
 #define NN_KEY_INF 0x7f800000u                  // +inf as a key
 #define NN_KEY_PLACE 0x3ffu                     // place in the scan: row << 7 | offset in the row
 #define NN_KEY_SLACK 1.000123f                  // > 1 + 2^-13
@@ -512,8 +510,8 @@ __device__ __forceinline__ void nn_key_measure(PartRef P, unsigned key, int b_ro
     pos = __double2hiint(rb.y);
 }
 
-__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want, float &far_bound, int max_ring = PRL_NN_MAX_RING) {
-    far_bound = INFINITY;                                             // -2: the squared distance of a sample found on the way, rounded up
+__device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double pt[3], bool want, float &far_bound) {
+    far_bound = INFINITY;                                             // -2: the squared distance of a sample seen on the way, rounded up
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
     const double f1 = (h1 - P.fg_o1) * P.fg_inv - (double)icx, f2 = (h2 - P.fg_o2) * P.fg_inv - (double)icy;   // place in the cell
@@ -523,101 +521,68 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     const double mq = fmax(fmax(fabs(pt[0]), fabs(pt[1])), fmax(fabs(pt[2]), P.samp_absmax));
     const float E = (float)(mq * 1.1920929e-7 * 1.001);              // 2^-23 M, rounded up
     int result = want ? -2 : -1;
-    bool open = want && mq < 1.0e6;
-    int r = in_cell ? 0 : 1;                                          // 0: the 2 x 2 block, r >= 1: r rings
-    // how many rings of cells lie between the point's cell and the nearest cell that has samples at all (fg_seed): a
-    // search that finds its first block empty starts there -- or, beyond three rings, leaves the point to the tree at
-    // once (a hit on the hull over a window of the part)
-    const int gcx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), gcy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
-    const int seed = open ? ldg(P.fg_seed, gcy * P.fg_nx + gcx) : 0;
-    const int gap = (seed >= 0 && icx == gcx && icy == gcy) ? seed >> 24 : 0;
-    for (int pass = 0; pass < 4; ++pass) {
-        if (open && r > max_ring) open = false;                       // (stays -2)
-        if (ballot64(open) == 0) break;
-        int cx0 = r ? icx - r : (f1 < 0.5 ? icx - 1 : icx), cx1 = r ? icx + r : cx0 + 1;
-        int cy0 = r ? icy - r : (f2 < 0.5 ? icy - 1 : icy), cy1 = r ? icy + r : cy0 + 1;
-        // the block's border is this far from the point, in cells, wherever it is not the grid's own (0.5 .. 1 for the
-        // 2 x 2 block, r for r rings): every sample outside the block is farther than that
-        const double reach = r ? (double)r : fmin(fmin(f1 < 0.5 ? f1 + 1.0 : f1, f1 < 0.5 ? 1.0 - f1 : 2.0 - f1),
-                                                  fmin(f2 < 0.5 ? f2 + 1.0 : f2, f2 < 0.5 ? 1.0 - f2 : 2.0 - f2));
-        cx0 = cx0 < 0 ? 0 : cx0, cx1 = cx1 > P.fg_nx - 1 ? P.fg_nx - 1 : cx1;
-        cy0 = cy0 < 0 ? 0 : cy0, cy1 = cy1 > P.fg_ny - 1 ? P.fg_ny - 1 : cy1;
-        const int rows = (open && cx0 <= cx1 && cy0 <= cy1) ? cy1 - cy0 + 1 : 0;
-        const int nrows = -wave_min_i(-rows);                         // wave-uniform trip count, per-lane ranges
-        // the record ranges of the first two rows travel together (the 2 x 2 block has no more)
-        const int b0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx0) : 0, e0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx1 + 1) : 0;
-        const int b1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx0) : 0, e1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx1 + 1) : 0;
-        unsigned k1 = NN_KEY_INF, k2 = NN_KEY_INF, k3 = NN_KEY_INF;
-        bool wide = false;
-        for (int j = 0; j < nrows; ++j) {
-            const bool row_ok = j < rows;
-            int b = j == 0 ? b0 : b1, e = j == 0 ? e0 : e1;
-            if (j > 1) {
-                b = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx0) : 0;
-                e = row_ok ? ldg(P.fg_start, (cy0 + j) * P.fg_nx + cx1 + 1) : 0;
-            }
-            if (e - b > 128) wide = true, e = b;                      // (more than a key can place: the tree decides)
-            unsigned place = (unsigned)j << 7;
-            for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4, place += 4) {
-                const int ib = i0 < e ? i0 : b;                       // (a lane that is through stays in range)
-                f32x4 rc[4];
+    const bool open = want && mq < 1.0e6 && in_cell;
+    if (ballot64(open) == 0) return result;
+    int cx0 = f1 < 0.5 ? icx - 1 : icx, cx1 = cx0 + 1, cy0 = f2 < 0.5 ? icy - 1 : icy, cy1 = cy0 + 1;
+    // the block's border is this far from the point, in cells, wherever it is not the grid's own (0.5 .. 1): every sample
+    // outside the block is farther than that
+    const double reach = fmin(fmin(f1 < 0.5 ? f1 + 1.0 : f1, f1 < 0.5 ? 1.0 - f1 : 2.0 - f1), fmin(f2 < 0.5 ? f2 + 1.0 : f2, f2 < 0.5 ? 1.0 - f2 : 2.0 - f2));
+    cx0 = cx0 < 0 ? 0 : cx0, cx1 = cx1 > P.fg_nx - 1 ? P.fg_nx - 1 : cx1;
+    cy0 = cy0 < 0 ? 0 : cy0, cy1 = cy1 > P.fg_ny - 1 ? P.fg_ny - 1 : cy1;
+    const int rows = (open && cx0 <= cx1 && cy0 <= cy1) ? cy1 - cy0 + 1 : 0;
+    // the record ranges of the two rows travel together
+    const int b0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx0) : 0, e0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx1 + 1) : 0;
+    const int b1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx0) : 0, e1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx1 + 1) : 0;
+    unsigned k1 = NN_KEY_INF, k2 = NN_KEY_INF, k3 = NN_KEY_INF;
+    bool wide = false;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rc[q] = ldg(rec, ib + q); // (the table is padded by four records)
+    for (int j = 0; j < 2; ++j) {
+        const int b = j == 0 ? b0 : b1;
+        int e = j == 0 ? e0 : e1;
+        if (e - b > 128) wide = true, e = b;                          // (more than a key can place: the pyramid decides)
+        unsigned place = (unsigned)j << 7;
+        for (int i0 = b; ballot64(i0 < e) != 0; i0 += 4, place += 4) {
+            const int ib = i0 < e ? i0 : b;                           // (a lane that is through stays in range)
+            f32x4 rc[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float ex = rc[q].x - qx, ey = rc[q].y - qy, ez = rc[q].z - qz;
-                    const float dd = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                    const unsigned key = i0 + q < e ? ((__float_as_uint(dd) & ~NN_KEY_PLACE) | (place + q)) : NN_KEY_INF;
-                    k3 = umed3(k2, k3, key);                          // keep the three smallest (k1 <= k2 <= k3)
-                    k2 = umed3(k1, k2, key);
-                    k1 = k1 < key ? k1 : key;
-                }
+            for (int q = 0; q < 4; ++q) rc[q] = ldg(rec, ib + q);     // (the table is padded by four records)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ex = rc[q].x - qx, ey = rc[q].y - qy, ez = rc[q].z - qz;
+                const float dd = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                const unsigned key = i0 + q < e ? ((__float_as_uint(dd) & ~NN_KEY_PLACE) | (place + q)) : NN_KEY_INF;
+                k3 = umed3(k2, k3, key);                              // keep the three smallest (k1 <= k2 <= k3)
+                k2 = umed3(k1, k2, key);
+                k1 = k1 < key ? k1 : key;
             }
-        }
-        // float64 for the contenders
-        double best_d = INFINITY;
-        int best_rank = 0x7fffffff, best_pos = -1;
-        const float t1 = __uint_as_float(k1 & ~NN_KEY_PLACE) * NN_KEY_SLACK;
-        const float lim1 = t1 + nn_band(t1, E);
-        const float t2 = __uint_as_float(k2 & ~NN_KEY_PLACE), t3 = __uint_as_float(k3 & ~NN_KEY_PLACE);
-        const bool c2 = open && k2 < NN_KEY_INF && t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1;
-        const bool c3 = open && k3 < NN_KEY_INF && t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1;
-        const bool m1 = open && k1 < NN_KEY_INF, m2 = c2 && !c3;
-        if (ballot64(m1) != 0) {
-            // (rows past the second: their first record is looked up again)
-            const int row1 = (int)((k1 >> 7) & 7u), row2 = (int)((k2 >> 7) & 7u);
-            int s1 = row1 == 0 ? b0 : b1, s2 = row2 == 0 ? b0 : b1;
-            if (ballot64((m1 && row1 > 1) || (m2 && row2 > 1)) != 0) {
-                if (m1 && row1 > 1) s1 = ldg(P.fg_start, (cy0 + row1) * P.fg_nx + cx0);
-                if (m2 && row2 > 1) s2 = ldg(P.fg_start, (cy0 + row2) * P.fg_nx + cx0);
-            }
-            if (m1) nn_key_measure(P, k1, s1, pt, best_d, best_rank, best_pos);
-            if (ballot64(m2) != 0) {
-                if (m2) {
-                    double dd;
-                    int rk, ps;
-                    nn_key_measure(P, k2, s2, pt, dd, rk, ps);
-                    if (dd < best_d || (dd == best_d && rk < best_rank)) {
-                        best_d = dd;
-                        best_pos = ps;
-                    }
-                }
-            }
-        }
-        const double lim = reach * P.fg_accept;
-        if (open && best_pos >= 0) far_bound = fminf(far_bound, __double2float_ru(best_d));
-        if (open && (c3 || wide)) {
-            open = false;                                            // three the float distances cannot order: the tree decides
-        } else if (open && best_pos >= 0 && best_d <= lim * lim) {
-            result = best_pos;
-            open = false;
-        } else if (open) {
-            // the ring that will settle it: the best so far names it; an empty block asks the gap table
-            const int need = best_pos >= 0 ? (int)fmin(ceil(sqrt(best_d) / P.fg_accept), 1.0e6) : (gap > 0 ? gap : (r ? 2 * r + 2 : 1));
-            r = need > r ? need : r + 1;
         }
     }
-#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the far kernel's tree walk
+    // float64 for the contenders
+    double best_d = INFINITY;
+    int best_rank = 0x7fffffff, best_pos = -1;
+    const float t1 = __uint_as_float(k1 & ~NN_KEY_PLACE) * NN_KEY_SLACK;
+    const float lim1 = t1 + nn_band(t1, E);
+    const float t2 = __uint_as_float(k2 & ~NN_KEY_PLACE), t3 = __uint_as_float(k3 & ~NN_KEY_PLACE);
+    const bool c2 = open && k2 < NN_KEY_INF && t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1;
+    const bool c3 = open && k3 < NN_KEY_INF && t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1;
+    const bool m1 = open && k1 < NN_KEY_INF, m2 = c2 && !c3;
+    if (m1) nn_key_measure(P, k1, ((k1 >> 7) & 1u) ? b1 : b0, pt, best_d, best_rank, best_pos);
+    if (ballot64(m2) != 0) {
+        if (m2) {
+            double dd;
+            int rk, ps;
+            nn_key_measure(P, k2, ((k2 >> 7) & 1u) ? b1 : b0, pt, dd, rk, ps);
+            if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                best_d = dd;
+                best_pos = ps;
+            }
+        }
+    }
+    const double lim = reach * P.fg_accept;
+    if (open && best_pos >= 0) far_bound = __double2float_ru(best_d);
+    // three the float distances cannot order, a row beyond a key's places, a nearest sample beyond the block's reach: -2
+    if (open && !(c3 || wide) && best_pos >= 0 && best_d <= lim * lim) result = best_pos;
+#ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the far kernel's search
     if (want) result = -2;
 #endif
     return result;
@@ -871,8 +836,9 @@ __device__ __forceinline__ void cone_trip_fast(PartRef P, const double pos[3], c
     far_bound = INFINITY;
     double dst[3], t;
     state = cone_walk_lanes(P, pos, quat, b0, lane, dst, t, last_facet);
-    // what the walk left over: beams that pass beside the part are settled here (a tool that has left the part: most of them)
+#ifdef PRL_CONE_OUTLINE_IN_BEAMS                      // (A/B switch: settles 40 % of the leftover rays here; beams kernel 138 -> 144 us, rest kernel the same)
     beams_outside_outline_lanes(P, pos, dst[0] - pos[0], dst[1] - pos[1], dst[2] - pos[2], state);
+#endif
 #ifdef PRL_FORCE_GENERAL_RAY                          // diagnostic build: every trip through the rest kernel's general code
     if (b0 + lane < P.n_beams) state = 3;
 #endif
