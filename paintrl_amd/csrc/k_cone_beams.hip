@@ -261,13 +261,13 @@ __global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
     const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
     const int far_cap = a.cone_work[2];
     SubLists lists;
-    lists.load(far_counters(a), far_cap, 8, lane);
+    lists.load(far_counters(a), far_cap, BFS_N, lane);
     for (int chunk = wave; chunk < lists.total; chunk += n_waves) {
         CONE_TIME_BEGIN();
         int sub, j, count;
         lists.find(chunk, sub, j, count);
-        const bool in = 8 * j + (lane >> 3) < count;
-        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + 8 * j + (in ? lane >> 3 : 0));
+        const bool in = BFS_N * j + (lane >> BFS_SHIFT) < count;
+        const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + BFS_N * j + (in ? lane >> BFS_SHIFT : 0));
         const f64x2 e0 = e[0], e1 = e[1];
         const double pt[3] = {e0.x, e0.y, e1.x};
         const int dest = __double2loint(e1.y);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
             todo &= ~ballot64(mine);
             PartRef P = *(const PartDev CAS *)(a.parts + p);
             const int sidx = nearest_sample_groups(P, pt, mine, hint, lane, fr);
-            if (mine && (lane & 7) == 0) a.cone_hits[dest] = sidx;
+            if (mine && (lane & (BFS_G - 1)) == 0) a.cone_hits[dest] = sidx;
         }
         CONE_TIME_END(0);
     }
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
                         }
                         pushed = true;
                     } else {                                             // (the sub-list is full: searched here)
-                        sidx = nearest_sample_groups(P, hw, lane < 8, hint, lane, fr);
+                        sidx = nearest_sample_groups(P, hw, lane < BFS_G, hint, lane, fr);
                     }
                 }
             }

@@ -609,8 +609,14 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
 // `fr`: the wave's 2 x 8 x BFS_CAP ints of LDS.  A frontier that outgrows BFS_CAP gives up: -2, the caller asks
 // nearest_sample_wave (exact as well).  Returns (in every lane of the group) the device position of the sample; -1 if not
 // `want`.
+#ifndef PRL_BFS_LANES
+#define PRL_BFS_LANES 4                        // (8: far kernel 66 us, 4: 55, 2: 86)
+#endif
+constexpr int BFS_G = PRL_BFS_LANES;              // lanes a point (a power of two, at most 8), BFS_N points a wave
+constexpr int BFS_N = 64 / BFS_G;
+constexpr int BFS_SHIFT = BFS_G == 8 ? 3 : (BFS_G == 4 ? 2 : 1);
 constexpr int BFS_CAP = 32;
-constexpr int BFS_LDS_INTS = 2 * 8 * BFS_CAP;
+constexpr int BFS_LDS_INTS = 2 * BFS_N * BFS_CAP;
 __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -618,14 +624,14 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 __device__ __forceinline__ float group8_min(float v) {
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) v = fminf(v, __shfl_xor(v, o));
+    for (int o = 1; o < BFS_G; o <<= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
 }
 
 __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
     if (P.py_levels <= 0) return want ? -2 : -1;
-    const int g = lane >> 3, m = lane & 7;
-    int *cur = fr + g * BFS_CAP, *nxt = fr + (8 + g) * BFS_CAP;
+    const int g = lane >> BFS_SHIFT, m = lane & (BFS_G - 1);
+    int *cur = fr + g * BFS_CAP, *nxt = fr + (BFS_N + g) * BFS_CAP;
     const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.py_box);
     const f64x2 GAS *rec = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
     double best_d = INFINITY;
@@ -660,32 +666,32 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     const int tl = lane < PY_MAX_LEVELS ? lane : PY_MAX_LEVELS - 1;
     const int lv_nx = P.py_nx[tl], lv_ny = P.py_ny[tl], lv_off = P.py_off[tl];
     // the walk starts with ALL nodes of the highest level that has no more than eight (the levels above it: 1 .. 8 nodes,
-    // a round trip each for nothing), node k in lane k of the group
+    // a round trip each for nothing)
     int top = P.py_levels - 1;
     while (top > 0 && P.py_nx[top - 1] * P.py_ny[top - 1] <= 8) --top;
     const int top_nx = __builtin_amdgcn_readlane(lv_nx, top), top_n = top_nx * __builtin_amdgcn_readlane(lv_ny, top);
     int nf = want ? top_n : 0;
-    if (want && m < top_n) cur[m] = (top << 24) | ((m / top_nx) << 12) | (m % top_nx);      // (node: level << 24 | cy << 12 | cx)
+    for (int i = m; want && i < top_n; i += BFS_G) cur[i] = (top << 24) | ((i / top_nx) << 12) | (i % top_nx);      // (node: level << 24 | cy << 12 | cx)
     lds_wave_sync();
     for (int level = top; level >= 1; --level) {                     // (wave-uniform)
         const int cl = level - 1, cnx = __builtin_amdgcn_readlane(lv_nx, cl), cny = __builtin_amdgcn_readlane(lv_ny, cl),
                   off = __builtin_amdgcn_readlane(lv_off, cl);
         int nn = 0;
         float tight = INFINITY;
-        const int rounds = -wave_min_i(-((nf * 4 + 7) >> 3));
+        const int rounds = -wave_min_i(-((nf * 4 + BFS_G - 1) >> BFS_SHIFT));
 #ifdef PRL_CONE_TRACE
         rounds_ += rounds;
         widest_ = widest_ > nf ? widest_ : nf;
 #endif
         for (int r = 0; r < rounds; ++r) {
             CONE_STAT(19, 1);
-            const int c = r * 8 + m;
+            const int c = r * BFS_G + m;
             const bool has = c < nf * 4;
             const int node = cur[has ? c >> 2 : 0];
             const int q = c & 3, px = 2 * (node & 0xfff) + (q & 1), py = 2 * ((node >> 12) & 0xfff) + (q >> 1);
             const bool in = has && px < cnx && py < cny;
             const int n = off + (in ? py * cnx + px : 0);
-            const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);
+            const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);      // (a copy of the upper levels in LDS: no faster)
             const double ax = (double)lo.x - pt[0], bx = pt[0] - (double)hi.x, ay = (double)lo.y - pt[1], by = pt[1] - (double)hi.y,
                          az = (double)lo.z - pt[2], bz = pt[2] - (double)hi.z;
             const double ex = fmax(fmax(ax, bx), 0.0), ey = fmax(fmax(ay, by), 0.0), ez = fmax(fmax(az, bz), 0.0);
@@ -700,7 +706,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
                 const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
                 if (b < (1 << 22) && cnt < 512) word = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
             }
-            const unsigned bits = (unsigned)(ballot64(keep) >> (8 * g)) & 0xffu;
+            const unsigned bits = (unsigned)(ballot64(keep) >> (BFS_G * g)) & ((1u << BFS_G) - 1u);
             const int slot = nn + __popc(bits & ((1u << m) - 1u));
             if (keep && slot < BFS_CAP) nxt[slot] = word;
             nn += __popc(bits);
@@ -720,9 +726,9 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
 #endif
     // the cells that remain (a grid of no more than eight cells: all of them), shared by the lanes of the group
     {
-        const int rounds = -wave_min_i(-((nf + 7) >> 3));
+        const int rounds = -wave_min_i(-((nf + BFS_G - 1) >> BFS_SHIFT));
         for (int r = 0; r < rounds; ++r) {
-            const int c = r * 8 + m;
+            const int c = r * BFS_G + m;
             const bool has = c < nf;
             const int word = cur[has ? c : 0];
             int b = word & 0x3fffff, cnt = has ? (word >> 22) & 0x1ff : 0;
@@ -759,7 +765,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
         }
     }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {                                // the group's best
+    for (int o = 1; o < BFS_G; o <<= 1) {                            // the group's best
         const double od = __shfl_xor(best_d, o);
         const int ork = __shfl_xor(best_rank, o), ops = __shfl_xor(best_pos, o);
         if (od < best_d || (od == best_d && ork < best_rank)) {
@@ -775,27 +781,27 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
 // its list (or a part without the pyramid): the position in every lane of the group.
 __device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
     int pos = nearest_sample_bfs(P, pt, want, hint, lane, fr);
-    uint64_t ov = ballot64(want && pos == -2 && (lane & 7) == 0);
+    uint64_t ov = ballot64(want && pos == -2 && (lane & (BFS_G - 1)) == 0);
     while (ov) {
         const int L = __builtin_ctzll(ov);
         ov &= ov - 1;
         const double h3[3] = {bcast_d(pt[0], L), bcast_d(pt[1], L), bcast_d(pt[2], L)};
         const int s2 = nearest_sample_wave(P, h3, lane);
-        if ((lane >> 3) == (L >> 3)) pos = s2;
+        if ((lane >> BFS_SHIFT) == (L >> BFS_SHIFT)) pos = s2;
     }
     return pos;
 }
 
-// What is left of the hit points of a wave's lanes (one per lane, sidx == -2) after three rings of the fine grid: eight
+// What is left of the hit points of a wave's lanes (one per lane, sidx == -2) after the rings of the fine grid: BFS_N
 // of them at a time through nearest_sample_groups.
 __device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3], int lane, int &sidx, int *fr) {
     uint64_t rest = ballot64(sidx == -2);
-    const int g = lane >> 3;
+    const int g = lane >> BFS_SHIFT;
     while (rest) {
         uint64_t t = rest;
         int src = -1;                                                // the g-th of the lanes left is this group's
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < BFS_N; ++k) {
             const int L = t ? (int)__builtin_ctzll(t) : -1;
             src = k == g ? L : src;
             t &= t - 1;                                              // (0 stays 0)
@@ -807,7 +813,7 @@ __device__ __forceinline__ void nearest_sample_far(PartRef P, const double pt[3]
         const double q3[3] = {__shfl(pt[0], s), __shfl(pt[1], s), __shfl(pt[2], s)};
         const int pos = nearest_sample_groups(P, q3, want, INFINITY, lane, fr);
         const bool me = (taken >> lane) & 1;
-        const int got = __shfl(pos, me ? 8 * (int)__popcll(taken & ((1ull << lane) - 1)) : 0);
+        const int got = __shfl(pos, me ? BFS_G * (int)__popcll(taken & ((1ull << lane) - 1)) : 0);
         if (me) sidx = got;
     }
 }
