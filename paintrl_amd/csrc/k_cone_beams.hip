@@ -5,15 +5,17 @@
 //   cone_path_kernel    one wave per env: the five sub-shots of the tool (prl_step.hpp sub_shot: ray, hook point); the
 //                       five tool poses go to cone_shots.  The tool path of a step does not depend on what the beams paint.
 //   cone_beams_kernel   one wave per beam TRIP (env, shot, 64 beams), one beam per lane: walk over the hull, nearest
-//                       sample on the fine grid (prl_cone.hpp cone_trip_fast) -- the common case only, in few registers,
-//                       so that eight waves share a SIMD and hide each other's dependent table reads.  The 5 x 2 trips of
-//                       an env are independent of each other and the hardware dispatcher balances them over the chip:
-//                       with one wave per env a launch was as long as its slowest env (an env at the rim of the part, or
-//                       over a recess of it, takes several times the work of one in the middle).
-//   cone_rest_kernel    three work lists: the hit points the beams kernel found centimetres to decimetres from every sample
-//                       (the hull spans windows and recesses of the part, and stands above a curved panel), eight per wave
-//                       down the box pyramid over the samples (nearest_sample_bfs); the rays the walk left over, one per
-//                       wave through the wave-wide closest-hit search; and whole trips of a set that is not convex.
+//                       sample in the 2 x 2 cells of the fine grid around the hit point (prl_cone.hpp cone_trip_fast) --
+//                       the common case only, in few registers.  The 5 x 2 trips of an env are independent of each other
+//                       and the hardware dispatcher balances them over the chip: with one wave per env a launch was as
+//                       long as its slowest env (an env at the rim of the part, or over a recess of it, takes several
+//                       times the work of one in the middle).  What a lane does not settle goes to a work list.
+//   cone_rest_kernel    the rays the walk left over, one per wave through the wave-wide closest-hit search (their hit
+//                       points: the 2 x 2 cells, or the far list); whole trips of a set that is not convex.
+//   cone_far_kernel     the hit points not settled so far (8 % of the hits on the synthetic door: the hull spans windows
+//                       and recesses of the part and stands above a curved panel -- centimetres to decimetres from every
+//                       sample), sixteen per wave, four lanes each, level by level down the box pyramid over the samples
+//                       (nearest_sample_bfs).
 //   cone_finish_kernel  (k_cone.hip, per mask width) one wave per env: the five hit lists folded shot by shot into the
 //                       coverage masks (bpw:572-577), reward, termination, observation, auto-reset.
 // The extra HBM traffic (10 MB of hit lists written and read per 4 096-env step) is 3 us at HBM speed.
@@ -35,11 +37,11 @@ constexpr int REST_WGS = PRL_REST_WGS;   // workgroups of the rest kernel, grid-
 // The work lists the beams kernel fills (StepArgs::cone_work, cone_far).  Every trip with a far hit point or a leftover ray
 // reserves its entries with an atomic add that returns; on ONE counter those ~20 000 adds a step, from eight XCDs, queue
 // up behind each other (75 of the beams kernel's 207 us).  So the far list and the ray list are WORK_LISTS sub-lists each,
-// chosen by workgroup, with counters on cache lines of their own:
+// chosen by a hash of the trip, with counters on cache lines of their own:
 //   cone_work: [0] trips in the trip list, [2] capacity of a far sub-list, then the trip list (capacity: every trip), the
 //   ray sub-lists (item << 6 | lane, last facet of the walk; capacity: prl_cone_ray_sub_cap), the far counters, the ray counters
 //   (one every 16 ints); cone_far: WORK_LISTS x capacity entries of 32 bytes.
-// The kernels that empty them map work chunks (eight far entries, one ray) to sub-lists by a prefix sum over the counters
+// The kernels that empty them map work chunks (BFS_N far entries, one ray) to sub-lists by a prefix sum over the counters
 // (SubLists).
 constexpr int WORK_LISTS = PRL_CONE_WORK_LISTS;      // (prl_device.hpp: the host sizes the lists)
 __device__ __forceinline__ int cone_items(const StepArgs CAS &a) { return a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6); }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
 //                     trips of a collision set that is not convex (every ray left over) and trips a full sub-list turned
 //                     away, one per wave, through the general code (prl_cone.hpp cone_trip).
 //   cone_far_kernel   the far list: hit points the rings of the fine grid did not settle, whatever trip, shot and env they
-//                     come from: eight per wave, eight lanes each, level by level down the box pyramid over the samples
+//                     come from: BFS_N per wave, BFS_G lanes each, level by level down the box pyramid over the samples
 //                     (prl_cone.hpp nearest_sample_bfs).  Few registers: six waves a SIMD, every entry of a 4 096-env step
 //                     has its wave at once.
 // (Side by side on two streams they took as long as the longer one plus ~25 us of fork and join; the rays' own far points

@@ -13,9 +13,10 @@
 //     that reaches the hull's horizon ends with a PROVEN miss (cone_walk_step: both ends beyond a facet plane, or the
 //     silhouette-edge certificate).  What is left over (edge and vertex hits, grazing entries, walks that run out of steps)
 //     is searched by the general code: cone_rays_lanes, for the rest kernel.
-//   * nearest samples: one hit point per lane on the fine sample grid -- nearest_sample_lane_f32 (float records, the
-//     contenders confirmed in float64) in the beams kernel, nearest_sample_lane (float64 records) in the general code; hit
-//     points three rings of cells do not settle go down the box pyramid (nearest_sample_bfs): exact at any distance.
+//   * nearest samples: one hit point per lane on the fine sample grid -- nearest_sample_lane_f32 (the 2 x 2 cells around the
+//     point, float records, the contenders confirmed in float64) in the beams kernel, nearest_sample_lane (float64 records,
+//     rings of cells) in the general code; hit points these do not settle go down the box pyramid, a few lanes each
+//     (nearest_sample_bfs): exact at any distance.
 #pragma once
 
 namespace {
@@ -596,9 +597,9 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
 // the best distance known are opened; the samples of the cells that remain are measured as in nearest_sample_lane
 // (float64, equal distances to the lowest reference index).
 //
-// EIGHT LANES PER POINT, level by level (eight points a wave, group g = lanes 8 g .. 8 g + 7).  The walk of a point is a
-// chain of dependent reads and a lone wave issues an instruction every five cycles, so what counts is the number of
-// steps, not the lanes they keep busy: a depth-first walk with one point per lane took 20 loop trips of ~1.7 us for
+// BFS_G LANES PER POINT, level by level (BFS_N points a wave, group g = lanes BFS_G g .. BFS_G g + BFS_G - 1).  The walk of a
+// point is a chain of dependent reads and a lone wave issues an instruction every five cycles, so what counts is the number
+// of steps, not the lanes they keep busy: a depth-first walk with one point per lane took 20 loop trips of ~1.7 us for
 // the slowest of its 64 lanes (rest kernel 84 us); level by level a point takes one trip per level:
 //   * the first bound is a sample of the point's own cell column, or of the nearest column that has one (fg_seed);
 //   * per level, the lanes of the group share the children of the group's open nodes (its FRONTIER, in LDS); a child
@@ -606,7 +607,7 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
 //     (there is a sample at least that near), taken from the next level on;
 //   * the cells that remain carry their record range in the spare floats of their box; the lanes share them and the
 //     group's best is reduced over its lanes.
-// `fr`: the wave's 2 x 8 x BFS_CAP ints of LDS.  A frontier that outgrows BFS_CAP gives up: -2, the caller asks
+// `fr`: the wave's BFS_LDS_INTS ints of LDS.  A frontier that outgrows BFS_CAP gives up: -2, the caller asks
 // nearest_sample_wave (exact as well).  Returns (in every lane of the group) the device position of the sample; -1 if not
 // `want`.
 #ifndef PRL_BFS_LANES
