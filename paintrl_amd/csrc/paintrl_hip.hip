@@ -18,7 +18,7 @@
 #include <vector>
 
 #ifndef PRL_HG_CELL
-#define PRL_HG_CELL 0.7            // edge of a front-facet grid cell in root mean facet areas (the walk's starting facets)
+#define PRL_HG_CELL 0.25           // edge of a front-facet grid cell in root mean facet areas: the walk's starting facets (0.7: 3.7 loop trips a beam trip, 0.2: 3.0)
 #endif
 #ifndef PRL_FINE_CELL
 #define PRL_FINE_CELL 2.0          // edge of a fine sample-grid cell in mean sample spacings (prl_cone.hpp)
