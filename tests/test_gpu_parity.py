@@ -56,6 +56,8 @@ def test_gpu_replays_reference_episode(tag, name):
     ('square', dict(obs_mode='section', max_possible_point=14350)),
     ('square', dict(obs_mode='simple', n_discrete=8, max_possible_point=14350)),
     ('door_test', dict(obs_mode='section', paint_method='normal', _n=48, _steps=8)),
+    # the cone beams' work lists at a realistic fill (256 sub-lists each of the far list and the ray list: k_cone_beams.hip)
+    ('door_test', dict(obs_mode='section', paint_method='normal', _n=1536, _steps=12)),
     ('square', dict(obs_mode='grid', paint_method='normal', overlap_penalty=True, max_possible_point=14350, _n=32,
                     _steps=6)),
 ])
