@@ -302,11 +302,13 @@ def main():
             if not args.mixed else None
         if scratch is not None:
             scratch.reset()
-            a0 = actions[0][:scratch.n_envs].contiguous()
+            # (the timed run's own action rows, cycled: the pre-warm launches do the work the timed ones do, so that a
+            # rocprofv3 average over the whole process is the timed kernels' average)
+            rows = actions if scratch.n_envs == args.envs else actions[:, :scratch.n_envs].contiguous()
             t_end = time.perf_counter() + PREWARM_SECONDS
             while time.perf_counter() < t_end:
-                for _ in range(50):
-                    scratch.step_raw(a0)
+                for k in range(50):
+                    scratch.step_raw(rows[(prewarm_steps + k) % total])
                 prewarm_steps += 50
                 torch.cuda.synchronize(device)
             scratch.close()
