@@ -39,6 +39,18 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
     const int *hits = a.cone_hits + (size_t)env * PAINT_PER_ACTION * a.cone_nb;
     uint32_t n_succeeded_l = 0;
     double succ_l = 0.0;                                              // HSI: this lane's share of the deposited fractions
+    // the five shots' hit lists are read together, ahead of the loop that folds them one after the other (up to 192 beams:
+    // three a lane; five dependent round trips otherwise)
+    constexpr int PRE = 3;
+    const bool prefetched = !HSI && (a.cone_nb >> 6) <= PRE;
+    int pre[PAINT_PER_ACTION][PRE];
+    if (prefetched) {
+#pragma unroll
+        for (int shot = 0; shot < PAINT_PER_ACTION; ++shot)
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) pre[shot][q] = 64 * q + lane < P.n_beams ? hits[shot * a.cone_nb + 64 * q + lane] : -1;
+    }
+#pragma unroll
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
         // bpw:562-566 + 572-577: the samples this shot's beams hit are its "affected" set; no hit at all: the
         // reference returns early and leaves the last-shot set untouched (rob:283-285)
@@ -117,10 +129,19 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int beam_hits = 0;
-            for (int b = 0; b < P.n_beams; b += 64) {
-                const int sidx = b + lane < P.n_beams ? hits[shot * a.cone_nb + b + lane] : -1;
-                if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), 1ull << (sidx & 63));
-                beam_hits += __popcll(ballot64(sidx >= 0));
+            if (prefetched) {
+#pragma unroll
+                for (int q = 0; q < PRE; ++q) {
+                    const int sidx = pre[shot][q];
+                    if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), 1ull << (sidx & 63));
+                    beam_hits += __popcll(ballot64(sidx >= 0));
+                }
+            } else {
+                for (int b = 0; b < P.n_beams; b += 64) {
+                    const int sidx = b + lane < P.n_beams ? hits[shot * a.cone_nb + b + lane] : -1;
+                    if (sidx >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), 1ull << (sidx & 63));
+                    beam_hits += __popcll(ballot64(sidx >= 0));
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
