@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr int BEAM_WAVES = 4;        // waves (= beam trips) per workgroup of the beams kernel
+#ifndef PRL_BEAM_WAVES
+#define PRL_BEAM_WAVES 2
+#endif
+constexpr int BEAM_WAVES = PRL_BEAM_WAVES;   // waves (= beam trips) per workgroup of the beams kernel
 #ifndef PRL_REST_WGS
 #define PRL_REST_WGS 512
 #endif

@@ -21,7 +21,7 @@
 #define PRL_HG_CELL 0.25           // edge of a front-facet grid cell in root mean facet areas: the walk's starting facets (0.7: 3.7 loop trips a beam trip, 0.2: 3.0)
 #endif
 #ifndef PRL_FINE_CELL
-#define PRL_FINE_CELL 2.0          // edge of a fine sample-grid cell in mean sample spacings (prl_cone.hpp)
+#define PRL_FINE_CELL 1.6          // edge of a fine sample-grid cell in mean sample spacings (prl_cone.hpp; 1.5 / 1.6 / 1.75 / 2.0: beams + far kernel 137 / 134 / 139 / 147 us)
 #endif
 
 namespace {
@@ -444,7 +444,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         UP(samp_ub, ub.data(), ub.size());
         UP(word_pivot, pivot.data(), pivot.size());
     }
-    {   // fine grid over the real samples for the lane-parallel nearest-sample query (prl_cone.hpp): ~4 samples a cell
+    {   // fine grid over the real samples for the lane-parallel nearest-sample query (prl_cone.hpp): ~2.6 samples a cell
         const double *x1 = t->sample_xyz[d.a1], *x2 = t->sample_xyz[d.a2];
         double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
         std::vector<int> real;

@@ -405,7 +405,7 @@ __device__ bool cone_rays_lanes(PartRef P, const double pos[3], const double qua
 // ---------------------------------------------------------------- bpw:565 pixel_kd_tree.query(k=1), one hit point per lane
 // The nearest sample of this lane's point `pt` (if `want`), exact, equal distances resolved to the lowest reference
 // index -- as nearest_sample_wave, but 64 queries at once: each lane scans the (2r+1)^2 block of FINE grid cells around
-// its point (PartDev::fg_*: ~4 samples a cell, so a 3 x 3 block holds ~36 candidates where the painter's own sample
+// its point (PartDev::fg_*: ~2.6 samples a cell, so a 3 x 3 block holds ~23 candidates where the painter's own sample
 // grid holds ~1 350), rows as contiguous record ranges, four records per trip so that their reads travel together.
 // A sample outside the block is more than r cells away in the principal plane: the best of the block is the answer
 // once it lies within r * 0.99 * cell; a block whose best does not settle the query names the radius that will.  Returns
@@ -484,7 +484,7 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
 //    the row) -- three integer min / median instructions per record instead of three compares and six selects.  A key
 //    stands for a distance in [t, t (1 + 2^-13)), t = the key with the ten bits cleared; the contender test allows for it.
 //  * the block is the 2 x 2 cells around the point (the cell's quadrant picks them): every sample outside it is more than
-//    half a cell away, so a nearest sample within its reach is final -- ~16 records.  Anything else (-2) is the far
+//    half a cell away, so a nearest sample within its reach is final -- ~10 records.  Anything else (-2) is the far
 //    kernel's, with the distance found here as its first bound: rings of cells scanned here, by one or two lanes of 64,
 //    cost the wave more than the eight-lane search there (beams 139 + far 38 us with three rings, 99 + 66 with none).
 __device__ __forceinline__ float nn_band(float d2, float E) {

@@ -62,7 +62,7 @@ struct PartDev {
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
     // fine sample grid for the cone-beam painter's nearest-sample queries, one query per lane (prl_cone.hpp; derived
-    // in part_fill): cells of ~4 samples, fg_rec = the samples sorted by cell as (x, y, z, {i32 rank, i32 device pos})
+    // in part_fill): cells of ~2.6 samples, fg_rec = the samples sorted by cell as (x, y, z, {i32 rank, i32 device pos})
     double fg_o1, fg_o2, fg_inv, fg_accept;       // fg_accept = 0.99 * cell edge
     int fg_nx, fg_ny;
     gint_p fg_start;              // [fg_nx * fg_ny + 1]
