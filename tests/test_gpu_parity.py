@@ -97,6 +97,34 @@ def test_gpu_matches_oracle_on_random_batch(part, kw):
     env.close()
 
 
+def test_gpu_cone_beams_on_a_collision_set_that_is_not_convex():
+    """PAINT_METHOD 'normal' with collision_mode='trimesh': no hull to walk, every beam of every trip is left over and the trips
+    go through the general code whole (the trip list of k_cone_beams.hip)."""
+    from paintrl_amd import part_tables, synth_parts
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('square'), tex_size=(240, 240),
+                                           name='square', collision_mode='trimesh')
+    sp = start_points_for(tables, 'all')
+    dt = DeviceTables(tables, start_points=sp)
+    n, steps = 40, 6
+    env = BatchedPaintEnv(dt, n, max_possible_point=14350, paint_method='normal')
+    orc = oracle.Oracle(tables, n, start_points=sp, max_possible_point=14350, threads=8, paint_method='normal')
+    rng = np.random.RandomState(33)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo) and np.array_equal(r.cpu().numpy(), rr), 'step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd)
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    bits = dt.mask_to_canonical(words)
+    assert all(np.array_equal(bits[e], orc.painted_bits(e)) for e in range(n))
+    env.close()
+
+
 def test_gpu_auto_reset_matches_manual_reset():
     """auto_reset inside the step kernel == done -> reset with the same start index."""
     tables = synthetic_tables('door_test')
