@@ -486,24 +486,13 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         d.fg_nx = nx;
         d.fg_ny = ny;
         UP(fg_start, start.data(), start.size());
-        {   // fg_seed = ring count << 24 | record.  Ring count: how many rings of cells away the nearest cell with samples is
-            // (breadth first over the eight neighbours: exact).  Record: the sample nearest to the cell's centre in the
-            // principal plane -- of the cell itself, or of the nearest cell with samples (two raster sweeps that hand the
-            // nearest source cell from neighbour to neighbour: nearest but for rare ties in the sweep order; any sample is a
-            // correct first bound, a near one a tight one)
-            std::vector<int> gap((size_t)nx * ny, -1), queue, src((size_t)nx * ny, -1);
-            queue.reserve(gap.size());
+        {   // fg_seed: for every cell the record of the sample nearest to the cell's centre in the principal plane -- of the cell
+            // itself, or of the nearest cell with samples (two raster sweeps that hand the nearest source cell from neighbour
+            // to neighbour: nearest but for rare ties in the sweep order; any sample is a correct first bound of the far
+            // kernel's search, a near one a tight one)
+            std::vector<int> src((size_t)nx * ny, -1);
             for (int c = 0; c < nx * ny; ++c)
-                if (start[c + 1] > start[c]) gap[c] = 0, src[c] = c, queue.push_back(c);
-            for (size_t h = 0; h < queue.size(); ++h) {
-                const int c = queue[h], cx = c % nx, cy = c / nx;
-                for (int dy = -1; dy <= 1; ++dy)
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int x = cx + dx, y = cy + dy;
-                        if (x < 0 || x >= nx || y < 0 || y >= ny || gap[y * nx + x] >= 0) continue;
-                        gap[y * nx + x] = gap[c] + 1, queue.push_back(y * nx + x);
-                    }
-            }
+                if (start[c + 1] > start[c]) src[c] = c;
             auto dist2 = [&](int c, int s) {
                 const long long dx = c % nx - s % nx, dy = c / nx - s / nx;
                 return dx * dx + dy * dy;
@@ -523,7 +512,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             }
             std::vector<int> seed((size_t)nx * ny, -1);
             for (int c = 0; c < nx * ny; ++c) {
-                if (src[c] < 0 || real.size() >= ((size_t)1 << 24)) continue;      // (no sample at all; a table beyond 16 M samples: no seeds)
+                if (src[c] < 0) continue;                                          // (no sample at all)
                 const double m1 = lo1 + (c % nx + 0.5) * cell, m2 = lo2 + (c / nx + 0.5) * cell;
                 double best = INFINITY;
                 int pick = start[src[c]];
@@ -531,7 +520,7 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
                     const double d1 = rec[(size_t)i * 4 + d.a1] - m1, d2 = rec[(size_t)i * 4 + d.a2] - m2;
                     if (d1 * d1 + d2 * d2 < best) best = d1 * d1 + d2 * d2, pick = i;
                 }
-                seed[c] = pick | (std::min(gap[c], 127) << 24);
+                seed[c] = pick;
             }
             UP(fg_seed, seed.data(), seed.size());
         }

@@ -645,8 +645,8 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
             int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
             cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
             cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
-            const int sd = ldg(P.fg_seed, cy * P.fg_nx + cx), i = sd & 0xffffff;
-            if (sd >= 0) {
+            const int i = ldg(P.fg_seed, cy * P.fg_nx + cx);
+            if (i >= 0) {
                 const f64x2 ra = ldg(rec, 2 * i), rb = ldg(rec, 2 * i + 1);
                 const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
                 const double dd = (dx * dx + dy * dy) + dz * dz;

@@ -76,8 +76,8 @@ struct PartDev {
     int py_levels;                // 0: no pyramid
     int py_off[PY_MAX_LEVELS], py_nx[PY_MAX_LEVELS], py_ny[PY_MAX_LEVELS];      // first node / dimensions of each level
     gfloat_p py_box;
-    gint_p fg_seed;               // [fg_nx * fg_ny]: rings of cells to the nearest cell with samples << 24 | a record of that cell
-                                  // (the tree walk's first bound; the ring search starts at that ring)
+    gint_p fg_seed;               // [fg_nx * fg_ny]: a record near the cell (its own centre-nearest sample, or that of the nearest
+                                  // cell that has one; -1: the part has no sample): the first bound of nearest_sample_bfs
     // outline of the collision set in the principal plane (convex polygon, derived in part_fill) and its extent along
     // the third axis: a beam whose stretch inside that slab projects outside the outline misses the part (prl_cone.hpp)
     int n_outline;                // edges, 0 = no test; the table is padded to a multiple of 64 rows
