@@ -258,19 +258,29 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
 #ifndef PRL_FAR_OCC
 #define PRL_FAR_OCC 6                 // (80 registers: at 8 waves a SIMD the search spills; 45 -> 40 us)
 #endif
-__global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
-    __shared__ int s_bfs[4 * BFS_LDS_INTS];
+#ifndef PRL_FAR_WAVES
+#define PRL_FAR_WAVES 4
+#endif
+constexpr int FAR_WAVES = PRL_FAR_WAVES;         // waves a workgroup of the far kernel (a workgroup's slot is free when its last wave is through)
+__global__ __launch_bounds__(64 * FAR_WAVES, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
+    __shared__ int s_bfs[FAR_WAVES * BFS_LDS_INTS];
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
-    const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
+    const int wave = rfl(blockIdx.x * FAR_WAVES + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
     const int far_cap = a.cone_work[2];
     SubLists lists;
     lists.load(far_counters(a), far_cap, BFS_N, lane);
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
+    const unsigned long long far_t0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int chunk = wave; chunk < lists.total; chunk += n_waves) {
         CONE_TIME_BEGIN();
         int sub, j, count;
         lists.find(chunk, sub, j, count);
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
+        const unsigned long long far_t1_ = __builtin_amdgcn_s_memrealtime();
+#endif
         const bool in = BFS_N * j + (lane >> BFS_SHIFT) < count;
         const f64x2 *e = reinterpret_cast<const f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + BFS_N * j + (in ? lane >> BFS_SHIFT : 0));
         const f64x2 e0 = e[0], e1 = e[1];
@@ -285,8 +295,19 @@ __global__ __launch_bounds__(256, PRL_FAR_OCC) void cone_far_kernel(StepArgs) {
             const bool mine = have && part == p;
             todo &= ~ballot64(mine);
             PartRef P = *(const PartDev CAS *)(a.parts + p);
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
+            const unsigned long long far_t2_ = __builtin_amdgcn_s_memrealtime();
+#endif
             const int sidx = nearest_sample_groups(P, pt, mine, hint, lane, fr);
             if (mine && (lane & (BFS_G - 1)) == 0) a.cone_hits[dest] = sidx;
+#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
+            if (lane == 0 && chunk < 16384) {                             // ticks: kernel start -> this chunk, entry read, search
+                g_far_trace[4 * chunk] = (unsigned)(far_t1_ - far_t0_);
+                g_far_trace[4 * chunk + 1] = (unsigned)(far_t2_ - far_t1_);
+                g_far_trace[4 * chunk + 2] = (unsigned)(__builtin_amdgcn_s_memrealtime() - far_t2_);
+                g_far_trace[4 * chunk + 3] = (unsigned)(far_t0_ & 0xffffffffu);
+            }
+#endif
         }
         CONE_TIME_END(0);
     }
@@ -397,12 +418,15 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
     hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS * 4 / FAR_WAVES), dim3(64 * FAR_WAVES), 0, s, a);
     return (int)hipGetLastError();
 }
 
 #if defined(PRL_CONE_TRACE) && defined(PRL_DIAG_EXPORT)
 // diagnostic build only: read and clear the beams kernel's path counters (prl_cone.hpp CONE_STAT)
+extern "C" int prl_debug_far_trace(unsigned *out) {                      // out[4 * 16384]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_far_trace), sizeof(unsigned) * 4 * 16384) == hipSuccess ? PRL_OK : PRL_E_HIP;
+}
 extern "C" int prl_debug_cone_stats(unsigned long long *out) {       // out[32 + 160]: counters, wave-time histograms
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cone_stat), sizeof(unsigned long long) * 32) != hipSuccess) return PRL_E_HIP;
     if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_cone_hist), sizeof(unsigned long long) * 160) != hipSuccess) return PRL_E_HIP;

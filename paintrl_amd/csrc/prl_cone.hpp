@@ -37,6 +37,17 @@ __device__ unsigned long long g_cone_stat[32];
 // wave times (s_memrealtime ticks of 10 ns) as a histogram: slot k / 3 (0 far-list, 1 trip-list waves of the rest
 // kernel, 2 beams kernel), bucket = floor(log2(ticks)); ONE atomic per wave
 __device__ unsigned long long g_cone_hist[5 * 32];
+__device__ unsigned g_far_trace[4 * 16384];         // PRL_CONE_TRACE == 4: per wave of the far kernel, ticks of its phases (plain stores)
+__device__ unsigned g_far_stamp[4];
+#if PRL_CONE_TRACE == 4                          // (the far kernel's per-wave trace alone: no atomics anywhere)
+#define CONE_TIME_BEGIN() \
+    do {                  \
+    } while (0)
+#define CONE_TIME_END(k) \
+    do {                 \
+    } while (0)
+#define CONE_HIST(k, bucket)
+#else
 #define CONE_TIME_BEGIN() const unsigned long long cone_t0_ = __builtin_amdgcn_s_memrealtime()
 #define CONE_TIME_END(k)                                                             \
     do {                                                                             \
@@ -48,6 +59,7 @@ __device__ unsigned long long g_cone_hist[5 * 32];
         const int b_ = (bucket);                                                     \
         if ((threadIdx.x & 63) == 0) atomicAdd(&g_cone_hist[(k) * 32 + (b_ < 31 ? b_ : 31)], 1ull); \
     } while (0)
+#endif
 #else
 #define CONE_STAT(k, v)
 #define CONE_HIST(k, bucket)
@@ -583,6 +595,23 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     if (open && best_pos >= 0) far_bound = __double2float_ru(best_d);
     // three the float distances cannot order, a row beyond a key's places, a nearest sample beyond the block's reach: -2
     if (open && !(c3 || wide) && best_pos >= 0 && best_d <= lim * lim) result = best_pos;
+    // a point that has seen no sample at all (its block is empty: the hull over a window of the part): the distance to the
+    // seed sample of its cell (fg_seed) is the bound the far kernel starts with -- two dependent reads that cost a wave of
+    // this kernel nothing it does not hide, and were a fifth of a search's chain there
+    const bool blind = want && result == -2 && !(far_bound < INFINITY);
+    if (ballot64(blind) != 0) {
+        if (blind) {
+            const int gx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), gy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
+            const int i = ldg(P.fg_seed, gy * P.fg_nx + gx);
+            if (i >= 0) {
+                const f64x2 GAS *rec64 = reinterpret_cast<const f64x2 GAS *>(P.fg_rec);
+                const f64x2 ra = ldg(rec64, 2 * i), rb = ldg(rec64, 2 * i + 1);
+                const double dx = ra.x - pt[0], dy = ra.y - pt[1], dz = rb.x - pt[2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                if (dd == dd) far_bound = __double2float_ru(dd);      // (+inf stays: the search there finds nothing either)
+            }
+        }
+    }
 #ifdef PRL_FORCE_FULL_SCANS                          // diagnostic build: every query through the far kernel's search
     if (want) result = -2;
 #endif

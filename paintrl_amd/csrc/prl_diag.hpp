@@ -9,11 +9,12 @@
 //                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
 //   PRL_NO_PRIO, PRL_PRIO_SLOT=<s>  no s_setprio by progress / youngest-wave bias from hardware slot s (prl_step.hpp)
 //   PRL_OLD_BALLOT             HIP's __ballot instead of the builtin (prl_device.hpp)
-//   PRL_WALK_STEPS, PRL_CONE_JOINT_FROM, PRL_FINE_CELL, PRL_HG_CELL, PRL_BEAM_OCC, PRL_BEAM_WAVES, PRL_FAR_OCC, PRL_FAR_WGS,
+//   PRL_WALK_STEPS, PRL_CONE_JOINT_FROM, PRL_FINE_CELL, PRL_HG_CELL, PRL_BEAM_OCC, PRL_BEAM_WAVES, PRL_FAR_OCC, PRL_FAR_WGS, PRL_FAR_WAVES,
 //   PRL_REST_WGS, PRL_BFS_LANES   tuning constants of the cone-beam painter (prl_cone.hpp, paintrl_hip.hip, k_cone_beams.hip);
 //   PRL_CONE_F64_RECORDS, PRL_CONE_OUTLINE_IN_BEAMS: A/B switches; PRL_CONE_CUT_NN, PRL_CONE_CUT_FAR: timing builds
 //                              (wrong results: the beams kernel without its search / without its list pushes)
-//   PRL_CONE_TRACE             path counters of the cone-beam kernels (= 2: wave-time histograms alone; tools/cone_stats.py)
+//   PRL_CONE_TRACE             path counters of the cone-beam kernels (= 2: wave-time histograms alone; tools/cone_stats.py;
+//                              = 4: per-wave phase times of the far kernel, plain stores, no atomics; tools/far_trace.py)
 //   PRL_FRAG_TIMING            policy phase of act_step_kernel per barrier, rollout kernels' phases (tools/fragment_timing.py)
 //   PRL_PAINT_ONE_ROW_PER_TRIP one sample-grid row per trip of the painter (multi-trip path)   } the general paths,
 //   PRL_FORCE_FULL_SCANS       whole-table scans instead of the ring searches                } run by the forced-
