@@ -433,3 +433,29 @@ def test_cone_beam_step_on_a_side_stream_and_in_a_graph():
         for k in range(steps):
             for x, y in zip(ref[k], got[k]):
                 assert torch.equal(x, y), (mode, k)
+
+
+def test_cone_beams_do_not_depend_on_the_batch_they_run_in():
+    """PAINT_METHOD 'normal' at 8 192 envs in one batch == the same envs as two batches of 4 096 (the work lists, their
+    sub-lists and the kernels that empty them are shared by the envs of a batch; the envs themselves are independent)."""
+    import torch
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n, steps = 8192, 4
+    rng = np.random.RandomState(404)
+    start = rng.randint(0, len(sp), size=n)
+    acts = rng.randint(0, 4, size=(steps, n))
+    big = _env(tables, n, sp, paint_method='normal')
+    halves = [_env(tables, n // 2, sp, paint_method='normal') for _ in range(2)]
+    o = big.reset(start_idx=start)
+    oh = [h.reset(start_idx=start[k * (n // 2):(k + 1) * (n // 2)]) for k, h in enumerate(halves)]
+    assert torch.equal(o, torch.cat(oh))
+    for t in range(steps):
+        o, r, d, i = big.step(acts[t])
+        parts = [h.step(acts[t][k * (n // 2):(k + 1) * (n // 2)]) for k, h in enumerate(halves)]
+        assert torch.equal(o, torch.cat([p[0] for p in parts])), 'obs, step %d' % t
+        assert torch.equal(r, torch.cat([p[1] for p in parts])) and torch.equal(d, torch.cat([p[2] for p in parts]))
+    assert torch.equal(big.painted_words(), torch.cat([h.painted_words() for h in halves]))
+    big.close()
+    for h in halves:
+        h.close()
