@@ -60,6 +60,7 @@ def test_gpu_replays_reference_episode(tag, name):
     ('door_test', dict(obs_mode='section', paint_method='normal', _n=1536, _steps=12)),
     ('square', dict(obs_mode='grid', paint_method='normal', overlap_penalty=True, max_possible_point=14350, _n=32,
                     _steps=6)),
+    ('square', dict(obs_mode='section', paint_method='normal', max_possible_point=14350, _n=768, _steps=8)),
 ])
 def test_gpu_matches_oracle_on_random_batch(part, kw):
     tables = synthetic_tables(part)
