@@ -18,7 +18,7 @@ from paintrl_amd import build as hb  # noqa: E402
 
 NAMES = ['trips of the beams kernel', 'beams walked', 'hits', 'proven misses', 'rays the walk left over', '  det ~ 0',
          '  start facet not entered', '  horizon without a certificate', '  behind the origin', '  no neighbour across the edge',
-         '  steps exhausted', 'hit points past three rings', 'trips handed to the rest kernel', 'walk loop trips', '-', 'lane-steps']
+         '  steps exhausted', 'hit points for the far kernel', 'trips through the general code (trip list)', 'walk loop trips', '-', 'lane-steps']
 
 
 def main():
@@ -56,7 +56,7 @@ def main():
     for k, nm in enumerate(NAMES):
         if nm != '-':
             print('  %-40s %10.3f' % (nm, per[k]))
-    for k, nm in enumerate(('far-list waves of the rest kernel', 'trip-list waves of the rest kernel', 'waves of the beams kernel')):
+    for k, nm in enumerate(('waves of the far kernel', 'ray and trip waves of the rest kernel', 'waves of the beams kernel')):
         h = out[32 + 32 * k:64 + 32 * k].astype(np.int64)
         print('  %s: %.3f per env-step; by time (us, lower edge of the bucket: waves per launch)' % (nm, h.sum() / (steps * n)))
         print('     ' + '  '.join('%.1f: %.0f' % (2.0 ** b / 100.0, h[b] / steps) for b in range(32) if h[b]))
