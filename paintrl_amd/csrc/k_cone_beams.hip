@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * FAR_WAVES, PRL_FAR_OCC) void cone_far_kernel(S
 #if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
             const unsigned long long far_t2_ = __builtin_amdgcn_s_memrealtime();
 #endif
-            const int sidx = nearest_sample_groups(P, pt, mine, hint, lane, fr);
+            const int sidx = nearest_sample_groups<false>(P, pt, mine, hint, lane, fr);      // (every entry carries a bound)
             if (mine && (lane & (BFS_G - 1)) == 0) a.cone_hits[dest] = sidx;
 #if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
             if (lane == 0 && chunk < 16384) {                             // ticks: kernel start -> this chunk, entry read, search

@@ -658,6 +658,7 @@ __device__ __forceinline__ float group8_min(float v) {
     return v;
 }
 
+template <bool SEED = true>
 __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
     if (P.py_levels <= 0) return want ? -2 : -1;
     const int g = lane >> BFS_SHIFT, m = lane & (BFS_G - 1);
@@ -668,7 +669,8 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     int best_rank = 0x7fffffff, best_pos = -1;
     // the first bound: `hint` (the caller has seen a sample at that squared distance), or a sample of the point's own cell
     // column, or of the nearest column that has one (fg_seed)
-    if (ballot64(want && !(hint < INFINITY)) != 0) {
+    // (SEED = false: the caller always has a hint -- the far kernel, whose entries carry one; without, the search still ends)
+    if (SEED && ballot64(want && !(hint < INFINITY)) != 0) {
         if (want && !(hint < INFINITY)) {
             int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
             int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
@@ -809,8 +811,9 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
 
 // The search above for the eight points of a wave's groups, and nearest_sample_wave for a group whose frontier outgrew
 // its list (or a part without the pyramid): the position in every lane of the group.
+template <bool SEED = true>
 __device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
-    int pos = nearest_sample_bfs(P, pt, want, hint, lane, fr);
+    int pos = nearest_sample_bfs<SEED>(P, pt, want, hint, lane, fr);
     uint64_t ov = ballot64(want && pos == -2 && (lane & (BFS_G - 1)) == 0);
     while (ov) {
         const int L = __builtin_ctzll(ov);
