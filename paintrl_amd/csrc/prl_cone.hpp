@@ -498,7 +498,7 @@ __device__ __forceinline__ int nearest_sample_lane(PartRef P, const double pt[3]
 //  * the block is the 2 x 2 cells around the point (the cell's quadrant picks them): every sample outside it is more than
 //    half a cell away, so a nearest sample within its reach is final -- ~10 records.  Anything else (-2) is the far
 //    kernel's, with the distance found here as its first bound: rings of cells scanned here, by one or two lanes of 64,
-//    cost the wave more than the eight-lane search there (beams 139 + far 38 us with three rings, 99 + 66 with none).
+//    cost the wave more than the few-lane search there (beams 139 + far 38 us with three rings, 99 + 66 with none).
 __device__ __forceinline__ float nn_band(float d2, float E) {
     const float d = __builtin_sqrtf(d2) * 1.0001f + 1e-12f;
     return 3.5f * d * E + 3.0f * E * E + 2.4e-7f * d2 + 1e-30f;
@@ -809,7 +809,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     return want ? ((over || (best_pos < 0 && hint < INFINITY)) ? -2 : best_pos) : -1;       // (a hint that found nothing: never, but exact anyway)
 }
 
-// The search above for the eight points of a wave's groups, and nearest_sample_wave for a group whose frontier outgrew
+// The search above for the points of a wave's groups, and nearest_sample_wave for a group whose frontier outgrew
 // its list (or a part without the pyramid): the position in every lane of the group.
 template <bool SEED = true>
 __device__ __forceinline__ int nearest_sample_groups(PartRef P, const double pt[3], bool want, float hint, int lane, int *fr) {
