@@ -16,6 +16,7 @@
 //  * section / grid observations are popcounts over mask words; only words whose bounding box straddles the tool
 //    position are classified per sample.
 // No MFMA: this is gather / scan / bit work.
+#define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: how this unit holds the part's table pointers)
 #include "prl_all.hpp"
 
 #ifndef PRL_KW

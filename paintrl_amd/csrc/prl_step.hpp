@@ -302,7 +302,16 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         if (shot <= 1) PRIO_BY_PROGRESS(3);
         else PRIO_YOUNG_OLD(3, 2);
         double center[3], quat[4];                         // rob:277-278 shot centre
+#if defined(PRL_UNIT_STEP) && !defined(PRL_KEEP_PART)
+        // (k_step.hip: the part's table pointers are read again in every shot -- scalar loads from the constant cache --
+        // instead of kept across the shots, which spilled them to vector lanes and fetched them back with vector
+        // instructions: 65 -> 46 spilled scalar registers, 40.2 -> 39.7 us)
+        const PartDev CAS *pp = &P;
+        asm volatile("" : "+s"(pp));
+        sub_shot<KD>(*pp, lane, S, X, wl, center, quat PROF_PASS);
+#else
         sub_shot<KD>(P, lane, S, X, wl, center, quat PROF_PASS);
+#endif
         // painting is deferred until all five centres are known
 #pragma unroll
         for (int k = 0; k < 3; ++k)
