@@ -2,6 +2,8 @@
 // persistent launch with the policy (rollout_policy_kernel) or with given actions (rollout_fragment_kernel).
 // Compiled once per mask width (-DPRL_KW=1..4), see prl_launch.hpp.  KD: parts of the batch may carry the reference's
 // stale vertex kd-tree (bpw:943-946; the reference's own sheet `square.urdf` does), walked in per-wave LDS rows.
+#define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot; fragment 21.4 -> 21.8 k,
+                                           // given actions 29.5 -> 30.3 k steps/s)
 #include "prl_all.hpp"
 #include "prl_kargs.hpp"
 #define PRL_HAVE_F32X4
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
         if (env < a.n_envs) {
-            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+            PartRef P = *(const PartDev CAS *)(a.parts + rfl(a.env_part ? a.env_part[env] : 0));
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
             const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
             const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         if (t >= T) break;
         FRAG_T(ft1);
         if (env < n_envs) {                                           // exactly the per-step kernel's body
-            const int part_id = a.env_part ? a.env_part[env] : 0;
+            const int part_id = rfl(a.env_part ? a.env_part[env] : 0);       // (wave-uniform: the part's fields are scalar reads)
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
             CfgRef C = *(const CfgDev CAS *)a.cfg;
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
         if (env < a.n_envs) {
-            PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
+            PartRef P = *(const PartDev CAS *)(a.parts + rfl(a.env_part ? a.env_part[env] : 0));
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
             const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
             const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
@@ -164,7 +166,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
                                              double (*s_centres)[PAINT_PER_ACTION * 3 + 1], double (*s_kd)[KD ? KD_HEAP * 5 : 1]) {
     const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const StepArgs CAS &a = f.s;
-    const int part_id = a.env_part ? a.env_part[env] : 0;
+    const int part_id = rfl(a.env_part ? a.env_part[env] : 0);       // (wave-uniform: the part's fields are scalar reads)
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             const StepArgs CAS &a = h.f.s;
             const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0);
             const int env = opaque_s((int)blockIdx.x) * POLICY_WAVES + wave;
-            const int part_id = a.env_part ? a.env_part[env] : 0;
+            const int part_id = rfl(a.env_part ? a.env_part[env] : 0);       // (wave-uniform: the part's fields are scalar reads)
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
             CfgRef C = *(const CfgDev CAS *)a.cfg;
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
