@@ -2,6 +2,7 @@
 // front samples) do not fit four mask words per lane.  Their kernels keep the env's masks in LDS instead (three copies
 // of n_words words per env in the step kernel, one in reset / observe), sized at launch; everything else is the same
 // device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
+#define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot)
 #include "prl_all.hpp"
 
 #define PRL_KW 0
