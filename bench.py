@@ -159,13 +159,25 @@ def valu_issue_bound(kernel_us, obs_mode):
     c = m.get(obs_mode)
     if not c:
         return None
+    at = m.get('measured_at_commit')
+    stale = None
+    if at and at != 'unknown':
+        # the instruction counts belong to the kernel of that commit: say so when csrc/ has changed since
+        try:
+            base = at.split('+')[0]
+            changed = subprocess.check_output(['git', '-C', REPO, 'diff', '--name-only', base, '--', 'paintrl_amd/csrc'],
+                                              text=True, stderr=subprocess.DEVNULL).strip()
+            stale = bool(changed) or at.endswith('+dirty')
+        except (subprocess.CalledProcessError, OSError):
+            stale = None                  # no git here (the GPU box): unknown
     return {'bound': 'valu_issue', 'valu_per_wave': c['valu_per_wave'], 'valu_f64_per_wave': c['f64_per_wave'],
             'valu_f64_trans_per_wave': c['f64_trans_per_wave'], 'price_cycles': m['price_cycles'],
             'share_of_non_f64_at_2_cycles': c['share_of_the_rest_at_2_cycles'], 'clock_ghz': CLOCK_GHZ,
             'issue_bound_us': c['issue_bound_us'], 'frac': c['issue_bound_us'] / kernel_us,
             'sq_active_inst_valu_us': c['sq_active_inst_valu_us'], 'sq_active_inst_valu_frac': c['sq_active_inst_valu_us'] / kernel_us,
             'source': os.path.relpath(path, REPO) + ' (tools/valu_model.py: rocprofv3 --pmc counts x tools/microbench/valu_rate '
-                      'issue costs, split by the static encoding mix of the kernel)', 'measured_at_commit': m.get('measured_at_commit')}
+                      'issue costs, split by the static encoding mix of the kernel)', 'measured_at_commit': at,
+            'kernel_sources_changed_since': stale}
 
 
 # ---------------------------------------------------------------------------- self-launch (N > 1)
@@ -365,7 +377,8 @@ def main():
             act, _, _ = policy.act(obs_for_policy())
             env.step_raw(act)
 
-    gatherer = pdist.ReturnsGatherer(device) if world > 1 else None
+    import torch.distributed as dist
+    gatherer = pdist.ReturnsGatherer(device) if dist.is_initialized() else None      # (world 1: only under PAINTRL_FORCE_DIST)
 
     def gather_fragment():
         # the all_gather of the fragment's episode returns runs on a side stream, overlapped with the next steps
@@ -475,7 +488,6 @@ def main():
                                     'per launch)' % FRAGMENT,
                         'random-fragment': 'random (persistent rollout-fragment kernel reading the action rows, %d steps '
                                            'per launch)' % FRAGMENT}[args.policy]
-        import torch.distributed as dist
         dist_world = dist.get_world_size() if dist.is_initialized() else 1
         out = {
             'metric': 'batched env steps/sec (door panel, N=4096)', 'value': value,
@@ -493,6 +505,7 @@ def main():
                        'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
                        'episodes_finished_rank0': episodes, 'launches_per_step': len(subs),
                        'prewarm_steps_untimed_scratch_batch': prewarm_steps,
+                       'returns_gathers': gatherer.count if gatherer is not None else 0,
                        'parallelism': 'env-shard x%d (torch.distributed world size %d, backend %s)'
                                       % (world, dist_world, dist.get_backend() if dist.is_initialized() else 'none')
                                       + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs))
@@ -513,7 +526,7 @@ def main():
                                              else 'HIP event pairs around sampled launches',
                          'avg_kernel_us_sampled': sampled_us, 'sampled_launches': int(launches),
                          'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
-                         if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random'
+                         if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random' and args.actions == 'random'
                              and args.paint_method == 'fast' and len(subs) == 1) else None},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -522,9 +535,8 @@ def main():
         sys.stdout.flush()
     for e in subs:
         e.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+    if dist.is_initialized():
+        pdist.barrier()
         dist.destroy_process_group()
 
 

@@ -83,6 +83,10 @@ typedef struct {
     const int32_t *kd_less, *kd_greater, *kd_start, *kd_end;   /* [n] children / leaf range into kd_points */
     const int32_t *kd_points;      /* compact side-vertex ids in scipy's tree order, -1 = a row of another side */
     const double *kd_box;          /* [2][3] bounding box of the rows when the tree was built */
+    /* pixel_kd_tree.query(k = 1) (bpw:565) between samples at EQUAL distance -- samples that share one 3-D position, texels
+     * of different triangles on one mesh vertex: query.cxx keeps the first of a leaf in the tree's index order (strict <);
+     * sample_rank[s] = place of sample s in that order (paintrl_amd/part_tables.py _sample_tie_rank), lower wins */
+    const int32_t *sample_rank;    /* [P] */
 } OrPart;
 
 typedef struct {
@@ -428,7 +432,7 @@ static int cone_query(const OrPart *p, const double *pose, const double *quat, u
             const double *x = p->sample_pos + 3 * s;
             double dx = x[0] - hit[0], dy = x[1] - hit[1], dz = x[2] - hit[2];
             double d2 = (dx * dx + dy * dy) + dz * dz;
-            if (d2 < best_d) { best_d = d2; best = s; }
+            if (d2 < best_d || (d2 == best_d && p->sample_rank[s] < p->sample_rank[best])) { best_d = d2; best = s; }
         }
         cur[best >> 6] |= (uint64_t)1 << (best & 63);
         if (list) list[hits] = best;

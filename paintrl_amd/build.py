@@ -98,6 +98,10 @@ def build_named(name, out, extra=(), force=False, verbose=False, diag_unit=None,
         for j in jobs:
             j.result()
     objs = [os.path.join(obj_dir, u[0] + '.o') for u in UNITS]
+    missing = [o for o in objs if not os.path.isfile(o)]
+    if missing:
+        raise FileNotFoundError('cannot link %s: %d object(s) not built yet (e.g. %s); build without only= first'
+                                % (os.path.basename(out), len(missing), os.path.relpath(missing[0], _REPO)))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.isfile(out) or os.path.getmtime(out) < newest:
         os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -108,10 +112,23 @@ def build_named(name, out, extra=(), force=False, verbose=False, diag_unit=None,
     return out
 
 
+def _sources_newer_than(path):
+    """Any csrc/*.hip, csrc/*.hpp or include/*.h newer than ``path``."""
+    import glob
+    built = os.path.getmtime(path)
+    files = glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.hpp')) + \
+        glob.glob(os.path.join(_REPO, 'include', '*.h'))
+    return any(os.path.getmtime(f) > built for f in files)
+
+
 def is_stale():
     if not os.path.isfile(LIBRARY):
         return True
     obj_dir = os.path.join(_HERE, '_obj', 'product')
+    if not any(os.path.isfile(os.path.join(obj_dir, u[0] + '.o')) for u in UNITS):
+        # a prebuilt library without its objects (the GPU box, a fresh checkout: _obj/ does not travel): the library's
+        # own age against the sources decides
+        return _sources_newer_than(LIBRARY)
     for uname, src_file, uflags in UNITS:
         obj = os.path.join(obj_dir, uname + '.o')
         if not os.path.isfile(obj) or os.path.getmtime(obj) > os.path.getmtime(LIBRARY):

@@ -3,6 +3,9 @@
 // of n_words words per env in the step kernel, one in reset / observe), sized at launch; everything else is the same
 // device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot)
+#include <mutex>
+#include <unordered_map>
+
 #include "prl_all.hpp"
 
 #define PRL_KW 0
@@ -252,22 +255,50 @@ __global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int l
 }
 
 // Large parts: dynamic LDS = waves x copies x mask_stride words (+ extra bytes per wave); as many waves per workgroup (at
-// most four) as 150 KB hold.
-int big_waves(const StepArgs &a, int copies, size_t extra_per_wave) {
+// most four) as fit the CU's 160 KB NEXT TO the kernel's own static LDS (wave_lds: candidate list, shot centres, section
+// counters, and with the stale tree 20 KB of kd-walk rows) -- asked of the runtime once per kernel and remembered, like the
+// dynamic size already granted (hipFuncSetAttribute is not repeated per launch).
+struct BigKernelInfo {
+    size_t static_lds = 0, dyn_granted = 64 * 1024;
+    bool known = false;
+};
+
+BigKernelInfo &big_kernel_info(const void *kernel) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, BigKernelInfo> table;
+    std::lock_guard<std::mutex> lock(mu);
+    BigKernelInfo &info = table[kernel];
+    if (!info.known) {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) info.static_lds = attr.sharedSizeBytes;
+        else info.static_lds = 28 * 1024;            // (the largest wave_lds of these kernels)
+        info.known = true;
+    }
+    return info;
+}
+
+constexpr size_t LDS_PER_WORKGROUP = 160 * 1024;
+
+template <typename K>
+int big_waves(K kernel, const StepArgs &a, int copies, size_t extra_per_wave) {
     const size_t per_wave = (size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave;
-    int waves = per_wave ? (int)((150 * 1024) / per_wave) : 4;
+    const size_t fixed = big_kernel_info(reinterpret_cast<const void *>(kernel)).static_lds;
+    if (fixed >= LDS_PER_WORKGROUP) return 0;
+    int waves = per_wave ? (int)((LDS_PER_WORKGROUP - fixed) / per_wave) : 4;
     return waves > 4 ? 4 : waves;
 }
 
 template <typename... Extra>
 int launch_big(void (*kernel)(StepArgs, Extra...), const StepArgs &a, int copies, size_t extra_per_wave, hipStream_t s, Extra... extra) {
-    const int waves = big_waves(a, copies, extra_per_wave);
-    if (waves < 1) return (int)hipErrorInvalidValue;
+    const int waves = big_waves(kernel, a, copies, extra_per_wave);
+    if (waves < 1) return (int)hipErrorInvalidValue;              // (the caller names the part's size in its message)
     const size_t lds = (size_t)waves * ((size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave);
-    if (lds > 64 * 1024) {
+    BigKernelInfo &info = big_kernel_info(reinterpret_cast<const void *>(kernel));
+    if (lds > info.dyn_granted) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        info.dyn_granted = lds;
     }
     hipLaunchKernelGGL(kernel, dim3((a.n_envs + waves - 1) / waves), dim3(64 * waves), lds, s, a, extra...);
     return (int)hipGetLastError();
@@ -302,9 +333,10 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (sel->hsi) {
         const size_t list_bytes = sizeof(int) * (size_t)a.cone_nb;                  // per wave, behind all the mask copies
-        const int waves = big_waves(a, 5, list_bytes);
+        void (*k)(StepArgs, int) = sel->gensec ? cone_finish_kernel_big<true, true> : cone_finish_kernel_big<false, true>;
+        const int waves = big_waves(k, a, 5, list_bytes);
         const int list_off = (int)((size_t)waves * 5 * a.mask_stride * 2);          // in ints
-        return launch_big(sel->gensec ? cone_finish_kernel_big<true, true> : cone_finish_kernel_big<false, true>, a, 5, list_bytes, s, list_off);
+        return launch_big(k, a, 5, list_bytes, s, list_off);
     }
     return launch_big(sel->gensec ? cone_finish_kernel_big<true, false> : cone_finish_kernel_big<false, false>, a, 4, 0, s, 0);
 }

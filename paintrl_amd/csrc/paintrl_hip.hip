@@ -819,6 +819,9 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     }
     std::vector<PartDev> pd(n_parts);
     const int od = obs_dim_of(cfg->obs_mode, cfg->obs_grad);
+    // (the rollout entry points allocate nothing when they run: a fragment can be captured into a graph)
+    if (e == hipSuccess && cfg->auto_reset && cfg->action_mode == PRL_ACT_DISCRETE)
+        e = hipMalloc(reinterpret_cast<void **>(&b->scratch_action), sizeof(int32_t) * (size_t)n_envs);
     b->reset_obs.assign(n_parts, nullptr);
     for (int i = 0; i < n_parts; ++i) {
         pd[i] = parts[i]->dev;
@@ -1124,7 +1127,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
                 return rc;
         }
         if (w) {                                   // the bootstrap value; its draw is discarded
-            if (!b->scratch_action) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&b->scratch_action), sizeof(int32_t) * n));
+            if (!b->scratch_action) return fail(PRL_E_INVALID, "prl_rollout_fragment: batch without the rollout scratch row");
             if (int rc = prl_policy_act(w, b->n_envs, obs + (size_t)n_steps * n * od, nullptr, rng_count, rng_seed, b->scratch_action, nullptr,
                                         last_value, nullptr, stream))
                 return rc;

@@ -11,12 +11,8 @@ namespace {
 // backfilled sooner: at 8 192 envs 80.2 vs 90.2 us, at 32 768 298 vs 319); cone beams: 4.
 constexpr int STEP_WAVES_WIDE = 8, STEP_WAVES_NARROW = 4;
 constexpr int MAX_WAVES_PER_WG = STEP_WAVES_WIDE;   // per-wave LDS scratch rows
-#ifndef PRL_CONE_WAVES
-#define PRL_CONE_WAVES 8
-#endif
-constexpr int CONE_WAVES = PRL_CONE_WAVES;       // envs per workgroup of the cone-beam kernel (k_cone.hip): they share their beam trips
 constexpr int KW_MAX = 4;                       // mask slots per lane: up to 64*64*4 = 16384 samples in registers
-constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3 copies x 4 waves x 1600 x 8 B = 150 KB of 160 KB
+constexpr int BIG_MAX_WORDS = 1600;             // larger parts: masks in LDS, 3-5 copies per wave, as many waves (<= 4) as fit next to the static LDS (k_big.hip)
 constexpr double PAINT_RADIUS = 0.051;          // bpw:42
 constexpr double STEP_SIZE = 0.051;             // bpw:43
 constexpr double HOOK_DISTANCE = 0.1;           // bpw:443
@@ -162,12 +158,13 @@ struct StepArgs {
     uint8_t *done;
     const int *start_idx;
     const uint8_t *reset_mask;
-    // PAINT_METHOD 'normal' only: what the three cone-beam kernels of a step hand to each other (k_cone_beams.hip)
+    // PAINT_METHOD 'normal' only: what the five cone-beam launches of a step hand to each other (k_cone_beams.hip, k_cone.hip)
     double *cone_shots;           // [n_envs][5][8]: tool pose after each sub-shot (pos, quat) | {i32 facet hint, 0}
     double *cone_aux;             // [n_envs][2]: new turning angle | {i32 off-part counter before the step, i32 facet hint}
     int *cone_hits;               // [n_envs][5][cone_nb]: device position of the sample each beam paints, or -1
     int *cone_work;               // counters and work lists of a cone-beam step (k_cone_beams.hip)
-    double *cone_far;             // [capacity][4]: hit point x y z | {i32 index into cone_hits, i32 part id}
+    double *cone_far;             // far list, WORK_LISTS sub-lists of far_cap entries [4]: hit point x y z | {hi: f32 bits of the distance
+                                  // bound the beams kernel saw, lo: i32 index into cone_hits}
     int cone_nb;                  // beams per shot, padded to 64 (the largest beam count of the batch's parts)
 };
 

@@ -67,7 +67,10 @@ class DeviceTables(object):
         # that takes in the alignment pads, which are far away and never valid
         self.sgrid_start = starts.astype(np.int32)
         self.word_valid = np.packbits(valid, bitorder='little').view(np.uint64).copy()
-        self.sample_rank = np.where(valid, self.perm, 0x7fffffff).astype(np.int32)
+        # who wins the nearest-sample query among equally distant samples (samples sharing one position): the reference
+        # tree's own order, part_tables._sample_tie_rank (bpw:565)
+        tie = np.asarray(t.sample_tie_rank, dtype=np.int64)
+        self.sample_rank = np.where(valid, tie[np.maximum(self.perm, 0)], 0x7fffffff).astype(np.int32)
         bbox = np.empty((n_words, 4), dtype=np.float64)
         c1 = np.where(valid, xyz[a1], np.nan).reshape(n_words, 64)
         c2 = np.where(valid, xyz[a2], np.nan).reshape(n_words, 64)

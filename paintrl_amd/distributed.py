@@ -18,10 +18,17 @@ def env_rank():
         int(os.environ.get('WORLD_SIZE', '1'))
 
 
+def force_dist():
+    """PAINTRL_FORCE_DIST=1: take the torch.distributed path at world size 1 too (a one-rank RCCL communicator runs
+    every collective of this module -- init, the device-side all_gather on the side stream, barrier(device_ids),
+    the MAX all_reduce -- on a single GPU; without it a lone rank skips torch.distributed altogether)."""
+    return os.environ.get('PAINTRL_FORCE_DIST', '') not in ('', '0')
+
+
 def init_process_group(backend=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1 unless PAINTRL_FORCE_DIST)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_dist()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -50,7 +57,7 @@ def gather_returns(local_returns):
     """all_gather the per-env episode returns of every rank -> tensor (world * n_local,).
 
     ``local_returns`` is a 1-D tensor on the rank's device (cuda with RCCL, cpu with gloo)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local_returns.clone()
     world = dist.get_world_size()
     if dist.get_backend() == 'gloo' and local_returns.is_cuda:        # gloo moves host memory
@@ -96,7 +103,7 @@ class ReturnsGatherer(object):
 
 def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (used for the timed region of bench.py)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     if dist.get_backend() == 'gloo':
         device = 'cpu'
@@ -106,7 +113,7 @@ def max_over_ranks(value, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         if dist.get_backend() == 'nccl':             # name the device: RCCL otherwise guesses (and warns)
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:

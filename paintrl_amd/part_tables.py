@@ -131,26 +131,37 @@ def _side_of_normals(vn, a0):
 # the builder
 # ----------------------------------------------------------------------------
 def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, collision_mode='hull',
-                      base_position=obj_io.PART_BASE_POSITION, name=None, verbose=False, paint_radius=PAINT_RADIUS):
+                      base_position=obj_io.PART_BASE_POSITION, name=None, verbose=False, paint_radius=PAINT_RADIUS,
+                      tex_init=None):
     """Build the static tables of one part for painting its FRONT side.
 
     Either ``urdf_path`` (resolved like the reference does) or ``mesh``
-    (an ``obj_io.MeshData``) plus ``tex_size`` must be given.
+    (an ``obj_io.MeshData``) plus ``tex_size`` must be given.  ``tex_init``: the decoded bytes of the part's texture
+    file, uint8 (H, W, 3) (bpw:1316-1319) -- read from the file with ``urdf_path``, the uniform grey the synthetic
+    parts are written with (obj_io.write_part) otherwise; only ``texture_image`` looks at it.
     """
     if mesh is None:
         obj_path, tex_path = obj_io.resolve_part_files(urdf_path)
         mesh = obj_io.read_obj(obj_path)
         if tex_size is None:
             tex_size = obj_io.texture_size(tex_path)
+        if tex_init is None:
+            tex_init = obj_io.texture_bytes(tex_path)
         if name is None:
             name = urdf_path
     W, H = int(tex_size[0]), int(tex_size[1])
+    if tex_init is None:
+        tex_init = np.full((H, W, 3), obj_io.SYNTHETIC_TEXTURE_GREY, dtype=np.uint8)
+    tex_init = np.ascontiguousarray(tex_init, dtype=np.uint8)
+    if tex_init.size != H * W * 3:
+        raise ValueError('tex_init has %d bytes, the texture is %d x %d x 3' % (tex_init.size, W, H))
     t = PartTables()
     t.name = name or 'part'
     t.tex_w, t.tex_h = W, H
     t.collision_mode = collision_mode
     t.obs_grad = int(obs_grad)
     t.paint_radius = float(paint_radius)      # PaintToolProfile.PAINT_RADIUS at load time (bpw:42)
+    t.tex_init = tex_init.reshape(H, W, 3)
 
     # -- global frame, axes (bpw:1176-1182, 1294-1300, 498-500) ----------------
     V = np.asarray(base_position, dtype=np.float64)[None, :] + mesh.vertices
@@ -182,9 +193,12 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
     front_ids = np.nonzero(side == SIDE_FRONT)[0]
 
     # -- UV rasterisation -> samples (front) ------------------------------------
-    t.sample_pix, t.sample_pos = _rasterise_side(mesh, V, F, front_ids, W, H)
+    t.sample_pix, t.sample_pos, order = _rasterise_side(mesh, V, F, front_ids, W, H, insertion_order=True)
+    t.sample_tie_rank = _sample_tie_rank(t.sample_pix, t.sample_pos, order, W)
+    # the back side's texels (profile[Side.back], bpw:622-645): only their label in the texture image matters (bpw:588-591)
+    t.back_pix = _rasterise_side(mesh, V, F, np.nonzero(side == SIDE_BACK)[0], W, H, positions=False)
     if verbose:
-        print('samples', t.sample_pix.shape[0])
+        print('samples', t.sample_pix.shape[0], 'back texels', t.back_pix.shape[0])
 
     # -- per-side vertex set (bpw:599-620) ---------------------------------------
     has_front = np.zeros(V.shape[0], dtype=bool)
@@ -248,11 +262,35 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
     return t
 
 
-def _rasterise_side(mesh, V, F, tri_ids, W, H):
+def _sample_tie_rank(pix, pos, insertion, W):
+    """Who wins `pixel_kd_tree.query(point, k=1)` (bpw:565) among samples at EQUAL distance -- in practice samples with
+    the same 3-D position: texels of different triangles that map to one mesh vertex (109 pairs on the reference's
+    door_test.obj).  query.cxx keeps the first point of a leaf that reaches the minimum (strict <), in the order of the
+    tree's own index array; equal points always share a leaf.  That order comes from the tree's partitioning of the rows
+    in the order the reference hands them over: `profile[side] = list(set(pixels))` (bpw:641), the iteration order of a
+    CPython set of int tuples filled in rasterisation order.  Both are restated by running them: the same set here (the
+    interpreter is the reference's platform), scipy's own cKDTree of the positions in that order (as the stale vertex tree
+    is scipy's own object too).  Returns int32 [P]: rank of canonical sample s = its place in that index array."""
+    from scipy.spatial import cKDTree
+    profile = list(set(insertion))                                   # bpw:641
+    lin = np.array([p[0] + p[1] * W for p in profile], dtype=np.int64)
+    canon = pix[:, 0].astype(np.int64) + pix[:, 1].astype(np.int64) * W      # ascending (canonical sample order)
+    to_canon = np.searchsorted(canon, lin)
+    assert len(profile) == len(canon) and np.array_equal(canon[to_canon], lin)
+    tree = cKDTree(pos[to_canon])                                    # bpw:620
+    rank = np.empty(len(canon), dtype=np.int32)
+    rank[to_canon[np.asarray(tree.indices)]] = np.arange(len(canon), dtype=np.int32)
+    return rank
+
+
+def _rasterise_side(mesh, V, F, tri_ids, W, H, positions=True, insertion_order=False):
     """Walk the side's triangles in file order; the last triangle covering a
-    pixel defines that pixel's 3-D position (bpw:622-645, 192-212)."""
+    pixel defines that pixel's 3-D position (bpw:622-645, 192-212).  positions=False: only the pixel set.
+    insertion_order=True: also the list of (i, j) int tuples in the order the reference appends them to
+    profile[side] (bpw:192-212, 633: per triangle its three corner texels, then the inside texels u-major)."""
     pos_map = np.zeros((H * W, 3), dtype=np.float64)
     have = np.zeros(H * W, dtype=bool)
+    order = []
     uvs = mesh.uvs
     FT = mesh.faces_vt
     for ti in tri_ids:
@@ -266,6 +304,8 @@ def _rasterise_side(mesh, V, F, tri_ids, W, H):
             idx = pi[k] + pj[k] * W
             pos_map[idx] = P3[k]
             have[idx] = True
+            if insertion_order:
+                order.append((int(pi[k]), int(pj[k])))
         b0, b1, e00, e01, e11, einv = _bary_setup(uv[0], uv[1], uv[2])
         if einv == 0:
             continue
@@ -279,21 +319,29 @@ def _rasterise_side(mesh, V, F, tri_ids, W, H):
         inside = (bu >= 0) & (bu <= 1) & (bv >= 0) & (bv <= 1) & (bw >= 0) & (bw <= 1)
         if not inside.any():
             continue
+        idx = uu[inside] + vv[inside] * W
+        have[idx] = True
+        if insertion_order:
+            order.extend(zip(uu[inside].tolist(), vv[inside].tolist()))
+        if not positions:
+            continue
         bu, bv, bw = bu[inside], bv[inside], bw[inside]
         p = (bu[:, None] * P3[0][None, :] + bv[:, None] * P3[1][None, :]) + bw[:, None] * P3[2][None, :]
-        idx = uu[inside] + vv[inside] * W
         pos_map[idx] = p
-        have[idx] = True
     # bpw:505-506: get_texel clamps the byte index of texel (W-1, H-1) to len - 4, i.e. onto the BLUE byte of its
     # left neighbour (W-2, H-1): the corner texel keeps its painted flag in that byte.  As long as the neighbour is
     # not a sample of the same side nothing ever writes that byte except the corner's own label and paint, and the
     # corner behaves like every other sample (the reference's test.urdf).  With both in the profile, painting the
     # neighbour would clear the corner's flag in an order that depends on cKDTree internals: not restated.
-    if have[H * W - 1] and have[H * W - 2]:
+    if positions and have[H * W - 1] and have[H * W - 2]:
         raise NotImplementedError('texels (W-1,H-1) and (W-2,H-1) are both samples: the reference get_texel clamp '
                                   '(bpw:505-506) aliases their state bytes')
     lin = np.nonzero(have)[0]
     pix = np.stack([lin % W, lin // W], axis=1).astype(np.int32)
+    if not positions:
+        return pix
+    if insertion_order:
+        return pix, pos_map[lin].copy(), order
     return pix, pos_map[lin].copy()
 
 
@@ -749,15 +797,84 @@ def beta_plain(density, beta=2, expected_points=450, uniform=None):
 
 
 # ----------------------------------------------------------------------------
+# the texture image (bpw:579-592 _label_part, 358-365 change_pixel, 404-406 HSI deposits, 737-738 get_texture_image)
+# ----------------------------------------------------------------------------
+def _set_texels(tex, W, color, pix, skip_if_first_equals=True):
+    """ColorHandler.init_part / change_pixel (bpw:358-365, 377-381) for a list of pixels: the three bytes at
+    get_texel(i, j) = min(3 (i + j W), len - 4) (bpw:505-506) become `color` unless the first already equals
+    color[0].  Pixel (W-1, H-1) is the one the clamp moves: its bytes start on the blue byte of (W-2, H-1); those two
+    are done one after the other in list order, everything else at once."""
+    if len(pix) == 0:
+        return
+    pix = np.asarray(pix, dtype=np.int64).reshape(-1, 2)
+    limit = tex.size - 4
+    base = 3 * (pix[:, 0] + pix[:, 1] * W)
+    special = base >= limit - 2
+    b = base[~special]
+    if skip_if_first_equals:
+        b = b[tex[b] != color[0]]
+    for k in range(3):
+        tex[b + k] = color[k]
+    for b in base[special]:
+        b = min(int(b), limit)
+        if skip_if_first_equals and tex[b] == color[0]:
+            continue
+        for k in range(3):
+            tex[b + k] = color[k]
+
+
+def label_texture(t, color_mode='RGB'):
+    """Part._label_part, render branch (bpw:579-592): the texture's decoded bytes with every texel outside the
+    profiles set to (0, 0, 0), the back side's to (0, 255, 0), the front side's to (191, 191, 191) -- (255, 255, 255) in
+    COLOR_MODE 'HSI' -- in that order, each texel skipped when its red byte already has the target's value (`is_changed`,
+    bpw:352-354: such a texel keeps the green and blue bytes of the texture file).  Returns the flat uint8 texel list
+    (index (i + j W) 3, bpw:505-506) = Part.init_texture."""
+    W, H = int(t.tex_w), int(t.tex_h)
+    tex = np.array(t.tex_init, dtype=np.uint8).reshape(-1).copy()
+    in_profile = np.zeros(H * W, dtype=bool)
+    for pix in (t.sample_pix, t.back_pix):
+        in_profile[pix[:, 0].astype(np.int64) + pix[:, 1].astype(np.int64) * W] = True
+    ii, jj = np.meshgrid(np.arange(W), np.arange(H), indexing='ij')       # bpw:581: for i in width for j in height
+    ii, jj = ii.ravel(), jj.ravel()
+    irrelevant = np.stack([ii, jj], axis=1)[~in_profile[ii + jj * W]]
+    front = (255, 255, 255) if color_mode == 'HSI' else (191, 191, 191)   # int(0.75 * 255), bpw:495-496
+    _set_texels(tex, W, (0, 0, 0), irrelevant)
+    _set_texels(tex, W, (0, 255, 0), t.back_pix)
+    _set_texels(tex, W, front, t.sample_pix)
+    return tex
+
+
+def texture_image(t, painted=None, thickness=None, color_mode='RGB'):
+    """Part.get_texture_image() (bpw:737-738, 18-21) of an env whose front samples are `painted` (bool [P], canonical
+    sample order; COLOR_MODE 'RGB': painted texels are (255, 0, 0), bpw:358-365) or carry the `thickness` bytes
+    (uint8 [P]; COLOR_MODE 'HSI': every deposit lowers the three bytes of a texel by the same amount in uint8
+    arithmetic, bpw:404-406, so green and blue follow the red byte).  uint8 array (W, H, 3) as the reference shapes it
+    (row j, column i for the square textures of every part)."""
+    W, H = int(t.tex_w), int(t.tex_h)
+    tex = label_texture(t, color_mode)
+    pix = np.asarray(t.sample_pix, dtype=np.int64)
+    if color_mode == 'HSI':
+        if thickness is None:
+            raise ValueError("COLOR_MODE 'HSI' needs the thickness bytes")
+        base = np.minimum(3 * (pix[:, 0] + pix[:, 1] * W), tex.size - 4)
+        delta = tex[base] - np.asarray(thickness, dtype=np.uint8)           # what the deposits took off so far (mod 256)
+        for k in range(3):
+            tex[base + k] = tex[base + k] - delta
+    elif painted is not None:
+        _set_texels(tex, W, (255, 0, 0), pix[np.asarray(painted, dtype=bool)])
+    return tex.reshape(W, H, 3)
+
+
+# ----------------------------------------------------------------------------
 # on-disk table format (SURVEY.md 8f-2): one .npz per part
 # ----------------------------------------------------------------------------
 _ARRAY_FIELDS = ['vertices', 'tri_vidx', 'tri_side', 'tri_area', 'tri_area_valid', 'tri_center', 'tri_a', 'tri_v0',
                  'tri_v1', 'tri_d00', 'tri_d01', 'tri_d11', 'tri_inv', 'tri_normal', 'sample_pix', 'sample_pos',
                  'sample_cell', 'vertex_is_side', '_side_data', 'col_v0', 'col_e1', 'col_e2', 'grid_lo', 'grid_hi',
-                 'grid_range', 'beams', 'front_ids'] + list(KD_FIELDS)
+                 'grid_range', 'beams', 'front_ids', 'back_pix', 'tex_init', 'sample_tie_rank'] + list(KD_FIELDS)
 _SCALAR_FIELDS = ['name', 'tex_w', 'tex_h', 'collision_mode', 'obs_grad', 'paint_radius', 'a0', 'a1', 'a2', 'lwr', 'max_grid_size',
                   'density', 'n_hull_corrected', 'n_smoothed']
-TABLE_FORMAT_VERSION = 2
+TABLE_FORMAT_VERSION = 3          # 3: back_pix, tex_init (texture_image), sample_tie_rank
 
 
 def save_tables(t, path):

@@ -219,17 +219,14 @@ class PaintGymEnv(spaces.Env):
         return obs
 
     def get_texture_image(self):
-        """(H, W, 3) uint8 texture: painted texels red, unpainted front texels grey (bpw:585-592, 737-738)."""
-        t = self._tables
-        img = np.zeros((t.tex_h, t.tex_w, 3), dtype=np.uint8)
-        pix = t.sample_pix
-        if self.COLOR_MODE == 'HSI':              # the three channels of a front texel carry the same byte (bpw:404-406)
-            img[pix[:, 1], pix[:, 0]] = self._batch.thickness(0)[:, None]
-            return img
-        bits = self._batch.painted_bits(0)
-        img[pix[:, 1], pix[:, 0]] = (191, 191, 191)
-        img[pix[bits, 1], pix[bits, 0]] = (255, 0, 0)
-        return img
+        """Part.get_texture_image() (bpw:737-738): the reference's texel list as a uint8 (W, H, 3) array -- texels outside
+        the profiles black, the back side's (0, 255, 0), unpainted front texels (191, 191, 191), painted ones (255, 0, 0),
+        with the quirks of the labelling kept (part_tables.label_texture); COLOR_MODE 'HSI': front texels carry their
+        thickness byte in all three channels (bpw:404-406)."""
+        from . import part_tables
+        if self.COLOR_MODE == 'HSI':
+            return part_tables.texture_image(self._tables, thickness=self._batch.thickness(0), color_mode='HSI')
+        return part_tables.texture_image(self._tables, painted=self._batch.painted_bits(0))
 
     def get_job_status(self):
         """Number of painted samples (bpw:727-732)."""

@@ -320,6 +320,61 @@ def main_termination():
     assert bool(eps['t2_finished9000']['done'][-1]) and len(eps['t2_finished9000']['actions']) < 245
 
 
+def texture_of(drv):
+    """Part.get_texture_image() (bpw:737-738) as the uint8 array the PIL image is made from (bpw:18-21)."""
+    part = drv.part
+    return np.asarray(part.texels, dtype=np.uint8).reshape(part.texture_width, part.texture_height, 3).copy()
+
+
+def replay_policy(actions):
+    acts = [int(a) for a in actions]
+    return lambda k, obs: acts[k]
+
+
+def main_textures():
+    """The reference's texture image (Part.get_texture_image, bpw:737-738) after a reset and at the end of three committed
+    episodes -- their recorded action lists are replayed on the reference -- : g2_zigzag (sheet), g3_serpentine (door),
+    g13_hsi_serpentine (door, COLOR_MODE 'HSI').  Written to textures.npz (whole images: they compress to a few KB)."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    ref_import.load_reference('hull')
+
+    def load(tag, name):
+        z = np.load(os.path.join(HERE, 'episodes_%s.npz' % tag), allow_pickle=False)
+        return {k.split('/', 1)[1]: z[k] for k in z.files if k.startswith(name + '/')}
+
+    out = {}
+
+    def record(drv, tag, name, seed, want_idx):
+        ep = load(tag, name)
+        got = drv.episode(seed, replay_policy(ep['actions']), max_steps=len(ep['actions']), want_idx=want_idx)
+        assert np.array_equal(got['obs'], ep['obs']) and np.array_equal(got['snaps'][-1], ep['snaps'][-1]), name
+        img = texture_of(drv)
+        out[name] = img
+        out[name + '_sha256'] = np.array(sha(img))
+        print(name, img.shape, out[name + '_sha256'])
+
+    sheet = RefDriver(root, 1)
+    sheet.configure('simple', 4, 'fixed', rollout=True)
+    sheet.reset(0)
+    out['sheet_after_reset'] = texture_of(sheet)
+    record(sheet, 'sheet', 'g2_zigzag', 0, None)
+    sheet.env.close()
+    door = RefDriver(root, 0)
+    door.configure('section', 4, 'anchor')
+    door.reset(0)
+    out['door_after_reset'] = texture_of(door)
+    record(door, 'door', 'g3_serpentine', 8, 0)
+    door.env.close()
+    hsi = RefDriver(root, 0, extra={'COLOR_MODE': 'HSI'})
+    hsi.configure('section', 4, 'anchor')
+    hsi.reset(0)
+    out['door_hsi_after_reset'] = texture_of(hsi)
+    record(hsi, 'door_hsi', 'g13_hsi_serpentine', 8, 0)
+    np.savez_compressed(os.path.join(HERE, 'textures.npz'), **out)
+    print('textures.npz', os.path.getsize(os.path.join(HERE, 'textures.npz')), 'bytes')
+
+
 def main():
     root = os.path.join(HERE, '_synth_root')
     synth_parts.write_synthetic_parts(root)
@@ -427,5 +482,7 @@ if __name__ == '__main__':
         main_termination()
     elif '--param-test-modes' in sys.argv:
         main_param_test_modes()
+    elif '--textures' in sys.argv:
+        main_textures()
     else:
         main()

@@ -9,7 +9,7 @@
    in-container check of the CPU oracle against the reference on a real large part (tables are rebuilt from
    /root/reference at test time; the test is skipped where the reference is absent).
 
-    python tests/golden/make_golden_parts.py [digests] [big] [door_rr]
+    python tests/golden/make_golden_parts.py [digests] [big] [door_rr] [reference_meshes] [hsi] [hsi_cone] [sparse]
 """
 import json
 import os
@@ -97,6 +97,59 @@ def reference_door_rr():
     save_episodes(os.path.join(HERE, 'episodes_reference_door_rr.npz'), eps)
 
 
+def reference_meshes(which=('door_test', 'square')):
+    """Episodes on the two parts the reference's published results use, on the reference's OWN meshes (rge:106-108:
+    door_test.urdf = Part_NO 0, square.urdf = Part_NO 1; zigzag.py:8, spiral.py:8, paint_ppo.py:95): section observation
+    from 'all' and anchor starts, grid + both penalties, the cone beams, COLOR_MODE 'HSI', and the texture image at the
+    end of one episode (the real pattern.jpg under the labels).  Replayed by the oracle on tables rebuilt from
+    /root/reference at test time (tests/test_reference_parts.py, skipped where the reference is absent): the meshes do
+    not travel, the recorded trajectories do."""
+    from make_golden import texture_of, zigzag_policy
+    root = os.path.join(ref_import.REFERENCE_ROOT, 'PaintRLEnv')
+    for part_no, name in ((0, 'door_test'), (1, 'square')):
+        if name not in which:
+            continue
+        sys.modules.get('pybullet') and sys.modules['pybullet'].resetSimulation()
+        drv = RefDriver(root, part_no)
+        eps = {}
+        drv.configure('section', 4, 'all')
+        for s in range(3):
+            eps['g16_%s_all_%d' % (name, s)] = drv.episode(700 + s, random_policy(100 + s), max_steps=150)
+        drv.configure('section', 4, 'anchor')
+        eps['g16_%s_anchor' % name] = drv.episode(710, random_policy(110), max_steps=150)
+        sweep = zigzag_policy_grid() if part_no == 0 else zigzag_policy(-1, 2)
+        eps['g16_%s_sweep' % name] = drv.episode(711, sweep, max_steps=120, want_idx=0)
+        eps['g16_%s_sweep' % name]['texture'] = texture_of(drv)
+        drv.configure('grid', 4, 'anchor', overlap=True, turning=True)
+        eps['g16_%s_grid_penalties' % name] = drv.episode(712, zigzag_policy_grid(), max_steps=80, want_idx=0)
+        drv.configure('grid', 4, 'all', overlap=True)
+        eps['g16_%s_grid_all' % name] = drv.episode(713, random_policy(113), max_steps=80)
+        drv.configure('section', 4, 'anchor', paint_method='normal')
+        eps['g16_%s_cone' % name] = drv.episode(714, zigzag_policy_grid(), max_steps=10, want_idx=0)
+        drv.env.close()
+        sys.modules['pybullet'].resetSimulation()
+        hsi = RefDriver(root, part_no, extra={'COLOR_MODE': 'HSI'})
+        hsi.configure('section', 4, 'anchor')
+        n = 60
+        while True:                                # a shot that hits no sample makes the reference raise: stop before it
+            try:
+                ep = hsi.episode(715, zigzag_policy_grid(), max_steps=n, want_idx=0)
+                break
+            except ValueError:
+                n -= 1
+        ep['final_thick'] = np.array([int(hsi.part.texels[hsi.part.get_texel(*p)]) for p in hsi.pix], dtype=np.uint8)
+        ep['texture'] = texture_of(hsi)
+        cfg = json.loads(str(ep['cfg']))
+        cfg['color_mode'] = 'HSI'
+        ep['cfg'] = json.dumps(cfg)
+        eps['g16_%s_hsi' % name] = ep
+        hsi.env.close()
+        save_episodes(os.path.join(HERE, 'episodes_reference_%s.npz' % name), eps)
+        for k, ep in sorted(eps.items()):
+            print('%-28s steps %3d return %8.3f done %s' % (k, len(ep['actions']), float(ep['total_return']),
+                                                            bool(ep['done'][-1])), flush=True)
+
+
 def sparse_synthetic():
     """The coarse synthetic sheet ('test', Part_NO 9): the reference moves vertex rows under its kd-tree there."""
     root = os.path.join(HERE, '_synth_root')
@@ -180,6 +233,8 @@ def hsi_cone_door():
 
 if __name__ == '__main__':
     what = sys.argv[1:] or ['digests', 'big', 'door_rr']
+    if 'reference_meshes' in what:
+        reference_meshes()
     if 'hsi_cone' in what:
         hsi_cone_door()
     if 'hsi' in what:

@@ -104,3 +104,27 @@ def test_bench_launcher_names_the_failing_rank():
                           '--envs', '64', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
     assert 'of 8 exited with status' in out.stderr, out.stderr[-1500:]
+
+
+def _forced_single_rank(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      PAINTRL_FORCE_DIST='1', PAINTRL_DIST_BACKEND='gloo')
+    from paintrl_amd import distributed as pdist
+    r, lr, w = pdist.init_process_group()
+    assert torch.distributed.is_initialized() and (r, w) == (0, 1)
+    local = torch.arange(5, dtype=torch.float64)
+    g = pdist.ReturnsGatherer('cpu')
+    g.submit(local)
+    assert torch.equal(g.wait(), local) and g.count == 1
+    assert pdist.max_over_ranks(2.5, torch.device('cpu')) == 2.5
+    pdist.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(out_dir, 'ok'), 'w').write('ok')
+
+
+def test_force_dist_takes_the_collective_path_at_world_size_one(tmp_path):
+    """PAINTRL_FORCE_DIST=1: a lone rank still initialises torch.distributed and runs the gather / barrier / MAX
+    all_reduce through it (gloo here; the RCCL run of the same switch is tests/test_gpu_configs.py)."""
+    mp.spawn(_forced_single_rank, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / 'ok').read_text() == 'ok'

@@ -243,3 +243,46 @@ def test_big_part_replays_reference_episode(name):
     assert np.array_equal(st['pose'][0], ep['final_pose']) and np.array_equal(st['quat'][0], ep['final_quat'])
     assert st['total_return'][0] == float(ep['total_return'])
     env.close()
+
+
+@pytest.mark.parametrize('kw,n,steps', [
+    (dict(color_mode='HSI'), 24, 10),                               # four LDS copies of 1 234 words + the kd-walk rows
+    (dict(), 24, 10),                                               # three copies
+    (dict(color_mode='HSI', paint_method='normal'), 6, 3),          # five copies + the hit list
+    (dict(obs_mode='section', obs_grad=6), 16, 6),                  # atan2 sectors: the counters' static LDS on top
+])
+def test_reference_sized_part_with_the_stale_tree_fits_the_lds(kw, n, steps):
+    """A part of the reference's largest size (78 218 samples, mask stride 1 234 words; door_rr_big has 71 k) that also
+    carries the stale kd-tree: the masks' LDS copies are sized NEXT TO the kernels' own static LDS (candidate list, shot
+    centres, kd-walk rows: ~24 KB), so the launch takes fewer waves per workgroup instead of failing (4 waves x 4 copies x
+    1 234 x 8 B + 24 KB > 160 KB)."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    tables = synthetic_tables('test', tex_size=(560, 560))
+    assert tables.sample_pos.shape[0] > 70000 and len(tables.kd_split_dim) > 0
+    sp = start_points_for(tables, 'all')
+    hsi = kw.get('color_mode') == 'HSI'
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    env = BatchedPaintEnv(DeviceTables(tables, obs_grad=kw.get('obs_grad', 4), start_points=sp), n, max_possible_point=mpp, **kw)
+    assert env.mask_stride >= 1100
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=mpp, **kw)
+    rng = np.random.RandomState(71)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        if hsi:
+            assert np.allclose(r.cpu().numpy(), rr, rtol=0, atol=1e-12) and np.array_equal(env.thickness(), orc.thick), 'step %d' % k
+        else:
+            assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(i.cpu().numpy(), ii), 'reward, step %d' % k
+        assert np.array_equal(d.cpu().numpy(), dd), 'done, step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    assert np.array_equal(env.parts[0].mask_to_canonical(words), np.stack([orc.painted_bits(e) for e in range(n)]))
+    assert np.array_equal(env.observe().cpu().numpy(), orc.observe())
+    env.close()

@@ -180,3 +180,68 @@ def test_bench_self_launches_its_ranks(tmp_path, ranks):
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == ranks and 'world size %d' % ranks in rec['config']['parallelism']
     assert rec['value'] > 0 and rec['roofline']['avg_kernel_us'] <= 1e3 * rec['ms_per_step'] * 1.001
+
+
+_RCCL_SCRIPT = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(repo)r); sys.path.insert(0, os.path.join(%(repo)r, 'tests'))
+import torch
+import torch.distributed as dist
+from paintrl_amd import distributed as pdist, part_tables
+rank, local_rank, world = pdist.init_process_group()          # before anything else touches the GPU
+assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1, (dist.is_initialized(), world)
+from paintrl_amd.batched_env import BatchedPaintEnv
+from paintrl_amd.device_tables import DeviceTables
+from conftest import synthetic_tables
+torch.cuda.set_device(0)
+tables = synthetic_tables('door_test')
+sp = part_tables.start_points(tables, 'all')
+n, steps = 512, 40
+rng = np.random.RandomState(23)
+env = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, device='cuda:0', auto_reset=True, seed=9)
+env.reset(start_idx=rng.randint(0, len(sp), size=n))
+g = pdist.ReturnsGatherer('cuda:0')
+for k in range(steps):
+    env.step(rng.randint(0, 4, size=n))
+    if (k + 1) %% 10 == 0:
+        g.submit(env.episode_returns())                        # device-side all_gather_into_tensor on the side stream
+out = g.wait()
+torch.cuda.synchronize()
+local = env.episode_returns()
+assert out.is_cuda and out.shape == (n,) and torch.equal(out, local) and int((local != 0).sum()) > 50
+pdist.barrier()                                                # dist.barrier(device_ids=[...])
+assert pdist.max_over_ranks(1.25, 'cuda:0') == 1.25            # the MAX all_reduce of the timed region
+assert g.count == 4
+env.close()
+dist.destroy_process_group()
+print('RCCL_WORLD1_OK backend=%%s' %% 'nccl')
+'''
+
+
+def test_rccl_communicator_runs_the_gather_on_one_gpu(tmp_path):
+    """The `nccl` (= RCCL) branch of paintrl_amd/distributed.py on the one GPU there is: PAINTRL_FORCE_DIST=1 makes a
+    one-rank communicator, and init, the device-side all_gather of episode returns on the side stream, the barrier with
+    device_ids and the MAX all_reduce all execute (a fresh child process: the group is initialised before any GPU call)."""
+    script = tmp_path / 'rccl1.py'
+    script.write_text(_RCCL_SCRIPT % dict(repo=REPO))
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               PAINTRL_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env.pop('PAINTRL_DIST_BACKEND', None)
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'RCCL_WORLD1_OK backend=nccl' in out.stdout
+
+
+def test_bench_reports_the_rccl_backend_under_force_dist():
+    """`bench.py --gpus 1` with PAINTRL_FORCE_DIST=1 takes the same distributed path the N > 1 runs take (barriers, MAX over
+    ranks, the per-fragment returns gather) over a one-rank RCCL communicator, and says so in its JSON line."""
+    env = dict(os.environ, PAINTRL_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PAINTRL_DIST_BACKEND'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '60', '--warmup', '10',
+                          '--envs', '1024', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['n_gpus'] == 1 and 'backend nccl' in rec['config']['parallelism']
+    assert rec['config']['returns_gathers'] == 3 and rec['value'] > 0

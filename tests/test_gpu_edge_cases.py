@@ -388,8 +388,8 @@ def test_small_textures_use_the_one_and_two_slot_kernels(tex, kw_slots, obs_mode
 
 
 def test_cone_beam_step_on_a_side_stream_and_in_a_graph():
-    """PAINT_METHOD 'normal' forks its far kernel onto a stream of the batch and joins it again (k_cone_beams.hip): a step
-    issued on a non-default stream, and one captured into a graph and replayed, give what direct stepping gives."""
+    """PAINT_METHOD 'normal' is five launches on the caller's stream handing work lists to each other (k_cone_beams.hip): a
+    step issued on a non-default stream, and one captured into a graph and replayed, give what direct stepping gives."""
     import torch
     tables = synthetic_tables('door_test')
     n, steps = 96, 6

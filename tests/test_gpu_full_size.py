@@ -1,0 +1,172 @@
+"""The BASELINE configurations at their per-GPU size (4 096 envs) over MANY steps with the in-kernel auto-reset ON --
+what `bench.py` runs -- against the oracle on every row: observation (the terminal one through `final_obs`, the one
+after the reset through `obs`), reward, done, info, and at the end every painted bit and the whole motion state.
+
+The short full-size tests (tests/test_gpu_edge_cases.py, tests/test_gpu_configs.py: 4 steps from a fresh reset, no
+auto-reset) never see an episode boundary, a mask more than a few per cent full or the off-part termination at this
+size; these do: with random discrete-4 actions an episode lasts ~17 steps, so 60 steps are three to four
+episode ends per env.  The start point of every new episode is passed explicitly (`start_idx`), so that the oracle can
+be reset to the same one (rge:370-387).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import start_points_for, synthetic_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def _dt(tables, sp, obs_grad=4):
+    from paintrl_amd.device_tables import DeviceTables
+    return DeviceTables(tables, obs_grad=obs_grad, start_points=sp)
+
+
+class _Slices(object):
+    """The oracles of a (possibly mixed) batch: oracle k holds the envs of `index[k]` (arrays of env numbers)."""
+
+    def __init__(self, oracles, index, n):
+        self.oracles, self.index, self.n = oracles, index, n
+        self.obs_dim = oracles[0].obs_dim
+
+    def reset(self, start, mask=None):
+        out = np.zeros((self.n, self.obs_dim))
+        for o, ix in zip(self.oracles, self.index):
+            out[ix] = o.reset(start[ix], mask=None if mask is None else mask[ix])
+        return out
+
+    def step(self, a):
+        obs, rew = np.zeros((self.n, self.obs_dim)), np.zeros(self.n)
+        done, info = np.zeros(self.n, dtype=bool), np.zeros((self.n, 2))
+        for o, ix in zip(self.oracles, self.index):
+            obs[ix], rew[ix], done[ix], info[ix] = o.step(a[ix])
+        return obs, rew, done, info
+
+    def painted_bits(self, e):
+        for o, ix in zip(self.oracles, self.index):
+            k = np.nonzero(ix == e)[0]
+            if k.size:
+                return o.painted_bits(int(k[0]))
+        raise IndexError(e)
+
+    def state(self, e):
+        for o, ix in zip(self.oracles, self.index):
+            k = np.nonzero(ix == e)[0]
+            if k.size:
+                return o.state(int(k[0]))
+        raise IndexError(e)
+
+
+def _run(env, orc, n_start_of_env, steps, seed, min_episode_ends):
+    """`steps` batched steps of `env` (auto_reset=True) and of the oracle side by side; returns the number of episodes
+    that ended.  n_start_of_env: int array (N,), the size of each env's start-point table."""
+    n = env.n_envs
+    rng = np.random.RandomState(seed)
+    start = (rng.randint(0, 1 << 30, size=n) % n_start_of_env).astype(np.int32)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start)), 'reset observation'
+    ends = 0
+    fullest = 0.0
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        nxt = (rng.randint(0, 1 << 30, size=n) % n_start_of_env).astype(np.int32)
+        o, r, d, i = env.step(a, start_idx=nxt)
+        o, r, d, i = o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy(), i.cpu().numpy().copy()
+        f = env.final_obs.cpu().numpy()
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(d, dd), 'done, step %d' % k
+        assert np.array_equal(r, rr) and np.array_equal(i, ii), 'reward / info, step %d' % k
+        assert np.array_equal(o[~dd], oo[~dd]), 'observation, step %d' % k
+        assert np.array_equal(f[dd], oo[dd]), 'terminal observation, step %d' % k
+        if dd.any():
+            o2 = orc.reset(nxt, mask=dd)
+            assert np.array_equal(o[dd], o2[dd]), 'observation after the auto-reset, step %d' % k
+            ends += int(dd.sum())
+    assert ends >= min_episode_ends, ends
+    # the state the next step would start from: every painted bit, the tool, the counters
+    words = env.painted_words().cpu().numpy().view(np.uint64)
+    st = env.state()
+    for p, part in enumerate(env.parts):
+        ix = np.nonzero(env.env_part_id == p)[0]
+        bits = part.mask_to_canonical(words[ix])
+        want = np.stack([orc.painted_bits(int(e)) for e in ix])
+        assert np.array_equal(bits, want), 'painted bits of part %d' % p
+        fullest = max(fullest, float(want.mean(axis=1).max()))
+    for e in range(n):
+        s = orc.state(e)
+        assert np.array_equal(st['pose'][e], s['pose']) and np.array_equal(st['quat'][e], s['quat']), e
+        assert st['total_return'][e] == s['total_return'] and st['total_reward'][e] == s['total_reward'], e
+        assert st['step_counter'][e] == s['step_counter'] and st['terminate_counter'][e] == s['terminate_counter'], e
+        assert st['last_on_part'][e] == s['last_on_part'], e
+    return ends, fullest
+
+
+def test_headline_config_60_steps_with_auto_reset_equals_oracle():
+    """BASELINE config 2 as the bench runs it: door, section observation, 4 096 envs, anchor starts, random discrete-4
+    actions, auto-reset on -- 60 steps, more than three episode ends per env."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'anchor')
+    n = 4096
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16)
+    ends, _ = _run(env, orc, np.full(n, len(sp)), 60, 2024, 3 * n)
+    assert (env.state()['episode'] >= 2).all()
+    env.close()
+
+
+def test_headline_config_all_starts_long_episodes_equals_oracle():
+    """The same batch from the 'all' start table (episodes from the middle of the door run longer: masks fill up, section
+    counts see painted words on both sides of the lines), 60 steps."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'all')
+    n = 4096
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16)
+    ends, fullest = _run(env, orc, np.full(n, len(sp)), 60, 4048, n // 2)
+    assert fullest > 0.1                                 # some env carried a mask more than a tenth full at the end
+    env.close()
+
+
+def test_grid_overlap_turning_30_steps_with_auto_reset_equals_oracle():
+    """BASELINE config 3: door, grid observation (16 cells) + OVERLAP_PENALTY (+ TURNING_PENALTY), 4 096 envs, 30 steps."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'anchor')
+    n = 4096
+    kw = dict(obs_mode='grid', obs_grad=4, overlap_penalty=True, turning_penalty=True)
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16, **kw)
+    _run(env, orc, np.full(n, len(sp)), 30, 303, n)
+    env.close()
+
+
+def test_mixed_door_sheet_30_steps_with_auto_reset_equals_oracle():
+    """BASELINE config 5's per-GPU share: env i on the door if i is even, on the sheet if odd, 'all' start tables,
+    4 096 envs, 30 steps with auto-reset."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    door, sheet = synthetic_tables('door_test'), synthetic_tables('square')
+    sp_d, sp_s = start_points_for(door, 'all'), start_points_for(sheet, 'all')
+    n = 4096
+    ids = (np.arange(n) % 2).astype(np.int32)
+    env = BatchedPaintEnv([_dt(door, sp_d), _dt(sheet, sp_s)], n, env_part_id=ids, max_possible_point=[9148, 14350],
+                          auto_reset=True)
+    od = oracle.Oracle(door, n // 2, start_points=sp_d, max_possible_point=9148, threads=16)
+    os_ = oracle.Oracle(sheet, n // 2, start_points=sp_s, max_possible_point=14350, threads=16)
+    orc = _Slices([od, os_], [np.arange(0, n, 2), np.arange(1, n, 2)], n)
+    n_start = np.where(ids == 0, len(sp_d), len(sp_s))
+    _run(env, orc, n_start, 30, 505, n // 8)
+    env.close()
+
+
+def test_cone_beams_full_size_8_steps_equals_oracle():
+    """PAINT_METHOD 'normal' (rob:251-285, bpw:562-566) at the launch shape of the benchmark: 4 096 envs, 8 steps with
+    auto-reset, anchor starts (off-part shots, the window and the rim of the door all occur)."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables('door_test')
+    sp = start_points_for(tables, 'anchor')
+    n = 4096
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True, paint_method='normal')
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16, paint_method='normal')
+    _run(env, orc, np.full(n, len(sp)), 8, 808, 1)
+    env.close()

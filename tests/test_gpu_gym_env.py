@@ -5,7 +5,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import load_episodes
+from conftest import GOLDEN, load_episodes
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,13 @@ def test_gym_env_rollout_replays_golden_sheet_zigzag(urdf_root):
         assert done and env.get_job_status() == int(np.unpackbits(ep['snaps'][-1], bitorder='little').sum())
         img = env.render(mode='rgb_array')
         assert img.shape == (240, 240, 3) and (img[..., 0] == 255).sum() == env.get_job_status()
+        # Part.get_texture_image() of the reference at the end of this very episode (tests/golden/textures.npz): painted
+        # texels red, the rest of the front side grey, the back side green, everything else black -- byte for byte
+        want = np.load(os.path.join(GOLDEN, 'textures.npz'))
+        assert np.array_equal(env.get_texture_image(), want['g2_zigzag'])
+        assert (want['g2_zigzag'][..., 1] == 255).sum() > 5000               # the back side's label is in the picture
+        env.reset()
+        assert np.array_equal(env.get_texture_image(), want['sheet_after_reset'])
     PaintGymEnv.change_obs_mode('section', 4)
 
 
@@ -167,4 +174,27 @@ def test_robot_view_angle_diff_and_termination(urdf_root):
     assert pose.shape == (3,) and quat.shape == (4,) and abs(np.linalg.norm(quat) - 1) < 1e-9
     env.reset()
     assert env.robot.get_angle_diff() == 0.0
+    env.close()
+
+
+@pytest.mark.parametrize('tag,name,color_mode', [('door', 'g3_serpentine', 'RGB'), ('door_hsi', 'g13_hsi_serpentine', 'HSI')])
+def test_texture_image_equals_the_reference(urdf_root, tag, name, color_mode):
+    """get_texture_image() (bpw:737-738) through the Gym view on the door, COLOR_MODE 'RGB' and 'HSI' (thickness bytes in
+    all three channels of a front texel): equal to the reference's image after the reset and at the end of a recorded episode."""
+    from paintrl_amd import PaintGymEnv
+    ep = load_episodes(tag)[name]
+    want = np.load(os.path.join(GOLDEN, 'textures.npz'))
+    PaintGymEnv.change_action_mode(1, 'discrete', 4)
+    PaintGymEnv.change_obs_mode('section', 4)
+    cfg = dict(PaintGymEnv.EXTRA_CONFIG, Part_NO=0, COLOR_MODE=color_mode)
+    env = PaintGymEnv(urdf_root, with_robot=False, rollout=True, extra_config=cfg)      # rollout: start point 0
+    assert int(ep['start_idx']) == 0
+    obs = env.reset()
+    assert np.array_equal(obs, ep['obs0'])
+    assert np.array_equal(env.get_texture_image(), want['door_hsi_after_reset' if color_mode == 'HSI' else 'door_after_reset'])
+    for k, a in enumerate(ep['actions']):
+        obs, r, done, info = env.step(int(a))
+        assert np.array_equal(obs, ep['obs'][k])
+    img = env.get_texture_image()
+    assert img.dtype == np.uint8 and np.array_equal(img, want[name])
     env.close()

@@ -258,3 +258,37 @@ def test_beta_plain_is_the_reference_table():
     for _ in range(6):
         random.random()
     assert np.array_equal(part_tables.beta_plain(tables.density), ep['beams'])
+
+
+@pytest.mark.parametrize('tag,name,part,after_reset', [('sheet', 'g2_zigzag', 'square', 'sheet_after_reset'),
+                                                       ('door', 'g3_serpentine', 'door_test', 'door_after_reset'),
+                                                       ('door_hsi', 'g13_hsi_serpentine', 'door_test', 'door_hsi_after_reset')])
+def test_texture_image_equals_the_reference(tag, name, part, after_reset):
+    """part_tables.texture_image = Part.get_texture_image() of the reference (bpw:737-738 after _label_part bpw:579-592):
+    the images recorded from the imported reference after a reset and at the end of three committed episodes
+    (tests/golden/textures.npz, make_golden.py --textures), reproduced from the oracle's painted bits / thickness bytes --
+    irrelevant texels black, the back side (0, 255, 0), the front grey / red (the thickness byte in 'HSI'), and the
+    get_texel clamp's corner texel left as the texture file had it."""
+    import oracle
+    from conftest import GOLDEN, env_kwargs_from_cfg, load_episodes, synthetic_tables
+    from paintrl_amd import part_tables
+    want = np.load(os.path.join(GOLDEN, 'textures.npz'))
+    t = synthetic_tables(part)
+    ep = load_episodes(tag)[name]
+    cfg = ep['cfg']
+    mode = cfg.get('color_mode', 'RGB')
+    P = t.sample_pix.shape[0]
+    fresh = part_tables.texture_image(t, painted=np.zeros(P, dtype=bool), thickness=np.full(P, 255, dtype=np.uint8), color_mode=mode)
+    assert fresh.dtype == np.uint8 and np.array_equal(fresh, want[after_reset])
+    back = (fresh[..., 0] == 0) & (fresh[..., 1] == 255) & (fresh[..., 2] == 0)
+    assert back.sum() > 0.9 * t.back_pix.shape[0]                    # (texels in both profiles carry the front label)
+    orc = oracle.Oracle(t, 1, start_points=part_tables.start_points(t, cfg['start_mode']), color_mode=mode,
+                        **env_kwargs_from_cfg(cfg))
+    orc.reset([int(ep['start_idx'])])
+    for a in ep['actions']:
+        orc.step([a])
+    img = (part_tables.texture_image(t, thickness=orc.thick[0], color_mode='HSI') if mode == 'HSI'
+           else part_tables.texture_image(t, painted=orc.painted_bits(0)))
+    assert np.array_equal(img, want[name])
+    import hashlib
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(want[name + '_sha256'])

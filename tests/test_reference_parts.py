@@ -3,7 +3,10 @@ test time -- these tests are skipped wherever the reference is absent (the GPU b
 
 * every Part_Dict entry builds, and its static tables equal the digests recorded from the imported reference
   (tests/golden/g0_reference_parts.json, written by tests/golden/make_golden_parts.py: only digests are stored);
-* the CPU oracle replays episodes the reference recorded on its own door_rr.urdf (Part_NO 5: 17 891 samples).
+* the CPU oracle replays episodes the reference recorded on its own door_rr.urdf (Part_NO 5: 17 891 samples), and on
+  the two parts its published results use -- door_test.urdf (Part_NO 0) and square.urdf (Part_NO 1, the stale kd-tree
+  case): section / grid + penalties / 'all' starts / cone beams / COLOR_MODE 'HSI', and the texture image at the end
+  (tests/golden/episodes_reference_{door_test,square}.npz, make_golden_parts.py reference_meshes).
 """
 import hashlib
 import json
@@ -100,3 +103,47 @@ def test_oracle_replays_reference_episode_on_door_rr(name):
     st = orc.state(0)
     assert np.array_equal(st['pose'], ep['final_pose']) and np.array_equal(st['quat'], ep['final_quat'])
     assert st['total_return'] == float(ep['total_return'])
+
+
+def _reference_cases():
+    out = []
+    for part in ('door_test', 'square'):
+        path = os.path.join(GOLDEN, 'episodes_reference_%s.npz' % part)
+        if os.path.isfile(path):
+            out += [(part, n) for n in sorted(load_episodes('reference_%s' % part))]
+    return out
+
+
+@pytest.mark.parametrize('part,name', _reference_cases())
+def test_oracle_replays_reference_episode_on_the_published_parts(part, name):
+    """SURVEY 8c "in-container-only extra check": the reference's own door_test.urdf / square.urdf (rge:106-108) -- tables
+    rebuilt here from /root/reference, the recorded episode replayed by the oracle exactly (observations, rewards, done,
+    painted-texel snapshots, final pose and return; COLOR_MODE 'HSI': rewards to 1e-12, thickness bytes exactly), and where
+    the fixture holds one, the reference's texture image at the end (real pattern.jpg under the labels)."""
+    from paintrl_amd import part_tables
+    from test_oracle_golden import replay
+    ep = load_episodes('reference_%s' % part)[name]
+    cfg = ep['cfg']
+    tables = reference_tables(part + '.urdf')
+    hsi = cfg.get('color_mode', 'RGB') == 'HSI'
+    orc = oracle.Oracle(tables, 1, start_points=part_tables.start_points(tables, cfg['start_mode']),
+                        color_mode=cfg.get('color_mode', 'RGB'), **env_kwargs_from_cfg(cfg))
+
+    def reset(idx):
+        return orc.reset([idx])[0]
+
+    def step(a, want_bits):
+        obs, rew, done, info = orc.step([a])
+        return obs[0], rew[0], done[0], info[0], orc.painted_bits(0)
+
+    replay(step, reset, ep, exact=not hsi, atol=1e-12)
+    st = orc.state(0)
+    assert np.array_equal(st['pose'], ep['final_pose']) and np.array_equal(st['quat'], ep['final_quat'])
+    if hsi:
+        assert np.array_equal(orc.thick[0], ep['final_thick'])
+    else:
+        assert st['total_return'] == float(ep['total_return'])
+    if 'texture' in ep:
+        img = (part_tables.texture_image(tables, thickness=orc.thick[0], color_mode='HSI') if hsi
+               else part_tables.texture_image(tables, painted=orc.painted_bits(0)))
+        assert np.array_equal(img, ep['texture'])

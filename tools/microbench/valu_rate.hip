@@ -2,7 +2,7 @@
 // at 1 / 2 / 4 waves per SIMD (the step kernel runs at 4).  Prints cycles per wave-instruction as seen by one wave
 // (s_memtime around an unrolled stream of independent instructions) and the SIMD's throughput (wall clock).
 // Feeds bench.py's `second_bound` model (profiles/r03_valu_rate.json).
-//     hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rate.hip -o gpurun_out/valu_rate && gpurun_out/valu_rate
+//     hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rate.hip -o tools/microbench/valu_rate   (tools/collect_profiles.sh runs it)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

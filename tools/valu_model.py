@@ -21,6 +21,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tools'))
 from paintrl_amd import build as hb  # noqa: E402
 
 KERNEL = '_ZN12_GLOBAL__N_111step_kernelILi3ELb0ELb0ELb0ELi8E'       # step_kernel<3, false, false, false, 8>
@@ -73,11 +74,17 @@ def main():
         if r['waves_per_simd'] == 4:
             cyc[r['op']] = r['cycles_at_2p4ghz']
     mix = static_mix()
+    from summarise_profiles import head_commit
+    sq_commit = next((c['measured_at_commit'] for c in sq.values() if isinstance(c, dict) and c.get('measured_at_commit')), None)
     out = {'tag': tag, 'kernel': 'step_kernel<3, false, false, false, 8>', 'static_valu_mix': mix,
+           # the counters' commit if they recorded one, else the tree the static mix was taken from just now
+           'measured_at_commit': sq_commit or head_commit(),
            'measured_issue_cycles_4_waves_per_simd': cyc,
            'price_cycles': {'vop12_32bit': 2, 'vop3': 4, 'dpp_sdwa': 4, 'lane_move': 4, 'f64': 4, 'f64_trans': 16},
            'note': __doc__.split('What the microbenchmark says')[1].strip()}
     for mode, c in sq.items():
+        if not isinstance(c, dict):
+            continue
         valu, f64 = c['valu_per_wave'], c['valu_f64_per_wave']
         trans = c.get('valu_trans_f64_per_wave', 0.0) or 0.0
         other = valu - f64
