@@ -19,6 +19,12 @@
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: how this unit holds the part's table pointers)
 #include "prl_all.hpp"
 
+#ifdef PRL_FACET_TILE                      // (A/B switch, prl_ray.hpp: the ray's LDS facet tile; off)
+#define PRL_TILE_ON true
+#else
+#define PRL_TILE_ON false
+#endif
+
 #ifndef PRL_KW
 #error "compile with -DPRL_KW=1..4 (paintrl_amd/build.py)"
 #endif
@@ -103,10 +109,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    // the last-shot masks in LDS rows (prl_paint.hpp RowWords) where it pays: four mask words per lane on a part with the
-    // stale tree -- the reference's own sheet -- spilled 63 vector registers without (77.7 -> 72.4 us on the synthetic
-    // coarse sheet; the other kernels are a per cent faster with the masks in registers)
-    const WaveLds wl = wave_lds<GENSEC, KD, (KD && !HSI && KW == 4) ? KW : 0, WAVES>();
+    // (round 3 parked the last-shot masks of the four-word kernels in LDS rows -- prl_paint.hpp RowWords, WaveLds::lastrow --
+    // against 63 spilled vector registers on the reference's own sheet.  The registers were the observation's: four slots'
+    // pivot probes at once, 64 of them (prl_observe.hpp section4_accumulate); taken two slots at a time no KW = 4 kernel
+    // spills any more and the rows are not needed.)
+    const WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES, PRL_TILE_ON, true>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
     PROF_END();
+    PROF_STORE(env);
     TRACE_END(env, dn);
 }
 

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(const PartDev *part, int
     const double e[3] = {to[3 * r], to[3 * r + 1], to[3 * r + 2]};
     double t, hit[3] = {0, 0, 0};
     int hint = -1;
-    const int idx = ray_closest_wave(*(const PartDev CAS *)part, o, e, lane, t, hit, hint, wave_lds<false>().cand);
+    const int facet = ray_closest_wave(*(const PartDev CAS *)part, o, e, lane, t, hit, hint, wave_lds<false>().cand);
     if (lane == 0) {
-        tri[r] = idx;
+        tri[r] = facet >= 0 ? part->col_rank[facet] : -1;          // the reference's triangle index
         frac[r] = t;
         pos[3 * r] = hit[0];
         pos[3 * r + 1] = hit[1];

@@ -197,6 +197,31 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // threadIdx.x and 64-bit generic row addresses alive in vector registers through the whole kernel -- and, at
 // this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
 constexpr int KD_HEAP = 64;         // queued cells of the stale kd-tree walk (5 doubles each)
+
+// Convex collision sets: the records of ONE facet's vertex neighbourhood (the facet itself in lane 0, PartDev::col_nbr) staged
+// in this wave's LDS -- the "LDS-staged triangle tile" of the ray (prl_ray.hpp).  A sub-shot's ray ends on the facet the
+// previous one hit or on one that shares a vertex with it, so the five rays of a step test against LDS (one ds_read of 96
+// bytes per lane) instead of walking global memory twice per ray (neighbour list, then records); the tile of a newly entered
+// facet is fetched by LDS-DMA (global_load_lds_dwordx4: no vector registers) under the hook-point search of the same
+// sub-shot.  Chunk c of lane l's record lives at rec[c][l]: what one DMA instruction writes (wave-uniform base + lane * 16).
+constexpr int TILE_LANES = 32;      // = NBR_WIDTH of paintrl_amd/device_tables.py; sets with wider lists take the global path
+struct FacetTile {
+    f64x2 rec[6][TILE_LANES];       // v0 e1 e2 | edge margin | |e1 x e2|^2 | orient   (PartDev::col_rec)
+    int id[TILE_LANES];             // facet of lane l, -1: none
+    int rank[TILE_LANES];           // its reference index (PartDev::col_rank)
+    int facet;                      // whose neighbourhood is resident, -1: none
+    int pad_[3];
+};
+
+// Records gathered by a few lanes -- the <= 12 triangles around a vertex (192 bytes each), the <= 32 facets around a facet (96
+// bytes) -- cost one vector-memory instruction per 16-byte chunk of the record when every candidate lane fetches its own
+// (thirteen for a hook point), and the texture addresser takes ~19 cycles per instruction whatever its width: at sixteen
+// waves a CU it was busy 61 % of the step (TA_TA_BUSY, profiles/r03_sq_counters.txt).  record_gather spreads the chunks of
+// all candidates over the 64 lanes instead (chunk f = record f / C, piece f % C: two or three instructions), parks them in
+// this wave's LDS in that order, and the candidate lanes read their records back from there -- as does the winner's tail,
+// which no longer is a dependent round trip of its own.
+constexpr int GATHER_CHUNKS = 192;  // 16 triangle records of 12 chunks, or 32 facet records of 6
+
 struct WaveLds {
     int *cand;          // [64]
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
@@ -204,16 +229,21 @@ struct WaveLds {
     double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
     uint64_t *lastrow;  // [2][64 * KW]: the last-shot mask and its successor while the ball painter runs (step_kernel; nullptr:
                         // both stay in registers)
+    FacetTile *tile;    // the ray's facet tile, or nullptr (kernels that do not stage one: the ray then reads global memory)
+    f64x2 *gather;      // [GATHER_CHUNKS]: where a few lanes' records are fetched by ALL lanes (record_gather below), or nullptr
 };
-template <bool GENSEC, bool KD = false, int LASTROW_KW = 0, int WAVES = MAX_WAVES_PER_WG>
+template <bool GENSEC, bool KD = false, int LASTROW_KW = 0, int WAVES = MAX_WAVES_PER_WG, bool TILE = false, bool GATHER = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[WAVES][64];
     __shared__ double s_centres[WAVES][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? WAVES : 1][128];
     __shared__ double s_kd[KD ? WAVES : 1][KD ? KD_HEAP * 5 : 1];
     __shared__ uint64_t s_last[LASTROW_KW ? WAVES : 1][LASTROW_KW ? 2 * 64 * LASTROW_KW : 1];
+    __shared__ FacetTile s_tile[TILE ? WAVES : 1];
+    __shared__ f64x2 s_gather[GATHER ? WAVES : 1][GATHER ? GATHER_CHUNKS : 1];
     const int w = rfl((int)(threadIdx.x >> 6));
-    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], LASTROW_KW ? s_last[w] : nullptr};
+    return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], LASTROW_KW ? s_last[w] : nullptr,
+                   TILE ? &s_tile[w] : nullptr, GATHER ? s_gather[w] : nullptr};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

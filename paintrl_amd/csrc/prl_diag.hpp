@@ -125,7 +125,47 @@ __device__ unsigned long long g_pol_stamps[8];          // policy_forward of wor
     } while (0)
 #endif
 
-#ifdef PRL_PHASE_TIMING
+#if defined(PRL_WAVE_TRACE) && !defined(PRL_PHASE_TIMING)
+// The trace build also splits each wave's life by phase: the STAMP points of the step add the s_memrealtime ticks (10 ns)
+// since the previous stamp to lane <phase> of ONE vector register (a lane move each way, no memory, two scalar registers for
+// the last stamp) -- the per-phase atomics of PRL_PHASE_TIMING tripled the kernel's run time.  Stored per env at PROF_END.
+enum { PH_LOAD = 0, PH_RAY, PH_VERTEX, PH_BARY, PH_MATH, PH_BALL, PH_APPLY, PH_OBS, PH_STORE, PH_COUNT };
+__device__ unsigned g_wave_phase[16 * PRL_TRACE_ENVS];
+struct Prof {
+    unsigned acc;       // lane k: ticks of phase k
+    unsigned prev;      // wave-uniform
+};
+#define PROF_ARG , Prof &prof
+#define PROF_PASS , prof
+#define PROF_BEGIN()                                          \
+    Prof prof;                                                \
+    prof.acc = 0;                                             \
+    prof.prev = (unsigned)__builtin_amdgcn_s_memrealtime()
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STAMP(ph)                                                                                        \
+    do {                                                                                                 \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memrealtime();                                \
+        const unsigned cur_ = (unsigned)__builtin_amdgcn_readlane((int)prof.acc, (ph));                  \
+        const unsigned new_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(cur_ + (now_ - prof.prev)));  \
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(prof.acc) : "s"(new_), "n"(ph));                 \
+        prof.prev = now_;                                                                                \
+    } while (0)
+#else                                    // (the host pass of the compiler only has to parse the device functions)
+#define STAMP(ph) \
+    do {          \
+    } while (0)
+#endif
+#define PROF_END() \
+    do {           \
+    } while (0)
+#define PROF_STORE(env)                                                                                  \
+    do {                                                                                                 \
+        if ((env) < PRL_TRACE_ENVS && (threadIdx.x & 63) < 16) g_wave_phase[16 * (env) + (threadIdx.x & 63)] = prof.acc; \
+    } while (0)
+#elif defined(PRL_PHASE_TIMING)
+#define PROF_STORE(env) \
+    do {                \
+    } while (0)
 // (cdna_hip_programming.md "In-kernel stamps"): the stamps go to a buffer nothing else reads.  ONE phase is
 // accumulated per build (-DPRL_PHASE_TIMING=<phase index>, or -1 for the whole kernel): the accumulator and the
 // previous stamp then fit in four scalar registers and the build keeps the product kernel's register allocation
@@ -163,6 +203,9 @@ struct Prof {
     } while (0)
 #define PROF_END() \
     do {           \
+    } while (0)
+#define PROF_STORE(env) \
+    do {                \
     } while (0)
 #define STAMP(ph) \
     do {          \

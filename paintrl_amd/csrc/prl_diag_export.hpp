@@ -36,6 +36,13 @@ int prl_debug_wave_trace(unsigned long long *out, int n_envs) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
     return PRL_OK;
 }
+#ifndef PRL_PHASE_TIMING
+int prl_debug_wave_phase(unsigned *out, int n_envs) {            // [n_envs][16] ticks (10 ns) per phase of the last launch
+    if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_phase), sizeof(unsigned) * 16 * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;
+    return PRL_OK;
+}
+#endif
 int prl_debug_wave_trace16(unsigned long long *out, int n_envs) {
     if (n_envs > PRL_TRACE_ENVS) n_envs = PRL_TRACE_ENVS;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace16), sizeof(unsigned long long) * (size_t)n_envs) != hipSuccess) return PRL_E_HIP;

@@ -144,42 +144,46 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     // once: the word's eight pivots (samples 7, 15, .. 63) name the group of eight that holds the boundary, the
     // group itself gives the position.
     // Above the line the rule reads  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043).
-    {
+    // (four slots' probes at once are 64 vector registers of pivots: KW = 4 takes them two slots at a time -- one round trip
+    // more for the reference's 14 482-sample sheet, and no spilled registers)
+    constexpr int G = KW == 4 ? 2 : KW;
+#pragma unroll
+    for (int k0 = 0; k0 < KW; k0 += G) {
         bool any = false;
 #pragma unroll
-        for (int k = 0; k < KW; ++k) any = any || vline[k];
+        for (int k = k0; k < k0 + G; ++k) any = any || vline[k];
         if (ballot64(any)) {
             const f64x4 GAS *pv = reinterpret_cast<const f64x4 GAS *>(P.word_pivot);
             const f64x4 GAS *sx4 = reinterpret_cast<const f64x4 GAS *>(sx);
-            int grp[KW_MAX];
+            int grp[G];
             {
-                f64x4 pa[KW_MAX], pb[KW_MAX];
+                f64x4 pa[G], pb[G];
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const int w = vline[k] ? lane + 64 * (slot0 + k) : 0;    // other lanes probe word 0: harmless, in bounds
+                for (int k = 0; k < G; ++k) {
+                    const int w = vline[k0 + k] ? lane + 64 * (slot0 + k0 + k) : 0;    // other lanes probe word 0: harmless, in bounds
                     pa[k] = ldg(pv, 2 * w);
                     pb[k] = ldg(pv, 2 * w + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // the slots' probes travel together: one round trip
 #pragma unroll
-                for (int k = 0; k < KW; ++k)
+                for (int k = 0; k < G; ++k)
                     grp[k] = (pa[k].x < x1) + (pa[k].y < x1) + (pa[k].z < x1) + (pa[k].w < x1) + (pb[k].x < x1) + (pb[k].y < x1) +
                              (pb[k].z < x1) + (pb[k].w < x1);
             }
-            int pos[KW_MAX];
-            bool eq[KW_MAX];
+            int pos[G];
+            bool eq[G];
             {
-                f64x4 ga[KW_MAX], gb[KW_MAX];
+                f64x4 ga[G], gb[G];
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const int w = vline[k] ? lane + 64 * (slot0 + k) : 0;
+                for (int k = 0; k < G; ++k) {
+                    const int w = vline[k0 + k] ? lane + 64 * (slot0 + k0 + k) : 0;
                     const int g8 = grp[k] < 8 ? grp[k] : 7;                  // grp = 8: the whole word lies left of x1
                     ga[k] = ldg(sx4, 16 * w + 2 * g8);
                     gb[k] = ldg(sx4, 16 * w + 2 * g8 + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
+                for (int k = 0; k < G; ++k) {
                     const int in = (ga[k].x < x1) + (ga[k].y < x1) + (ga[k].z < x1) + (ga[k].w < x1) + (gb[k].x < x1) + (gb[k].y < x1) +
                                    (gb[k].z < x1) + (gb[k].w < x1);
                     pos[k] = grp[k] < 8 ? 8 * grp[k] + in : 64;
@@ -189,15 +193,16 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
                 }
             }
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                int ub = pos[k];
-                if (ballot64(eq[k] && vline[k])) {                  // a sample exactly on the line: the run of equals ends at samp_ub
-                    const int at = ((vline[k] ? lane + 64 * (slot0 + k) : 0) << 6) + (pos[k] < 64 ? pos[k] : 63);
-                    if (eq[k]) ub = (int)ldg(P.samp_ub, at);
+            for (int kk = 0; kk < G; ++kk) {
+                const int k = k0 + kk;
+                int ub = pos[kk];
+                if (ballot64(eq[kk] && vline[k])) {                 // a sample exactly on the line: the run of equals ends at samp_ub
+                    const int at = ((vline[k] ? lane + 64 * (slot0 + k) : 0) << 6) + (pos[kk] < 64 ? pos[kk] : 63);
+                    if (eq[kk]) ub = (int)ldg(P.samp_ub, at);
                 }
                 if (x1 != x1) ub = 64;                              // NaN: nothing is greater either
                 if (vline[k]) {
-                    const uint64_t lt = pos[k] >= 64 ? ~0ull : ((1ull << pos[k]) - 1);
+                    const uint64_t lt = pos[kk] >= 64 ? ~0ull : ((1ull << pos[kk]) - 1);
                     const uint64_t ng = ub >= 64 ? ~0ull : ((1ull << ub) - 1);
                     const uint64_t v = valid[k], u = valid[k] & ~painted[k];
                     const uint64_t vg = __popcll(v & ~ng), vl = __popcll(v & lt), ve = __popcll(v) - vg - vl;

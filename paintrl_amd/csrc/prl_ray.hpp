@@ -74,15 +74,11 @@ __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], doub
 
 // The same test on the facet record of a convex set (one 96-byte gather per lane instead of ten
 // strided loads); `interior` reports a hit that meets the single-facet criterion of ray_closest_wave.
-__device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
-                                       double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
+__device__ __forceinline__ void mt_rec_core(int i, const f64x2 r0, const f64x2 r1, const f64x2 r2, const f64x2 r3, const f64x2 r4,
+                                            const f64x2 r5, int rk, const double o[3], double d0, double d1, double d2, double dd,
+                                            double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
     interior = false;
     if (i >= 0) {
-        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
-        const int i6 = i * 6;
-        const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4),
-                    r5 = ldg(r, i6 + 5);
-        const int rk = ldg(P.col_rank, i);
         const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
         const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
         const double p0 = d1 * e22 - d2 * e21;
@@ -111,6 +107,55 @@ __device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], doub
     }
 }
 
+__device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
+                                       double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
+    f64x2 r0 = {0, 0}, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+    int rk = 0;
+    if (i >= 0) {
+        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
+        const int i6 = i * 6;
+        r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4), r5 = ldg(r, i6 + 5);
+        rk = ldg(P.col_rank, i);
+    }
+    mt_rec_core(i, r0, r1, r2, r3, r4, r5, rk, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+}
+
+// ---------------------------------------------------------------- the facet tile (prl_device.hpp FacetTile)
+typedef __attribute__((address_space(3))) void *lds_void_p;
+
+// lane l's entry of the vertex neighbourhood of `facet` (itself in lane 0): the one load the records' addresses depend on
+__device__ __forceinline__ int tile_ids_load(PartRef P, int facet, int lane) {
+    return lane < P.nbr_width ? ldg(P.col_nbr, facet * P.nbr_width + lane) : -1;
+}
+
+// Starts the copy of the records (and reference indices) of `ids` into the tile: seven LDS-DMA instructions that write
+// wave-uniform base + lane * size, no vector register in between; the tile may be read after `s_waitcnt vmcnt(0)`
+// (tile_wait).  The caller guarantees P.nbr_width <= TILE_LANES.
+__device__ __forceinline__ void tile_fill(PartRef P, FacetTile *T, int facet, int ids, int lane) {
+    if (lane < TILE_LANES) {
+        T->id[lane] = ids;
+        if (ids >= 0) {
+            const f64x2 GAS *src = reinterpret_cast<const f64x2 GAS *>(P.col_rec) + (uint32_t)ids * 6u;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const GAS void *>(src + c), (lds_void_p)&T->rec[c][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const GAS void *>(P.col_rank + (uint32_t)ids), (lds_void_p)&T->rank[0], 4, 0, 0);
+        }
+    }
+    if (lane == 0) T->facet = facet;
+}
+
+__device__ __forceinline__ void tile_wait() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// what a ray leaves for the hook-point search to start (sub_shot): the next tile's facet and its neighbour ids
+struct TilePrefetch {
+    int facet;       // -1: nothing to fetch
+    int ids;         // per lane
+};
+
 // Lane holding the wave's best (t, rank); -1 if no lane has a hit.
 __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double &tmin) {
     if (ballot64(best_t < INFINITY) == 0) return -1;
@@ -121,6 +166,7 @@ __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double
     return __builtin_ctzll(ballot64(best_t == tmin && best_r == rmin));
 }
 
+// Returns the collision-set position of the facet hit (= the new `hint`; its reference index is PartDev::col_rank of it), or -1.
 // `hint` (in/out): collision-set position of the facet hit by the previous ray of this env, or -1.
 //
 // Convex fast path (collision set = boundary of a convex polytope, i.e. hull mode): a segment that
@@ -130,20 +176,79 @@ __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double
 // closest hit of the whole set is the best over that facet's own neighbourhood.  Anything else (no
 // hit there, an exit hit, a facet without a neighbour list) takes the general search below.
 // `cand`: this wave's 64-int LDS row (WaveLds::cand).
+// `tile` / `pf` (optional): this wave's facet tile and where to leave the next one's prefetch.  With a tile the facet of `hint`
+// and the facets around it are tested in ONE pass on LDS-resident records -- lane 0 holds `hint` itself, so the pass
+// subsumes test (1) below: an interior entry in any lane is the closest hit of the whole set, same arithmetic.
 __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3], int lane, double &t_out,
-                                double hit[3], int &hint, int *cand) {
+                                double hit[3], int &hint, int *cand, FacetTile *tile = nullptr, TilePrefetch *pf = nullptr) {
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
     double best_t = INFINITY, best_det = 0, tmin = INFINITY;
     int best_r = 0x7fffffff, best_i = -1, win = -1;
 #ifdef PRL_FORCE_GENERAL_RAY                         // diagnostic build: never take the convex fast path
     hint = -1;
 #endif
-    if (P.col_convex && hint >= 0) {
-        // (1) The previous facet alone, wave-uniform on scalar-loaded data.  If the segment ENTERS the hull
-        // through it at a point at least FACET_EDGE_MARGIN away from its edges, and not at a grazing
-        // angle, no other facet can report a hit at or before that point: a second hit there would lie
-        // in the other facet's 1e-9 tolerance fringe, i.e. within nanometres of an edge of the entered
-        // facet.  The result is then this facet's own Moller-Trumbore value, arithmetic as in mt_one.
+#ifndef PRL_FACET_TILE                               // A/B switch: the LDS tile lost to the scalar test + global rounds
+    tile = nullptr;                                  // (profiles/r04_ab_log.txt: 42.0 against 40.2 us), so it is off
+#endif
+    if (tile && P.nbr_width > TILE_LANES) tile = nullptr;
+    if (pf) pf->facet = -1;
+    if (P.col_convex && hint >= 0 && tile) {
+        // (lane 0 wrote `facet` and the tile's ids in tile_fill, every lane reads them: order the two within the wave)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (rfl(tile->facet) != hint) tile_fill(P, tile, hint, tile_ids_load(P, hint, lane), lane);       // (not prefetched)
+        tile_wait();
+        WCNT(4, 1);
+        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
+        int i1 = -1, rk = 0;
+        f64x2 r0 = {0, 0}, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
+        if (lane < TILE_LANES) {
+            i1 = tile->id[lane];
+            rk = tile->rank[lane];
+            r0 = tile->rec[0][lane], r1 = tile->rec[1][lane], r2 = tile->rec[2][lane], r3 = tile->rec[3][lane], r4 = tile->rec[4][lane],
+            r5 = tile->rec[5][lane];
+        }
+        bool interior;
+        mt_rec_core(i1, r0, r1, r2, r3, r4, r5, rk, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+        const uint64_t im = ballot64(interior);
+        if (im) {
+            win = __builtin_ctzll(im);
+            tmin = bcast_d(best_t, win);
+            if (win == 0) WCNT(7, 1);
+        } else {
+            win = ray_winner_lane(best_t, best_r, tmin);
+            if (win >= 0) {
+                const int f = __builtin_amdgcn_readlane(best_i, rfl(win));
+                const double fdet = bcast_d(best_det, win);
+                const int i2 = lane < P.nbr_width ? ldg(P.col_nbr, f * P.nbr_width + lane) : -1;
+                const bool entering = (double)P.col_orient[f] * fdet > 0;
+                if (entering && ballot64(i2 >= 0) != 0) {
+                    if (f != hint) {
+                        WCNT(4, 16);
+                        mt_rec(P, i2, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
+                        win = ray_winner_lane(best_t, best_r, tmin);
+                    }
+                } else {
+                    win = -1;
+                }
+            }
+        }
+        if (win < 0) {
+            best_t = INFINITY;
+            best_r = 0x7fffffff;
+            best_i = -1;
+        }
+    }
+    // (the record table's address is read together with the flag, not behind it: one scalar round trip less per ray)
+    const uint64_t col_rec_addr = (uint64_t)P.col_rec;
+#ifdef PRL_WIDE_FACET_LOAD
+    asm volatile("" ::"s"(col_rec_addr), "s"(P.col_convex));       // (pins both loads here: the compiler sinks the address' otherwise)
+#endif
+    if (tile) {
+    } else if (P.col_convex && hint >= 0) {
+#ifndef PRL_WIDE_FACET_LOAD                         // (default: the round-3 form; the whole-record form below measured +0.4 us)
+        // (1) The previous facet alone, wave-uniform on scalar-loaded data: fields read where first needed, early exits.
         {
             const int h = rfl(hint);
             const double CAS *r = reinterpret_cast<const double CAS *>((uint64_t)P.col_rec) + (size_t)h * 12;
@@ -173,9 +278,51 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
                 hit[0] = o[0] + t * d0;
                 hit[1] = o[1] + t * d1;
                 hit[2] = o[2] + t * d2;
-                return reinterpret_cast<const int CAS *>((uint64_t)P.col_rank)[h];
+                return h;
             }
         }
+#else
+        // (1) The previous facet alone, wave-uniform on scalar-loaded data.  If the segment ENTERS the hull
+        // through it at a point at least FACET_EDGE_MARGIN away from its edges, and not at a grazing
+        // angle, no other facet can report a hit at or before that point: a second hit there would lie
+        // in the other facet's 1e-9 tolerance fringe, i.e. within nanometres of an edge of the entered
+        // facet.  The result is then this facet's own Moller-Trumbore value, arithmetic as in mt_one.
+        // [-DPRL_WIDE_FACET_LOAD, A/B] The record is fetched whole (two scalar loads, one wait) and the test evaluated without
+        // early exits: six dependent scalar round trips fewer per ray -- and eight more spilled scalar registers:
+        // 40.46 against 40.07 us (profiles/r04_ab_log.txt), so the form above stays.
+        {
+            const int h = rfl(hint);
+            typedef double d8 __attribute__((ext_vector_type(8), aligned(8)));
+            typedef double d4 __attribute__((ext_vector_type(4), aligned(8)));
+            const double CAS *r = reinterpret_cast<const double CAS *>(col_rec_addr) + (size_t)h * 12;
+            const d8 ra = *reinterpret_cast<const d8 CAS *>(r);
+            const d4 rb = *reinterpret_cast<const d4 CAS *>(r + 8);
+            const double e10 = ra[3], e11 = ra[4], e12 = ra[5], e20 = ra[6], e21 = ra[7], e22 = rb[0];
+            const double p0 = d1 * e22 - d2 * e21;
+            const double p1 = d2 * e20 - d0 * e22;
+            const double p2 = d0 * e21 - d1 * e20;
+            const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+            const double inv = 1.0 / det;                       // (a degenerate det fails the first condition below)
+            const double s0 = o[0] - ra[0], s1 = o[1] - ra[1], s2 = o[2] - ra[2];
+            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+            const double q0 = s1 * e12 - s2 * e11;
+            const double q1 = s2 * e10 - s0 * e12;
+            const double q2 = s0 * e11 - s1 * e10;
+            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+            const double m = rb[1], dd = (d0 * d0 + d1 * d1) + d2 * d2;
+            const bool inside = (fabs(det) >= RAY_EPS_DET) & (u >= m) & (v >= m) & ((u + v) <= 1.0 - m) & (t >= 0.0) & (t <= 1.0) &
+                                (rb[3] * det > 0) & (det * det >= FACET_MIN_COS2 * dd * rb[2]);
+            if (rfl(inside)) {
+                WCNT(7, 1);
+                t_out = t;
+                hit[0] = o[0] + t * d0;
+                hit[1] = o[1] + t * d1;
+                hit[2] = o[2] + t * d2;
+                return h;
+            }
+        }
+#endif
         // (2) The facets that share a vertex with it, one per lane.  A lane whose facet is entered at an
         // interior point holds the closest hit of the whole set by the same argument (there is at most
         // one such lane): no reduction, no second round.
@@ -264,11 +411,15 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         return -1;
     }
     hint = __builtin_amdgcn_readlane(best_i, rfl(win));
+    if (tile && pf && P.col_convex && rfl(tile->facet) != hint) {     // the next ray starts from this facet: its tile, early
+        pf->facet = hint;
+        pf->ids = tile_ids_load(P, hint, lane);
+    }
     t_out = tmin;
     hit[0] = o[0] + tmin * d0;
     hit[1] = o[1] + tmin * d1;
     hit[2] = o[2] + tmin * d2;
-    return __builtin_amdgcn_readlane(best_r, rfl(win));
+    return hint;
 }
 
 }  // namespace

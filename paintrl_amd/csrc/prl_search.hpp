@@ -315,28 +315,79 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
 
+// ---------------------------------------------------------------- records of a few lanes, fetched by all (prl_device.hpp)
+// Lane j < n holds record id[j] >= 0 of a table of C-chunk records (16-byte chunks).  All n * C chunks are fetched in
+// ceil(n C / 64) instructions -- lane l of trip i takes chunk f = 64 i + l: piece f % C of record f / C -- and stored at
+// buf[f]; record j then lies at buf[j C .. j C + C - 1].  n * C <= GATHER_CHUNKS.  Ends with the wave-scope fence that
+// orders the stores before other lanes' reads.
+template <int C>
+__device__ __forceinline__ void record_gather(const f64x2 GAS *table, int id, int n, int lane, f64x2 *buf) {
+    static_assert(C == 12 || C == 6, "division constants below");
+    const int total = n * C;
+    constexpr int TRIPS = GATHER_CHUNKS / 64;
+    f64x2 v[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int f = 64 * i + lane;
+        const int j = C == 12 ? (f * 43691) >> 19 : (f * 43691) >> 18;          // f / C for f < 2048
+        const int piece = f - C * j;
+        const int rec = __shfl(id, j);                                          // (lanes beyond the records: some id, unused)
+        if (64 * i < total && f < total) v[i] = ldg(table, rec * C + piece);
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        const int f = 64 * i + lane;
+        if (64 * i < total && f < total) buf[f] = v[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------- bpw:525-534 _get_hook_point (+508-523)
 // Also returns what the chosen triangle's normal implies for the tool: the quaternion of rob:93-100 and the shot
 // centre of rob:277-278 (pose + R(quat)(0, 0, 0.1)), read from the triangle record's precomputed tail.
 // `tri` receives the chosen triangle (index into the triangle records).  KD: the part carries the reference's stale
 // vertex kd-tree (kd_heap = this wave's LDS rows for its walk); otherwise the exact nearest vertex.
+// `tile` / `pf`: the ray's facet tile and the prefetch the last ray left (prl_ray.hpp): its records are sent on their way to
+// LDS here, between the two searches -- the neighbour ids have arrived under the vertex search, the copy lands under the
+// triangle search.
+// `gather`: this wave's record_gather buffer, or nullptr (then every candidate lane fetches its own record).
 template <bool KD>
 __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3], double quat[4],
-                                double center[3], int &tri, double *kd_heap PROF_ARG) {
+                                double center[3], int &tri, double *kd_heap, FacetTile *tile, const TilePrefetch &pf,
+                                f64x2 *gather PROF_ARG) {
     int vidx;
     if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap) : nearest_vertex_wave(P, pt, lane);
     else vidx = nearest_vertex_wave(P, pt, lane);
+    if (tile && pf.facet >= 0) tile_fill(P, tile, pf.facet, pf.ids, lane);
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;
     const int ti = lane < P.adj_width ? ldg(P.vadj, vidx * P.adj_width + lane) : -1;   // file order, -1 = pad
-    if (ballot64(ti >= 0) == 0) return false;
+    const uint64_t cmask = ballot64(ti >= 0);
+    if (cmask == 0) return false;
     bool inside = false, ok = false;
     double m = -INFINITY, n0, n1, n2;
+    const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(P.tri_rec);
+    // the candidates' records through LDS (record_gather) where the kernel has the buffer, the candidates are the first
+    // lanes (rows of vadj are padded at the end) and fit it
+    const int n_cand = __popcll(cmask);
+#ifdef PRL_NO_GATHER                                  // A/B switch
+    const bool coop = false;
+#else
+    const bool coop = gather != nullptr && (cmask & (cmask + 1)) == 0 && n_cand * (TRI_REC / 2) <= GATHER_CHUNKS;
+#endif
+    if (coop) record_gather<TRI_REC / 2>(r2, ti, n_cand, lane, gather);
     if (ti >= 0) {
-        const f64x2 GAS *r2 = reinterpret_cast<const f64x2 GAS *>(P.tri_rec);
-        const int t8 = ti * (TRI_REC / 2);
-        const f64x2 q0 = ldg(r2, t8), q1 = ldg(r2, t8 + 1), q2 = ldg(r2, t8 + 2), q3 = ldg(r2, t8 + 3), q4 = ldg(r2, t8 + 4),
-                    q5 = ldg(r2, t8 + 5), q6 = ldg(r2, t8 + 6);
+        f64x2 q0, q1, q2, q3, q4, q5, q6;
+        if (coop) {
+            const f64x2 *g = gather + lane * (TRI_REC / 2);
+            q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3], q4 = g[4], q5 = g[5], q6 = g[6];
+        } else {
+            const int t8 = ti * (TRI_REC / 2);
+            q0 = ldg(r2, t8), q1 = ldg(r2, t8 + 1), q2 = ldg(r2, t8 + 2), q3 = ldg(r2, t8 + 3), q4 = ldg(r2, t8 + 4), q5 = ldg(r2, t8 + 5),
+            q6 = ldg(r2, t8 + 6);
+        }
         // a = q0.x q0.y q1.x | v0 = q1.y q2.x q2.y | v1 = q3.x q3.y q4.x | d00 q4.y d01 q5.x d11 q5.y inv q6.x | n q6.y q7.x q7.y
         const double x0 = pt[0] - q0.x, x1 = pt[1] - q0.y, x2 = pt[2] - q1.x;
         const double d20 = dot3_np(x0, x1, x2, q1.y, q2.x, q2.y);
@@ -373,8 +424,14 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     // dependent read but costs more than it gains, 48.0 -> 48.8 us)
     const int tj = __builtin_amdgcn_readlane(ti, rfl(j));
     tri = tj;
-    const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)tj * (TRI_REC / 2);
-    const f64x2 t6 = rj[6], t7 = rj[7], t8 = rj[8], t9 = rj[9], t10 = rj[10], t11 = rj[11];
+    f64x2 t6, t7, t8, t9, t10, t11;
+    if (coop) {                                     // it came with the candidates: no further round trip
+        const f64x2 *g = gather + rfl(j) * (TRI_REC / 2);
+        t6 = g[6], t7 = g[7], t8 = g[8], t9 = g[9], t10 = g[10], t11 = g[11];
+    } else {
+        const f64x2 GAS *rj = reinterpret_cast<const f64x2 GAS *>(P.tri_rec) + (uint32_t)tj * (TRI_REC / 2);
+        t6 = rj[6], t7 = rj[7], t8 = rj[8], t9 = rj[9], t10 = rj[10], t11 = rj[11];
+    }
     n0 = t6.y;
     n1 = t7.x;
     n2 = t7.y;

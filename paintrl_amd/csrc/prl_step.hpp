@@ -71,7 +71,8 @@ struct ShotCtx {
     int facet_hint, last_tri;
 };
 
-__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double d1, double d2, ShotCtx &X) {
+__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double d1, double d2, ShotCtx &X, FacetTile *tile = nullptr,
+                                            int lane = 0) {
     X.cur_pose[0] = S.pose[0];
     X.cur_pose[1] = S.pose[1];
     X.cur_pose[2] = S.pose[2];
@@ -81,6 +82,13 @@ __device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double
     X.d2 = uni_d(d2);
     // facet hit by the previous ray, also across steps (convex fast path); only a cache, but it indexes a table
     X.facet_hint = (S.facet_hint >= 0 && S.facet_hint < P.n_col_pad) ? S.facet_hint : -1;
+#ifdef PRL_FACET_TILE
+    if (tile) {          // the ray's facet tile (prl_ray.hpp): nothing resident at the start of a launch; the hint's goes on its way
+        if (lane == 0) tile->facet = -1;
+        if (P.col_convex && X.facet_hint >= 0 && P.nbr_width <= TILE_LANES)
+            tile_fill(P, tile, X.facet_hint, tile_ids_load(P, X.facet_hint, lane), lane);
+    }
+#endif
     // The tool quaternion is a function of the tool normal alone (rob:93-100), so it is not carried through the
     // shots (eight vector registers): after the last one it is read from the record of the triangle that shot
     // hooked to, or recomputed from the normal after a miss -- the same arithmetic either way.
@@ -107,11 +115,17 @@ __device__ __forceinline__ void sub_shot(PartRef P, int lane, EnvState &S, ShotC
     double t, hit[3], pos[3], orn[3];
     STAMP(PH_MATH);
 #if defined(PRL_CUT) && PRL_CUT >= 5
+    TilePrefetch pf;
+    pf.facet = -1;
+    pf.ids = -1;
     bool on = true;
     t = 0;
     hit[0] = end[0] * 0.1 + pt[0] * 0.9, hit[1] = end[1] * 0.1 + pt[1] * 0.9, hit[2] = end[2] * 0.1 + pt[2] * 0.9;
 #else
-    bool on = ray_closest_wave(P, pt, end, lane, t, hit, X.facet_hint, wl.cand) >= 0;
+    TilePrefetch pf;
+    pf.facet = -1;
+    pf.ids = -1;
+    bool on = ray_closest_wave(P, pt, end, lane, t, hit, X.facet_hint, wl.cand, wl.tile, &pf) >= 0;
 #endif
     STAMP(PH_RAY);
 #if defined(PRL_CUT) && PRL_CUT >= 4
@@ -120,7 +134,7 @@ __device__ __forceinline__ void sub_shot(PartRef P, int lane, EnvState &S, ShotC
         quat[0] = quat[1] = quat[2] = 0, quat[3] = 1;
     }
 #else
-    if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, X.last_tri, wl.kd_heap PROF_PASS);
+    if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, X.last_tri, wl.kd_heap, wl.tile, pf, wl.gather PROF_PASS);
 #endif
     if (!on) {
         X.last_tri = -1;
@@ -171,7 +185,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
                                            const double *state_rec, const MaskIO &masks, uint64_t painted[KW_MAX],
                                            uint64_t last[KW_MAX], double succeeded_f, int pixel_counter, int counter_before,
                                            double new_angle, int facet_hint, const RowIO &a, const WaveLds &wl,
-                                           const uint64_t *last_row = nullptr PROF_ARG) {
+                                           const uint64_t *last_row PROF_ARG) {
     // last_row: where the masks' last-shot words wait in LDS instead of `last` (step_env with WaveLds::lastrow), or nullptr
     constexpr bool BIG = KW == 0;
     PRIO_YOUNG_DECL();
@@ -286,7 +300,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
     ShotCtx X;
-    shots_begin(P, S, d1, d2, X);
+    shots_begin(P, S, d1, d2, X, wl.tile, lane);
     new_angle = uni_d(new_angle);
     double *cen = wl.cen;
 #if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away
@@ -436,6 +450,30 @@ struct BigMasks {
 };
 
 // The masks of env `env` in HBM: word w of a mask is read / written by lane w & 63 into slot w >> 6.
+// Every launch reads each env's two mask rows once and writes them once -- 21 MB at 4 096 envs of the door, through 8 x 4 MB of
+// L2 that also have to hold the 2 MB of part tables every sub-shot reads through a chain of dependent loads.  Plain loads
+// and stores leave the rows in L2 as most recently used lines and push tables out: measured, each XCD fetches
+// 1.2 MB of tables again in every launch (profiles/hbm_traffic.json, round 3), each first touch at the fabric's latency
+// (tools/microbench/l2_cold: 358 ns a dependent hop against 90 ns from L2).  Moving the rows with the
+// non-temporal hint (`nt`: allocated for streaming, first to be evicted) -- was the idea: measured, the step took 41.3 us
+// with it against 39.9 without (profiles/r04_ab_log.txt), so it is OFF; -DPRL_NT_MASKS is the A/B switch.
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#ifdef PRL_NT_MASKS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, T v) {
+#ifdef PRL_NT_MASKS
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct GlobalMasks {
     uint64_t *painted, *last;     // rows of this env
     int n_words, lane;
@@ -445,8 +483,8 @@ struct GlobalMasks {
         for (int k = 0; k < KW; ++k) {
             const uint32_t w = lane + 64 * k;
             const bool in = (int)w < n_words;
-            p[k] = in ? painted[w] : 0;
-            l[k] = in ? last[w] : 0;
+            p[k] = in ? stream_load(painted + w) : 0;
+            l[k] = in ? stream_load(last + w) : 0;
         }
     }
     template <int KW>
@@ -455,8 +493,8 @@ struct GlobalMasks {
         for (int k = 0; k < KW; ++k) {
             const uint32_t w = lane + 64 * k;
             if ((int)w < n_words) {
-                painted[w] = p[k];
-                last[w] = l[k];
+                stream_store(painted + w, p[k]);
+                stream_store(last + w, l[k]);
             }
         }
     }

@@ -110,7 +110,7 @@ def test_headline_config_60_steps_with_auto_reset_equals_oracle():
     env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True)
     orc = oracle.Oracle(tables, n, start_points=sp, threads=16)
     ends, _ = _run(env, orc, np.full(n, len(sp)), 60, 2024, 3 * n)
-    assert (env.state()['episode'] >= 2).all()
+    assert env.state()['episode'].mean() >= 3.5                # (the counter starts at 1 with the first reset)
     env.close()
 
 

@@ -14,10 +14,12 @@ def main():
     from paintrl_amd import part_tables, synth_parts
     from paintrl_amd.batched_env import BatchedPaintEnv
     from paintrl_amd.device_tables import DeviceTables
-    part = sys.argv[1] if len(sys.argv) > 1 else 'test'
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    pm = sys.argv[3] if len(sys.argv) > 3 else 'fast'
-    cm = sys.argv[4] if len(sys.argv) > 4 else 'RGB'
+    argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+    sys.argv = [sys.argv[0]] + argv + [a for a in sys.argv[1:] if a.startswith('--')]
+    part = sys.argv[1] if len(argv) > 0 else 'test'
+    n = int(argv[1]) if len(argv) > 1 else 4096
+    pm = argv[2] if len(argv) > 2 else 'fast'
+    cm = argv[3] if len(argv) > 3 else 'RGB'
     tex = synth_parts.TEXTURES[part][0]
     tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(part), tex_size=tuple(tex), name=part)
     env = BatchedPaintEnv(DeviceTables(tables, start_points=part_tables.start_points(tables, 'all')), n, auto_reset=True, seed=5678,
@@ -35,6 +37,12 @@ def main():
     dt = time.perf_counter() - t0
     print('%s: %d samples, %d mask words, kd nodes %d; %s / %s, %d envs: %.1f us per batched step (%.0f steps/s)' % (
         part, tables.sample_pos.shape[0], env.mask_stride, len(getattr(tables, 'kd_split_dim', ())), pm, cm, n, 1e6 * dt / steps, steps / dt))
+    if '--json' in sys.argv:
+        import json
+        print(json.dumps({'part': part, 'samples': int(tables.sample_pos.shape[0]), 'mask_words': int(env.mask_stride),
+                          'stale_kd_nodes': len(getattr(tables, 'kd_split_dim', ())), 'paint_method': pm, 'color_mode': cm, 'envs': n,
+                          'start_points': 'all', 'actions': 'random discrete-4, in-kernel auto-reset', 'steps_timed': steps,
+                          'us_per_batched_step': 1e6 * dt / steps, 'batched_steps_per_s': steps / dt}))
     env.close()
 
 

@@ -45,11 +45,17 @@ def main():
     for s in range(warm):
         env.step_raw(acts[s])
     torch.cuda.synchronize()
-    rows, rows16 = [], []
+    rows, rows16, rows_ph = [], [], []
+    have_phase = hasattr(lib, 'prl_debug_wave_phase')
+    buf_ph = np.zeros((n, 16), dtype=np.uint32)
     buf = np.zeros((n, 4), dtype=np.uint64)
     buf16 = np.zeros(n, dtype=np.uint64)
     lib.prl_debug_wave_trace16.argtypes = [C.c_void_p, C.c_int]
+    b2b = int(os.environ.get('PRL_TRACE_B2B', '0'))       # > 0: each traced launch is the last of b2b launches issued back to back
     for s in range(warm, warm + steps):
+        if b2b:
+            for k in range(b2b - 1):
+                env.step_raw(acts[(s + 7 * k) % acts.shape[0]])
         env.step_raw(acts[s])
         torch.cuda.synchronize()
         rc = lib.prl_debug_wave_trace(buf.ctypes.data, n)
@@ -57,6 +63,10 @@ def main():
         rows.append(buf.copy())
         lib.prl_debug_wave_trace16(buf16.ctypes.data, n)
         rows16.append(buf16.copy())
+        if have_phase:
+            lib.prl_debug_wave_phase.argtypes = [C.c_void_p, C.c_int]
+            lib.prl_debug_wave_phase(buf_ph.ctypes.data, n)
+            rows_ph.append(buf_ph.copy())
     env.close()
     tr = np.stack(rows).astype(np.int64)                          # [steps, n, 4]
     t0 = tr[:, :, 0].min(axis=1, keepdims=True)
@@ -88,9 +98,24 @@ def main():
             m = (c16f[:, 3] >= lo) & (c16f[:, 3] < hi)
             if m.any():
                 print('   hits in [%d, %d): %.1f %% of the waves, life mean %.1f us, p99 %.1f' % (lo, hi, 100 * m.mean(), flat_life[m].mean(), np.percentile(flat_life[m], 99)))
+    if rows_ph:
+        ph = np.stack(rows_ph).astype(np.float64) * 0.01          # us, [steps, n, 16]
+        names = ['load', 'ray', 'vertex', 'bary', 'math', 'paint', 'apply', 'obs', 'store']
+        tot = ph[..., :9].sum(-1)
+        print('phase split of a wave life (us, mean over waves; the stamps cost a few lane moves each): ' +
+              '  '.join('%s %.2f' % (nm, ph[..., k].mean()) for k, nm in enumerate(names)) + '  | sum %.1f of life %.1f' % (tot.mean(), life.mean()))
+        slow = life >= np.percentile(life, 95)
+        print('  the slowest 5 %% of the waves:                                                       ' +
+              '  '.join('%s %.2f' % (nm, ph[..., k][slow].mean()) for k, nm in enumerate(names)))
+        fast = life <= np.percentile(life, 5)
+        print('  the fastest 5 %%:                                                                    ' +
+              '  '.join('%s %.2f' % (nm, ph[..., k][fast].mean()) for k, nm in enumerate(names)))
     span = end.max(axis=1)
     print('launch span (first wave start -> last wave end): mean %.1f us, min %.1f, max %.1f' % (span.mean(), span.min(), span.max()))
     print('wave start offset: mean %.2f us, 99%% %.2f, max %.2f' % (start.mean(), np.percentile(start, 99), start.max()))
+    print('  first / mean / last wave start by XCD (us): ' + '  '.join('%d: %.1f / %.1f / %.1f' % (x, start[xcc == x].min(), start[xcc == x].mean(), start[xcc == x].max()) for x in np.unique(xcc)))
+    env_ix = np.broadcast_to(np.arange(start.shape[1]), start.shape)
+    print('  mean start by eighth of the env range (us): ' + ' '.join('%.1f' % start[(env_ix * 8) // start.shape[1] == k].mean() for k in range(8)))
     q = [50, 75, 90, 99, 99.9, 100]
     print('wave life us:  mean %.1f  ' % life.mean() + '  '.join('p%g %.1f' % (p, np.percentile(life, p)) for p in q))
     print('wave end us:   mean %.1f  ' % end.mean() + '  '.join('p%g %.1f' % (p, np.percentile(end, p)) for p in q))
