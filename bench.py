@@ -125,13 +125,27 @@ def cpu_baseline(tables, steps_sample=300, n_envs=ENVS_PER_GPU, obs_mode='sectio
                              'sample': '%d batched steps of %d envs, one thread, %.1f s wall' % (one_steps, n_envs, dt_one)}}
     try:
         with open(os.path.join(REPO, 'tests', 'golden', 'MANIFEST.json')) as f:
-            tm = json.load(f)['timings']
-        ms = tm['door_grid_ms_per_step' if obs_mode == 'grid' else 'door_section_ms_per_step']
-        out['reference_python'] = {
-            'ms_per_env_step': ms, 'env_steps_per_s_per_core': 1e3 / ms,
-            'provenance': 'the reference PaintGymEnv.step() itself (CPython, one core of the build container, '
-                          'synthetic door, ray time of the stand-in pybullet included), timed by '
-                          'tests/golden/make_golden.py while it recorded the golden episodes; tests/golden/MANIFEST.json'}
+            man = json.load(f)
+        mode = 'grid' if obs_mode == 'grid' else 'section'
+        rt = man.get('reference_step_timing')
+        if rt and mode in rt:
+            r = rt[mode]
+            out['reference_python'] = {
+                'ms_per_env_step': r['ms_per_env_step'], 'ms_per_env_step_without_ray_stand_in': r['ms_per_env_step_without_ray_stand_in'],
+                'ray_stand_in_ms_per_env_step': r['ray_stand_in_ms_per_env_step'],
+                'env_steps_per_s_all_processes': r['env_steps_per_s_all_processes'], 'processes': r['processes'],
+                'steps_per_process': r['steps_per_process'], 'cpu_model': rt.get('cpu_model'), 'cores': rt.get('cores'),
+                'provenance': 'the reference PaintGymEnv.step() itself (CPython, %d processes x one env on the build container, synthetic door, '
+                              'random discrete-4 actions with reset on done), timed by tests/golden/make_golden.py --timing; the stand-in '
+                              "pybullet's ray time (this project's numpy ray, not Bullet) is reported separately; tests/golden/MANIFEST.json"
+                              % r['processes']}
+        else:
+            ms = man['timings']['door_grid_ms_per_step' if obs_mode == 'grid' else 'door_section_ms_per_step']
+            out['reference_python'] = {
+                'ms_per_env_step': ms, 'env_steps_per_s_per_core': 1e3 / ms,
+                'provenance': 'the reference PaintGymEnv.step() itself (CPython, one core of the build container, '
+                              'synthetic door, ray time of the stand-in pybullet included), timed by '
+                              'tests/golden/make_golden.py while it recorded the golden episodes; tests/golden/MANIFEST.json'}
     except (OSError, KeyError, ValueError):
         pass
     return out

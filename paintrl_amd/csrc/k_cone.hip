@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
     const int succeeded = (int)(sums >> 32), pixel_counter = (int)(sums & 0xffffffffu);
     double succeeded_f = (double)succeeded;
     if constexpr (HSI) succeeded_f = wave_sum_d(succ_l);
-    const WaveLds wl{nullptr, nullptr, s_cnt[GENSEC ? wave : 0], nullptr, nullptr, nullptr, nullptr};
+    const WaveLds wl{nullptr, nullptr, s_cnt[GENSEC ? wave : 0], nullptr, nullptr, nullptr, nullptr, 0};
     PROF_BEGIN();
     const int dn = finish_step<KW, GENSEC, false, HSI>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
                                                        pixel_counter, counter_before, new_angle, facet_hint, StepRows{&a}, wl, nullptr PROF_PASS);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     const int counter_before = S.terminate_counter;
     ShotCtx X;
-    shots_begin(P, S, delta1, delta2, X);
+    shots_begin<KD>(P, S, delta1, delta2, X, lane, wl);
     double *shots = a.cone_shots + (size_t)env * PAINT_PER_ACTION * 8;
     PROF_BEGIN();
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {

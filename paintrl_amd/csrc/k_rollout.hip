@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             __shared__ int s_cand[FRAG_WAVES][64];
             __shared__ double s_centres[FRAG_WAVES][PAINT_PER_ACTION * 3 + 1];
             __shared__ double s_kd[KD ? FRAG_WAVES : 1][KD ? KD_HEAP * 5 : 1];
-            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr};
+            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
             PROF_BEGIN();
             const int dn = step_env<KW, false, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                                 new_angle, row, wl PROF_PASS);
@@ -175,7 +175,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;
     decode_discrete_action(C, act, delta1, delta2, new_angle);
-    const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr};
+    const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
     PROF_BEGIN();
     const int dn = step_env<KW, false, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,
                                                         StepRows{&a}, wl PROF_PASS);
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             double delta1, delta2, new_angle;
             decode_discrete_action(C, act, delta1, delta2, new_angle);
             const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
-            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr};
+            const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
             PROF_BEGIN();
             const int dn = step_env<KW, false, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                                 new_angle, row, wl PROF_PASS);

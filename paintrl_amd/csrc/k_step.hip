@@ -25,6 +25,12 @@
 #define PRL_TILE_ON false
 #endif
 
+#ifdef PRL_RECORD_GATHER                   // (A/B switch, prl_search.hpp: candidates' records fetched by all lanes through LDS; off)
+#define PRL_GATHER_ON true
+#else
+#define PRL_GATHER_ON false
+#endif
+
 #ifndef PRL_KW
 #error "compile with -DPRL_KW=1..4 (paintrl_amd/build.py)"
 #endif
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // against 63 spilled vector registers on the reference's own sheet.  The registers were the observation's: four slots'
     // pivot probes at once, 64 of them (prl_observe.hpp section4_accumulate); taken two slots at a time no KW = 4 kernel
     // spills any more and the rows are not needed.)
-    const WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES, PRL_TILE_ON, true>();
+    const WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES, PRL_TILE_ON, PRL_GATHER_ON>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;
@@ -121,6 +127,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     EnvState S;
     TRACE_BEGIN();
     load_state_motion(state_rec, S);
+#ifdef PRL_STAGGER                         // A/B: the odd wave slots of a SIMD start PRL_STAGGER x 64 cycles late (de-phasing the
+    if (__builtin_amdgcn_s_getreg(63492) & 1) __builtin_amdgcn_s_sleep(PRL_STAGGER);      // four envs that share it)
+#endif
     PROF_BEGIN();
     const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
     double delta1, delta2, new_angle;

@@ -197,6 +197,8 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // threadIdx.x and 64-bit generic row addresses alive in vector registers through the whole kernel -- and, at
 // this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
 constexpr int KD_HEAP = 64;         // queued cells of the stale kd-tree walk (5 doubles each)
+constexpr int KD_LDS_NODES = 64;    // trees of at most this many nodes are walked from a copy in LDS (kd_stage, prl_search.hpp)
+constexpr int KD_ROW = KD_HEAP * 5 + 3 * KD_LDS_NODES;      // doubles per wave: the queue | nodes as int4 | split values
 
 // Convex collision sets: the records of ONE facet's vertex neighbourhood (the facet itself in lane 0, PartDev::col_nbr) staged
 // in this wave's LDS -- the "LDS-staged triangle tile" of the ray (prl_ray.hpp).  A sub-shot's ray ends on the facet the
@@ -226,24 +228,25 @@ struct WaveLds {
     int *cand;          // [64]
     double *cen;        // [PAINT_PER_ACTION * 3] (+ 1 pad)
     int *cnt;           // [128], only with the atan2-sector observation
-    double *kd_heap;    // [KD_HEAP][5], only in the kernels for parts that carry the stale kd-tree
+    double *kd_heap;    // [KD_ROW]: the queue [KD_HEAP][5], then the staged tree; only in the kernels for parts with the stale kd-tree
     uint64_t *lastrow;  // [2][64 * KW]: the last-shot mask and its successor while the ball painter runs (step_kernel; nullptr:
                         // both stay in registers)
     FacetTile *tile;    // the ray's facet tile, or nullptr (kernels that do not stage one: the ray then reads global memory)
     f64x2 *gather;      // [GATHER_CHUNKS]: where a few lanes' records are fetched by ALL lanes (record_gather below), or nullptr
+    int kd_staged;      // kd_heap has KD_ROW doubles: small trees are walked from their copy behind the queue (kd_stage); 0: KD_HEAP * 5
 };
 template <bool GENSEC, bool KD = false, int LASTROW_KW = 0, int WAVES = MAX_WAVES_PER_WG, bool TILE = false, bool GATHER = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[WAVES][64];
     __shared__ double s_centres[WAVES][PAINT_PER_ACTION * 3 + 1];
     __shared__ int s_cnt[GENSEC ? WAVES : 1][128];
-    __shared__ double s_kd[KD ? WAVES : 1][KD ? KD_HEAP * 5 : 1];
+    __shared__ double s_kd[KD ? WAVES : 1][KD ? KD_ROW : 1];
     __shared__ uint64_t s_last[LASTROW_KW ? WAVES : 1][LASTROW_KW ? 2 * 64 * LASTROW_KW : 1];
     __shared__ FacetTile s_tile[TILE ? WAVES : 1];
     __shared__ f64x2 s_gather[GATHER ? WAVES : 1][GATHER ? GATHER_CHUNKS : 1];
     const int w = rfl((int)(threadIdx.x >> 6));
     return WaveLds{s_cand[w], s_centres[w], s_cnt[GENSEC ? w : 0], s_kd[KD ? w : 0], LASTROW_KW ? s_last[w] : nullptr,
-                   TILE ? &s_tile[w] : nullptr, GATHER ? s_gather[w] : nullptr};
+                   TILE ? &s_tile[w] : nullptr, GATHER ? s_gather[w] : nullptr, KD ? 1 : 0};
 }
 
 __device__ __forceinline__ double bcast_d(double v, int src) {

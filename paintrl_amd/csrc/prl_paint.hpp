@@ -166,56 +166,105 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
         rb[r] = __builtin_amdgcn_readlane(bound, 2 * r);
         re[r] = __builtin_amdgcn_readlane(bound, 2 * r + 1);
     }
+    // One word of samples per trip of the loop below: its 64 float records, the five distance tests, the fold into the masks.
+    // [-DPRL_PAINT_PIPELINE] The words of these rows are known before the first is fetched, so the NEXT word's records can be
+    // requested before the current word is worked on (a word's load is otherwise waited for where it is issued: ~7 exposed
+    // round trips a step).  Measured slower -- the step is bound by instruction issue, not by these waits -- and off.
+    auto do_word = [&](int w, const f32x4 pf, int lo, int hi) {
+        WCNT(5, 1);
+        const int s = (w << 6) + lane;
+        // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only: [lo, hi)
+        const bool in = s >= lo && s < hi;
+        uint64_t b[PAINT_PER_ACTION];
+        uint64_t any = 0, unsure = 0;
+#pragma unroll
+        for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+            const float dx = pf.x - cf[k][0], dy = pf.y - cf[k][1], dz = pf.z - cf[k][2];
+            const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            b[k] = ballot64(in && dd <= r2_in);
+            unsure |= b[k] ^ ballot64(in && dd <= r2_out);
+            any |= b[k];
+        }
+#ifdef PRL_FORCE_F64_PAINT
+        unsure = 1;
+#endif
+        if (unsure) {                           // some sample within rounding reach of the sphere: float64 decides
+            WCNT(6, 1);
+            const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
+            any = 0;
+#pragma unroll
+            for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+                const double dx = x - cen_lds[3 * k], dy = y - cen_lds[3 * k + 1], dz = z - cen_lds[3 * k + 2];
+                const double dd = (dx * dx + dy * dy) + dz * dz;
+                b[k] = ballot64(in && dd <= r2);
+                any |= b[k];
+            }
+        }
+        uint64_t pw, lw;
+        words.get(w, pw, lw);
+        if (any == 0 && lw == 0) return;         // nothing to record for this word
+        // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
+        // affected), folded: the newly painted samples of the five shots are the union minus what was
+        // painted before, and each shot's valid set only looks one shot back
+        succeeded += __popcll(any & ~pw);
+        pw |= any;
+        uint64_t uw = b[0] & ~lw;
+#pragma unroll
+        for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
+        lw = b[PAINT_PER_ACTION - 1];
+        pixel_counter += __popcll(uw);
+        words.put(w, pw, lw);
+    };
+    // the words of the trip's rows as a bit set relative to the first (rows are consecutive in memory: a few dozen words)
+    int base = -1;
+    uint64_t wm = 0;
+    bool flat = true;
 #pragma unroll
     for (int r = 0; r < TRIP; ++r) {
         if (re[r] <= rb[r]) continue;
-        const int wlast = (re[r] - 1) >> 6;
-        for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
-            WCNT(5, 1);
-            const int s = (w << 6) + lane;
-            const f32x4 pf = ldg(s4, s);
-            // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only
-            const bool in = s >= rb[r] && s < re[r];
-            uint64_t b[PAINT_PER_ACTION];
-            uint64_t any = 0, unsure = 0;
-#pragma unroll
-            for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-                const float dx = pf.x - cf[k][0], dy = pf.y - cf[k][1], dz = pf.z - cf[k][2];
-                const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                b[k] = ballot64(in && dd <= r2_in);
-                unsure |= b[k] ^ ballot64(in && dd <= r2_out);
-                any |= b[k];
-            }
-#ifdef PRL_FORCE_F64_PAINT
-            unsure = 1;
+        const int w0 = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1, w1 = (re[r] - 1) >> 6;
+        if (w1 < w0) continue;
+        if (base < 0) base = w0;
+        if (w0 < base || w1 - base >= 64) flat = false;
+        else wm |= (w1 - w0 == 63 ? ~0ull : ((1ull << (w1 - w0 + 1)) - 1)) << (w0 - base);
+    }
+#ifndef PRL_PAINT_PIPELINE                           // A/B switch; OFF: the prefetching loop hides ~7 round trips a step and adds
+    flat = false;                                    // ~150 scalar / vector instructions: 41.5 against 40.2 us (profiles/r04_ab_log.txt)
 #endif
-            if (unsure) {                           // some sample within rounding reach of the sphere: float64 decides
-                WCNT(6, 1);
-                const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
-                any = 0;
-#pragma unroll
-                for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-                    const double dx = x - cen_lds[3 * k], dy = y - cen_lds[3 * k + 1], dz = z - cen_lds[3 * k + 2];
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    b[k] = ballot64(in && dd <= r2);
-                    any |= b[k];
+    if (flat) {
+        if (wm) {
+            int w_cur = base + __builtin_ctzll(wm);
+            wm &= wm - 1;
+            f32x4 pf = ldg(s4, (w_cur << 6) + lane);
+            for (;;) {
+                const bool more = wm != 0;
+                int w_nxt = w_cur;
+                f32x4 pn = pf;
+                if (more) {
+                    w_nxt = base + __builtin_ctzll(wm);
+                    wm &= wm - 1;
+                    pn = ldg(s4, (w_nxt << 6) + lane);
                 }
-            }
-            done_w = w;
-            uint64_t pw, lw;
-            words.get(w, pw, lw);
-            if (any == 0 && lw == 0) continue;       // nothing to record for this word
-            // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
-            // affected), folded: the newly painted samples of the five shots are the union minus what was
-            // painted before, and each shot's valid set only looks one shot back
-            succeeded += __popcll(any & ~pw);
-            pw |= any;
-            uint64_t uw = b[0] & ~lw;
+                int lo = 0, hi = 0;                  // the row this word belongs to (scalar selects)
 #pragma unroll
-            for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
-            lw = b[PAINT_PER_ACTION - 1];
-            pixel_counter += __popcll(uw);
-            words.put(w, pw, lw);
+                for (int r = 0; r < TRIP; ++r)
+                    if (re[r] > rb[r] && w_cur >= (rb[r] >> 6) && w_cur <= ((re[r] - 1) >> 6)) lo = rb[r], hi = re[r];
+                do_word(w_cur, pf, lo, hi);
+                done_w = w_cur;
+                if (!more) break;
+                w_cur = w_nxt;
+                pf = pn;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < TRIP; ++r) {
+            if (re[r] <= rb[r]) continue;
+            const int wlast = (re[r] - 1) >> 6;
+            for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
+                do_word(w, ldg(s4, (w << 6) + lane), rb[r], re[r]);
+                done_w = w;
+            }
         }
     }
     }

@@ -169,7 +169,25 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
 // distance, scan a leaf's points in tree order keeping strictly smaller distances (distances to the rows as they
 // are NOW), continue with the nearest queued cell until none is left or it lies beyond the best.  The walk is
 // wave-uniform; the (at most 16) points of a leaf are one per lane; the queue lives in this wave's LDS rows.
-__device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap) {
+// The tree of a coarse part is tiny (the reference's sheet: 33 nodes) and every query walks it node by node, two dependent
+// global round trips a level.  kd_stage copies trees of up to KD_LDS_NODES nodes into this wave's LDS once per step (behind
+// the queue in `heap`); the walk then reads its nodes from there.
+__device__ __forceinline__ void kd_stage(PartRef P, double *heap, int lane) {
+    if (P.n_kd_nodes > 0 && P.n_kd_nodes <= KD_LDS_NODES) {
+        if (lane < P.n_kd_nodes) {
+            reinterpret_cast<i32x4 *>(heap + KD_HEAP * 5)[lane] = ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), lane);
+            heap[KD_HEAP * 5 + 2 * KD_LDS_NODES + lane] = ldg(P.kd_split, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+__device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap, bool has_copy) {
+    const bool staged = has_copy && P.n_kd_nodes <= KD_LDS_NODES;           // (kd_stage ran in shots_begin)
+    const i32x4 *lds_node = reinterpret_cast<const i32x4 *>(heap + KD_HEAP * 5);
+    const double *lds_split = heap + KD_HEAP * 5 + 2 * KD_LDS_NODES;
     double side0, side1, side2;
     {
         const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
@@ -185,8 +203,8 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
     double mind = (side0 + side1) + side2, dub = INFINITY;
     int node = 0, best = -1, n_heap = 0;
     for (int guard = 0; guard < 4 * 4096; ++guard) {                // every path ends far earlier; a bound all the same
-        const int nd0 = rfl(ldg(P.kd_node, 4 * node)), nd1 = rfl(ldg(P.kd_node, 4 * node + 1)),
-                  nd2 = rfl(ldg(P.kd_node, 4 * node + 2));
+        const i32x4 nd = staged ? lds_node[node] : ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), node);
+        const int nd0 = rfl(nd.x), nd1 = rfl(nd.y), nd2 = rfl(nd.z);
         if (nd0 < 0) {                                              // leaf: points nd1 .. nd2 - 1
             for (int i0 = nd1; i0 < nd2; i0 += 64) {
                 const int i = i0 + lane;
@@ -223,7 +241,7 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             if (mind > dub) break;
-            const double sp = ldg(P.kd_split, node);
+            const double sp = staged ? lds_split[node] : ldg(P.kd_split, node);
             const double xs = sel3(pt[0], pt[1], pt[2], nd0), old = sel3(side0, side1, side2, nd0);
             const bool low = xs < sp;
             const int near = low ? nd1 : nd2, far = low ? nd2 : nd1;
@@ -355,10 +373,12 @@ __device__ __forceinline__ void record_gather(const f64x2 GAS *table, int id, in
 // `gather`: this wave's record_gather buffer, or nullptr (then every candidate lane fetches its own record).
 template <bool KD>
 __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double pose[3], double orn[3], double quat[4],
-                                double center[3], int &tri, double *kd_heap, FacetTile *tile, const TilePrefetch &pf,
-                                f64x2 *gather PROF_ARG) {
+                                double center[3], int &tri, const WaveLds &wl, const TilePrefetch &pf PROF_ARG) {
+    double *kd_heap = wl.kd_heap;
+    FacetTile *tile = wl.tile;
+    f64x2 *gather = wl.gather;
     int vidx;
-    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap) : nearest_vertex_wave(P, pt, lane);
+    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap, wl.kd_staged != 0) : nearest_vertex_wave(P, pt, lane);
     else vidx = nearest_vertex_wave(P, pt, lane);
     if (tile && pf.facet >= 0) tile_fill(P, tile, pf.facet, pf.ids, lane);
     STAMP(PH_VERTEX);
@@ -372,10 +392,10 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     // the candidates' records through LDS (record_gather) where the kernel has the buffer, the candidates are the first
     // lanes (rows of vadj are padded at the end) and fit it
     const int n_cand = __popcll(cmask);
-#ifdef PRL_NO_GATHER                                  // A/B switch
-    const bool coop = false;
-#else
-    const bool coop = gather != nullptr && (cmask & (cmask + 1)) == 0 && n_cand * (TRI_REC / 2) <= GATHER_CHUNKS;
+#ifdef PRL_RECORD_GATHER                              // A/B switch; OFF: 13 -> 3 vector-memory instructions and one dependent round trip
+    const bool coop = gather != nullptr && (cmask & (cmask + 1)) == 0 && n_cand * (TRI_REC / 2) <= GATHER_CHUNKS;     // less per hook point, but
+#else                                                 // +212 vector / +107 scalar / +60 LDS instructions per env-step: 40.22 against 39.75 us
+    const bool coop = false;                          // (profiles/r04_ab_log.txt) -- the step is bound by instruction issue
 #endif
     if (coop) record_gather<TRI_REC / 2>(r2, ti, n_cand, lane, gather);
     if (ti >= 0) {

@@ -71,8 +71,11 @@ struct ShotCtx {
     int facet_hint, last_tri;
 };
 
-__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double d1, double d2, ShotCtx &X, FacetTile *tile = nullptr,
-                                            int lane = 0) {
+template <bool KD = false>
+__device__ __forceinline__ void shots_begin(PartRef P, const EnvState &S, double d1, double d2, ShotCtx &X, int lane, const WaveLds &wl) {
+    FacetTile *tile = wl.tile;
+    if constexpr (KD)
+        if (wl.kd_staged) kd_stage(P, wl.kd_heap, lane);
     X.cur_pose[0] = S.pose[0];
     X.cur_pose[1] = S.pose[1];
     X.cur_pose[2] = S.pose[2];
@@ -134,7 +137,7 @@ __device__ __forceinline__ void sub_shot(PartRef P, int lane, EnvState &S, ShotC
         quat[0] = quat[1] = quat[2] = 0, quat[3] = 1;
     }
 #else
-    if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, X.last_tri, wl.kd_heap, wl.tile, pf, wl.gather PROF_PASS);
+    if (on) on = hook_point_wave<KD>(P, hit, lane, pos, orn, quat, center, X.last_tri, wl, pf PROF_PASS);
 #endif
     if (!on) {
         X.last_tri = -1;
@@ -300,7 +303,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
 
     // ---- five chained sub-shots   rob:302-329 + 403-424
     ShotCtx X;
-    shots_begin(P, S, d1, d2, X, wl.tile, lane);
+    shots_begin<KD>(P, S, d1, d2, X, lane, wl);
     new_angle = uni_d(new_angle);
     double *cen = wl.cen;
 #if defined(PRL_CUT) && PRL_CUT >= 6              // diagnostic instruction-count builds (prl_diag.hpp): phases cut away

@@ -100,11 +100,13 @@ class RefDriver(object):
     def painted_bits(self):
         return np.packbits(np.array([bool(self.part.get_pixel_status(p)) for p in self.pix]), bitorder='little')
 
-    def episode(self, seed, policy, max_steps=400, want_idx=None):
+    def episode(self, seed, policy, max_steps=400, want_idx=None, after_reset=None):
         obs0, idx = self.reset(seed)
         while want_idx is not None and idx != want_idx:      # walk seeds until the wanted start comes up
             seed += 1000
             obs0, idx = self.reset(seed)
+        if after_reset is not None:
+            after_reset(self.env)
         rec = dict(actions=[], obs=[], reward=[], done=[], info=[], snaps=[], snap_steps=[])
         obs, done, k = obs0, False, 0
         t_step = 0.0
@@ -375,6 +377,104 @@ def main_textures():
     print('textures.npz', os.path.getsize(os.path.join(HERE, 'textures.npz')), 'bytes')
 
 
+def _timing_worker(args):
+    """One process = one reference env (the reference runs one env per process, paint_ppo.py:171): `steps` random discrete-4
+    steps with reset on done; returns (seconds in step(), seconds of those inside the stand-in's rayTestBatch, steps, episodes)."""
+    root, obs_mode, steps, seed = args
+    rge, bpw, rob, pte, stub = ref_import.load_reference('hull')
+    drv = RefDriver(root, 0)
+    drv.configure(obs_mode, 4, 'anchor', overlap=obs_mode == 'grid')
+    rng = np.random.RandomState(seed)
+    random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        drv.env.reset()
+        ray0, t_step, episodes = stub.RAY_SECONDS[0], 0.0, 0
+        for k in range(steps):
+            a = int(rng.randint(0, 4))
+            t0 = time.perf_counter()
+            _, _, done, _ = drv.env.step(a)
+            t_step += time.perf_counter() - t0
+            if done:
+                drv.env.reset()
+                episodes += 1
+    return t_step, stub.RAY_SECONDS[0] - ray0, steps, episodes
+
+
+def main_off_part():
+    """Episodes that END through Robot._count_not_on_part's own limit (rob:292-300: more than NOT_ON_PART_TERMINATE_STEPS = 1000
+    counted misses) -- the one branch of the step no other fixture reaches, because a step whose five shots all miss AND paint
+    nothing ends the episode at once (rob:427-430).  The tool is put beside the sheet with Robot.reset([pose, orn]) (rob:366-372,
+    what spiral.py:28-38 does), 4 / 6 cm outside its edge: every shot misses the part but its ball still reaches samples, so the
+    misses are counted, five a step, until the counter passes 1000 (EPISODE_MAX_LENGTH raised to 400 for that).
+    -> episodes_sheet_offpart.npz; the replay moves the tool the same way (oracle set_pose / prl_batch_set_pose)."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    ref_import.load_reference('hull')
+    sheet = RefDriver(root, 1)
+    eps = {}
+    for name, off, pattern in (('t4_offpart_counter_04', 0.04, (1, 3)), ('t4_offpart_mixed_06', 0.06, (0, 2))):
+        sheet.configure('section', 4, 'anchor', max_len=400)
+        moved = {}
+
+        def move(env, off=off, moved=moved):
+            a1 = sheet.part.principal_axes[0]
+            pose = [float(v) for v in env._start_points[0][0]]
+            orn = [float(v) for v in env._start_points[0][1]]
+            pose[a1] -= off
+            env.robot.reset([pose, orn])
+            moved['pose'], moved['orn'] = pose, orn
+
+        ep = sheet.episode(0, lambda k, obs, pattern=pattern: pattern[k % len(pattern)], max_steps=400, want_idx=0, after_reset=move)
+        ep['set_pose'] = np.asarray(moved['pose'], dtype=np.float64)
+        ep['set_orn'] = np.asarray(moved['orn'], dtype=np.float64)
+        ep['terminate_counter'] = np.int32(sheet.env.robot._terminate_counter)
+        ep['robot_terminate'] = np.bool_(sheet.env.robot._terminate)
+        eps[name] = ep
+    save_episodes('sheet_offpart', eps)
+    for name, ep in eps.items():
+        print(name, 'steps', len(ep['actions']), 'counter', int(ep['terminate_counter']), 'terminate', bool(ep['robot_terminate']))
+        assert bool(ep['done'][-1]) and int(ep['terminate_counter']) > 1000 and bool(ep['robot_terminate'])
+
+
+def main_timing(procs=8, steps=400):
+    """BASELINE.md 4.1 / SURVEY 8d: the reference's own step() on the build container's cores -- `procs` processes x one env,
+    `steps` random discrete-4 steps each with reset on done, the time of the stand-in's rayTestBatch (this project's numpy
+    ray, not Bullet) reported separately.  Numbers only, into MANIFEST.json."""
+    import multiprocessing as mp
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    out = {}
+    for mode in ('section', 'grid'):
+        with mp.get_context('spawn').Pool(procs) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_timing_worker, [(root, mode, steps, 9000 + 17 * k) for k in range(procs)])
+            wall = time.perf_counter() - t0
+        t_step = sum(r[0] for r in res)
+        t_ray = sum(r[1] for r in res)
+        n = sum(r[2] for r in res)
+        out[mode] = {'processes': procs, 'steps_per_process': steps, 'episodes': int(sum(r[3] for r in res)),
+                     'ms_per_env_step': 1e3 * t_step / n, 'ms_per_env_step_without_ray_stand_in': 1e3 * (t_step - t_ray) / n,
+                     'ray_stand_in_ms_per_env_step': 1e3 * t_ray / n,
+                     'env_steps_per_s_all_processes': n / max(r[0] for r in res), 'wall_s_incl_construction': wall}
+        print(mode, json.dumps(out[mode]))
+    path = os.path.join(HERE, 'MANIFEST.json')
+    meta = json.load(open(path))
+    cpu = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    meta['reference_step_timing'] = dict(out, cpu_model=cpu, cores=os.cpu_count(),
+                                         what='the imported reference PaintGymEnv.step() on the synthetic door, OBS_MODE section / '
+                                              'grid + OVERLAP_PENALTY, anchor starts, random discrete-4 actions, reset on done; one env per '
+                                              'process (make_golden.py --timing)')
+    with open(path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main():
     root = os.path.join(HERE, '_synth_root')
     synth_parts.write_synthetic_parts(root)
@@ -484,5 +584,9 @@ if __name__ == '__main__':
         main_param_test_modes()
     elif '--textures' in sys.argv:
         main_textures()
+    elif '--timing' in sys.argv:
+        main_timing()
+    elif '--off-part' in sys.argv:
+        main_off_part()
     else:
         main()

@@ -240,3 +240,33 @@ def test_gpu_trimesh_collision_mode_matches_oracle():
     hit = idx >= 0
     assert hit.sum() > 50 and np.array_equal(gi.cpu().numpy(), idx) and np.array_equal(gt.cpu().numpy()[hit], t[hit])
     env.close()
+
+
+@pytest.mark.parametrize('name', ['t4_offpart_counter_04', 't4_offpart_mixed_06'])
+def test_gpu_replays_the_off_part_counter_limit(name):
+    """rob:292-300 on the device: more than 1000 counted misses end the episode (S.terminate_counter > NOT_ON_PART_TERMINATE,
+    prl_step.hpp sub_shot) -- the reference's own run beside the sheet, with the tool moved mid-episode through
+    prl_batch_set_pose (Robot.reset([pose, orn]), rob:366-372); every row and the final state equal the recording."""
+    from test_oracle_golden import replay
+    ep = load_episodes('sheet_offpart')[name]
+    cfg = ep['cfg']
+    tables = synthetic_tables('square')
+    sp = start_points_for(tables, cfg['start_mode'])
+    env = _gpu_env(tables, 3, sp, **env_kwargs_from_cfg(cfg))         # env 1 is the one replayed; 0 and 2 stay put
+
+    def reset(idx):
+        obs = env.reset(start_idx=np.full(3, idx, dtype=np.int32)).cpu().numpy()[1].copy()
+        env.set_pose(1, ep['set_pose'], ep['set_orn'])
+        return obs
+
+    def step(a, want_bits):
+        obs, rew, done, info = env.step(np.array([1, a, 1], dtype=np.int32))
+        return (obs.cpu().numpy()[1].copy(), float(rew[1]), bool(done[1]), info.cpu().numpy()[1].copy(),
+                env.painted_bits(1) if want_bits else None)
+
+    replay(step, reset, ep, exact=True)
+    st = env.state()
+    assert st['terminate_counter'][1] == int(ep['terminate_counter']) > 1000 and st['terminate'][1] == 1
+    assert np.array_equal(st['pose'][1], ep['final_pose']) and np.array_equal(st['quat'][1], ep['final_quat'])
+    assert st['total_return'][1] == float(ep['total_return'])
+    env.close()
