@@ -194,6 +194,21 @@ def valu_issue_bound(kernel_us, obs_mode):
             'kernel_sources_changed_since': stale}
 
 
+def cone_second_bound(step_us):
+    """PAINT_METHOD 'normal': the beams kernel (the dominant one of the step's five launches) against its vector-issue and
+    texture-addresser occupancy, from the committed counters of the latest round (tools/summarise_profiles.py)."""
+    path = latest_profile('cone_model.json')
+    if not path:
+        return None
+    with open(path) as f:
+        m = json.load(f)
+    return {'bound': 'valu_issue', 'kernel': m['kernel'], 'frac': m['valu_busy_frac'], 'ta_busy_frac': m['ta_busy_frac'],
+            'valu_per_beam_trip': m['valu_per_wave'], 'vmem_rd_per_beam_trip': m['vmem_rd_per_wave'],
+            'kernel_us_when_measured': m['kernel_us_at_2p4ghz'], 'share_of_the_step': m['kernel_us_at_2p4ghz'] / step_us if step_us else None,
+            'measured_at_commit': m.get('measured_at_commit'),
+            'source': os.path.relpath(path, REPO) + ' (rocprofv3 --pmc: SQ_ACTIVE_INST_VALU x 4 / SIMD cycles, TA_TA_BUSY_sum / CU cycles); not measured in this run'}
+
+
 # ---------------------------------------------------------------------------- self-launch (N > 1)
 def _free_port():
     s = socket.socket()
@@ -524,7 +539,7 @@ def main():
                                       % (world, dist_world, dist.get_backend() if dist.is_initialized() else 'none')
                                       + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs))
                                          if len(subs) > 1 else '')},
-            'roofline': {'bound': 'hbm', 'kernel': 'step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'step_kernel' if args.paint_method == 'fast' else 'the five launches of a cone-beam step (path, beams, rest, far, finish)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
                          'traffic_over_algorithmic': traffic / survey_launch if traffic else None,
                          'traffic_measured_at': traffic_at,
@@ -541,7 +556,9 @@ def main():
                          'avg_kernel_us_sampled': sampled_us, 'sampled_launches': int(launches),
                          'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
                          if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random' and args.actions == 'random'
-                             and args.paint_method == 'fast' and len(subs) == 1) else None},
+                             and args.paint_method == 'fast' and len(subs) == 1) else
+                         (cone_second_bound(1e3 * ms_per_step) if (args.paint_method == 'normal' and args.envs == ENVS_PER_GPU
+                                                                    and not args.mixed and len(subs) == 1) else None)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs, obs_mode=args.obs_mode, overlap=overlap)

@@ -111,16 +111,21 @@ __device__ unsigned long long g_pol_stamps[8];          // policy_forward of wor
 #ifdef PRL_NO_PRIO                       // A/B switches for the progress-based issue priority (prl_step.hpp)
 #define PRIO_BY_PROGRESS(p)
 #define PRIO_YOUNG_DECL()
-#define PRIO_YOUNG_OLD(y, o)
+#define PRIO_YOUNG_OLD(y, o, ph)
 #else                                    // by progress; the two youngest waves of a SIMD (hardware wave slots 2, 3) one
 #ifndef PRL_PRIO_SLOT                    // level up from shot 2 on: 41.31 -> 41.05 us
 #define PRL_PRIO_SLOT 2
 #endif
 #define PRIO_BY_PROGRESS(p) __builtin_amdgcn_s_setprio(p)
-#define PRIO_YOUNG_DECL() const bool prio_young = (__builtin_amdgcn_s_getreg(63492) & 15) >= PRL_PRIO_SLOT
-#define PRIO_YOUNG_OLD(y, o)                       \
+#define PRIO_YOUNG_DECL() const int prio_slot = __builtin_amdgcn_s_getreg(63492) & 15
+#ifdef PRL_PRIO_ROTATE                   // A/B: the favoured pair of slots rotates with the phase (ph = 2 .. 6: shots 2-4, painting, observation)
+#define PRIO_IS_YOUNG(ph) (((prio_slot + (ph)) & 2) != 0)
+#else
+#define PRIO_IS_YOUNG(ph) (prio_slot >= PRL_PRIO_SLOT)
+#endif
+#define PRIO_YOUNG_OLD(y, o, ph)                   \
     do {                                           \
-        if (prio_young) __builtin_amdgcn_s_setprio(y); \
+        if (PRIO_IS_YOUNG(ph)) __builtin_amdgcn_s_setprio(y); \
         else __builtin_amdgcn_s_setprio(o);        \
     } while (0)
 #endif

@@ -218,7 +218,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
     if (!dn) S.total_return += actual;
     STAMP(PH_APPLY);
 
-    PRIO_YOUNG_OLD(1, 0);
+    PRIO_YOUNG_OLD(1, 0, 6);
     const bool do_reset = dn && C.auto_reset;
     const int od = obs_dim_of(C.obs_mode, C.obs_grad);
     double *obs_row = a.obs() + (size_t)env * od;
@@ -317,7 +317,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
         // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
         if (shot <= 1) PRIO_BY_PROGRESS(3);
-        else PRIO_YOUNG_OLD(3, 2);
+        else PRIO_YOUNG_OLD(3, 2, shot);
         double center[3], quat[4];                         // rob:277-278 shot centre
 #if defined(PRL_UNIT_STEP) && !defined(PRL_KEEP_PART)
         // (k_step.hip: the part's table pointers are read again in every shot -- scalar loads from the constant cache --
@@ -339,7 +339,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     shots_end(P, S, X);
-    PRIO_YOUNG_OLD(2, 1);
+    PRIO_YOUNG_OLD(2, 1, 5);
     // the last-shot mask waits in this wave's LDS rows where the kernel provides them (wl.lastrow), not in registers
     const bool rows = !BIG && !HSI && wl.lastrow != nullptr;
     if constexpr (!BIG) {

@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/; tools/summarise_profiles.py (run in the build container afterwards) turns it into profiles/<tag>_*.
 # Counter passes carry --pmc only (no --kernel-trace / --stats with them); the program after `--` is python3 itself.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -23,12 +23,20 @@ $B --policy fragment --no-cpu-baseline > "$OUT/bench_fragment.json" 2>> "$OUT/be
 $B --policy random-fragment --no-cpu-baseline > "$OUT/bench_random_fragment.json" 2>> "$OUT/bench.err"
 $B --streams 2 --no-cpu-baseline > "$OUT/bench_streams2.json" 2>> "$OUT/bench.err"
 $B --paint-method normal --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/bench_normal.json" 2>> "$OUT/bench.err"
+echo "== the reference's sheet: four mask words per lane (fine sheet), and with the stale kd-tree (coarse sheet)"
+for p in square test; do python3 "$ROOT/tools/bench_part.py" $p --json 2>/dev/null | tail -1 > "$OUT/bench_part_$p.json"; done
+echo "== the RCCL path on one rank (PAINTRL_FORCE_DIST=1)"
+PAINTRL_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29613 $B --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/bench_rccl_world1.json" 2>> "$OUT/bench.err"
 echo "== batch-size sweep (one wave per CU ... four per SIMD: the step's latency chain against its throughput)"
 for n in 256 1024 2048 3072 4096; do
   $B --envs $n --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_envs$n.json" 2>> "$OUT/bench.err"
 done
 echo "== issue cost of the vector instruction classes (tools/microbench/valu_rate.hip)"
 timeout -k 5 200 "$ROOT/tools/microbench/valu_rate" "$OUT/valu_rate.json" > "$OUT/valu_rate.txt" 2>&1
+echo "== does a table stay in L2 from launch to launch (tools/microbench/l2_cold.hip)"
+timeout -k 5 60 "$ROOT/tools/microbench/l2_cold" > "$OUT/l2_cold.txt" 2>&1
+echo "== per-wave trace of back-to-back launches (a -DPRL_WAVE_TRACE build under tools/_ab/trace.so, if present)"
+if [ -f "$ROOT/tools/_ab/trace.so" ]; then PRL_TRACE_B2B=12 PRL_TRACE_STEPS=30 timeout -k 10 200 python3 "$ROOT/tools/wave_trace.py" > "$OUT/wave_trace_b2b.txt" 2>&1; fi
 echo "== kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- $B --no-cpu-baseline > "$OUT/trace.log" 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_grid" --output-format csv -- $B --obs-mode grid --no-cpu-baseline > "$OUT/trace_grid.log" 2>&1
@@ -45,6 +53,10 @@ for MODE in section grid; do
     timeout -k 10 300 rocprofv3 --pmc $G -d "$OUT/pmc_${MODE}_$i" --output-format csv -- $W --obs-mode $MODE --steps 100 > "$OUT/pmc_${MODE}_$i.log" 2>&1 || echo "pmc $MODE pass $i failed"
   done
 done
+echo "== cone-beam step: counters of its beams kernel"
+PMCONE="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"
+timeout -k 10 300 rocprofv3 --pmc $PMCONE -d "$OUT/pmc_cone_1" --output-format csv -- $W --paint-method normal --steps 40 > "$OUT/pmc_cone_1.log" 2>&1 || echo "pmc cone pass 1 failed"
+timeout -k 10 300 rocprofv3 --pmc TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 -d "$OUT/pmc_cone_2" --output-format csv -- $W --paint-method normal --steps 40 > "$OUT/pmc_cone_2.log" 2>&1 || echo "pmc cone pass 2 failed"
 echo "== HBM bytes (FETCH_SIZE and WRITE_SIZE in separate passes) + calibration on copy_mask_kernel"
 for MODE in section grid; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/hbm_fetch_$MODE" --output-format csv -- $W --obs-mode $MODE --steps 200 > "$OUT/hbm_fetch_$MODE.log" 2>&1

@@ -33,7 +33,7 @@ def counters(d, kernel='step_kernel'):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
     src = os.path.join(REPO, 'gpurun_out', tag)
     dst = os.path.join(REPO, 'profiles')
     # bench lines
@@ -99,6 +99,23 @@ def main():
                                                 'dispatches_averaged': [nf.get('FETCH_SIZE'), nw.get('WRITE_SIZE')]}
                 out['bytes_per_launch_%s' % mode] = rd + wr
         json.dump(out, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+    # the cone-beam step's beams kernel: vector-issue and texture-addresser occupancy (bench.py --paint-method normal reads it)
+    c1, w1, _ = counters(os.path.join(src, 'pmc_cone_1'), 'cone_beams_kernel')
+    c2, w2, _ = counters(os.path.join(src, 'pmc_cone_2'), 'cone_beams_kernel')
+    if c1 and c2 and c2.get('GRBM_GUI_ACTIVE'):
+        kernel_cycles = c2['GRBM_GUI_ACTIVE'] / 8.0                       # the counter sums the eight XCDs
+        model = {'kernel': 'cone_beams_kernel', 'measured_at_commit': head_commit(), 'waves_per_dispatch': w1,
+                 'valu_per_wave': c1['SQ_INSTS_VALU'] / w1, 'vmem_rd_per_wave': c1['SQ_INSTS_VMEM_RD'] / w1,
+                 'valu_f64_per_wave': sum(c2.get(k, 0.0) for k in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64')) / w2,
+                 'kernel_cycles': kernel_cycles, 'kernel_us_at_2p4ghz': kernel_cycles / 2400.0,
+                 'valu_busy_frac': 4.0 * c1['SQ_ACTIVE_INST_VALU'] / (1024.0 * kernel_cycles),
+                 'ta_busy_frac': (c2['TA_TA_BUSY_sum'] / 256.0) / kernel_cycles,
+                 'note': 'SQ_ACTIVE_INST_VALU x 4 cycles over 1 024 SIMDs x the kernel\'s cycles; TA_TA_BUSY_sum per CU over the same; '
+                         'rocprofv3 --pmc in two passes over tools/run_workload.py --paint-method normal --steps 40'}
+        json.dump(model, open(os.path.join(dst, '%s_cone_model.json' % tag), 'w'), indent=1)
+    for name in ('l2_cold.txt', 'wave_trace_b2b.txt'):
+        if os.path.isfile(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
     for name in ('valu_rate.json', 'valu_rate.txt'):
         if os.path.isfile(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
