@@ -232,6 +232,18 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         UP(kd_node, t->kd_node, (size_t)d.n_kd_nodes * 4);
         UP(kd_split, t->kd_split, d.n_kd_nodes);
         UP(kd_points, t->kd_points, t->n_kd_points);
+        {   // the leaves' vertex records in tree order (derived): a leaf scan reads its points' x y z | {vertex, 0} in ONE round
+            // trip instead of two (the point's vertex id, then that vertex's record); a parked row (-1) keeps id -1
+            std::vector<double> kr((size_t)t->n_kd_points * 4, 0.0);
+            for (int i = 0; i < t->n_kd_points; ++i) {
+                const int v = t->kd_points[i];
+                if (v >= 0)
+                    for (int k = 0; k < 3; ++k) kr[(size_t)i * 4 + k] = t->vertex_xyz[k][v];
+                const int32_t pair[2] = {v, 0};
+                std::memcpy(&kr[(size_t)i * 4 + 3], pair, sizeof pair);
+            }
+            UP(kd_rec, kr.data(), kr.size());
+        }
         for (int k = 0; k < 6; ++k) d.kd_box[k] = t->kd_box[k];
     }
     {   // device triangle records: the host's 16 doubles + the quaternion and shot-centre offset a hit on the

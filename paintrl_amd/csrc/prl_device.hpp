@@ -99,6 +99,7 @@ struct PartDev {
     gint_p kd_node;               // [n][4] split dim | lesser or first point | greater or end | 0
     gdouble_p kd_split;
     gint_p kd_points;
+    gdouble_p kd_rec;             // [n_kd_points][4]: x y z | {i32 vertex or -1, 0} of the leaves' points in tree order (derived in part_fill)
     double kd_box[6];
     int n_triangles;
     gdouble_p tri_rec;            // [n_triangles][TRI_REC]: the 16 doubles of the host table + derived tail (part_fill)

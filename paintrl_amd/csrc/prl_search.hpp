@@ -208,14 +208,16 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
         if (nd0 < 0) {                                              // leaf: points nd1 .. nd2 - 1
             for (int i0 = nd1; i0 < nd2; i0 += 64) {
                 const int i = i0 + lane;
-                const int v = i < nd2 ? ldg(P.kd_points, i) : -1;   // -1: a row parked at (10, 10, 10)
+                int v = -1;                                         // -1: a row parked at (10, 10, 10)
                 double d = INFINITY;
-                if (v >= 0) {
-                    double x, y, z;
-                    int rk;
-                    load_vertex(P, v, x, y, z, rk);
-                    const double d0 = x - pt[0], d1 = y - pt[1], d2 = z - pt[2];
-                    d = (d0 * d0 + d1 * d1) + d2 * d2;
+                if (i < nd2) {
+                    const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.kd_rec);
+                    const f64x2 a = ldg(r, 2 * i), b = ldg(r, 2 * i + 1);      // the point's record, in tree order (PartDev::kd_rec)
+                    v = __double2loint(b.y);
+                    if (v >= 0) {
+                        const double d0 = a.x - pt[0], d1 = a.y - pt[1], d2 = b.x - pt[2];
+                        d = (d0 * d0 + d1 * d1) + d2 * d2;
+                    }
                 }
                 const double dmin = wave_min_d(d);
                 if (dmin < dub) {                                   // the first point (tree order) reaching the minimum
