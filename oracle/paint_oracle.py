@@ -28,7 +28,7 @@ class OrPart(C.Structure):
                 ('n_start', C.c_int32), ('start_pos', _dp), ('start_quat', _dp),
                 ('n_beams', C.c_int32), ('beams', _dp),
                 ('n_kd_nodes', C.c_int32), ('kd_split_dim', _ip), ('kd_split', _dp), ('kd_less', _ip), ('kd_greater', _ip),
-                ('kd_start', _ip), ('kd_end', _ip), ('kd_points', _ip), ('kd_box', _dp), ('sample_rank', _ip)]
+                ('kd_start', _ip), ('kd_end', _ip), ('kd_points', _ip), ('kd_box', _dp), ('sample_rank', _ip), ('vertex_rank', _ip)]
 
 
 class OrConfig(C.Structure):
@@ -159,6 +159,7 @@ class Oracle(object):
             orn = _f64(p[1])
             self.lib.or_pose_orn_quat(_ptr(orn), _ptr(sq[k]))
         keep.update(sample_pos=_f64(t.sample_pos), sample_cell=_i32(cells), sample_rank=_i32(t.sample_tie_rank),
+                    vertex_rank=_i32(np.asarray(t.vertex_tie_rank)[side_ids]),
                     vertex_pos=_f64(t._side_data[side_ids]), adj_off=_i32(off), adj_tri=_i32(adj),
                     tri_a=_f64(t.tri_a[front_ids]), tri_v0=_f64(t.tri_v0[front_ids]), tri_v1=_f64(t.tri_v1[front_ids]),
                     tri_d00=_f64(t.tri_d00[front_ids]), tri_d01=_f64(t.tri_d01[front_ids]),

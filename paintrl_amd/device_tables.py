@@ -119,7 +119,8 @@ class DeviceTables(object):
         vcell = vcy * vnx + vcx
         vorder = np.argsort(vcell, kind='stable')
         self.vertex_xyz = [np.ascontiguousarray(vpos[vorder, k]) for k in range(3)]
-        self.vertex_rank = vorder.astype(np.int32)            # rank in the reference's vertex order
+        # equally distant vertices (doubled in the OBJ): the order of the reference's own tree, part_tables._vertex_tie_rank
+        self.vertex_rank = np.asarray(t.vertex_tie_rank, dtype=np.int32)[side_ids][vorder]
         self.vgrid_start = np.searchsorted(vcell[vorder], np.arange(vnx * vny + 1)).astype(np.int32)
         self.vgrid = (vo1, vo2, inv, vnx, vny)
         self.vgrid_accept = 0.99 * self.vcell

@@ -210,6 +210,7 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
     relevant = side_data[:, 0] != IRRELEVANT
     relevant &= in_face      # a vertex in no face has no triangle to hook onto
     t.vertex_is_side = relevant
+    t.vertex_tie_rank = _vertex_tie_rank(side_data)
     # vertex -> incident front triangles in file order (uv_map restricted to the side)
     adj = [[] for _ in range(V.shape[0])]
     for ti in front_ids:
@@ -260,6 +261,20 @@ def build_part_tables(urdf_path=None, mesh=None, tex_size=None, obs_grad=4, coll
     t.beams = cone_beams(t.density)
     t.front_ids = front_ids
     return t
+
+
+def _vertex_tie_rank(side_rows):
+    """Who wins `vertices_kd_tree[side].query(point, k=1)` (bpw:526) between vertices at EQUAL distance -- vertices written
+    twice in the OBJ (exporters double them along UV seams: 179 in the reference's test.obj), each with its own incident
+    triangles, so the choice decides which triangles the hook point may take.  query.cxx keeps the first point of a leaf that
+    reaches the minimum, in the order of the tree's own index array (equal points share a leaf): the rank of vertex v is its
+    place in that array, of scipy's own cKDTree of the rows the reference builds it from (bpw:604-619: every vertex, those
+    without a triangle of the side parked at (10, 10, 10)).  int32 [V]."""
+    from scipy.spatial import cKDTree
+    tree = cKDTree(side_rows)
+    rank = np.empty(side_rows.shape[0], dtype=np.int32)
+    rank[np.asarray(tree.indices)] = np.arange(side_rows.shape[0], dtype=np.int32)
+    return rank
 
 
 def _sample_tie_rank(pix, pos, insertion, W):
@@ -455,9 +470,11 @@ def nearest_side_vertex(t, point):
     reference moved rows under its tree (see build_part_tables), then the walk of that stale tree."""
     if len(getattr(t, 'kd_split_dim', ())):
         return stale_kd_query(t, point)
-    d = t._side_data[t.vertex_is_side] - np.asarray(point, dtype=np.float64)[None, :]
+    ids = np.nonzero(t.vertex_is_side)[0]
+    d = t._side_data[ids] - np.asarray(point, dtype=np.float64)[None, :]
     d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
-    return int(np.nonzero(t.vertex_is_side)[0][int(np.argmin(d2))])
+    nearest = ids[d2 == d2.min()]                      # doubled vertices: the tree's own order decides (_vertex_tie_rank)
+    return int(nearest[np.argmin(t.vertex_tie_rank[nearest])])
 
 
 def closest_triangle(t, point, vertex):
@@ -871,10 +888,10 @@ def texture_image(t, painted=None, thickness=None, color_mode='RGB'):
 _ARRAY_FIELDS = ['vertices', 'tri_vidx', 'tri_side', 'tri_area', 'tri_area_valid', 'tri_center', 'tri_a', 'tri_v0',
                  'tri_v1', 'tri_d00', 'tri_d01', 'tri_d11', 'tri_inv', 'tri_normal', 'sample_pix', 'sample_pos',
                  'sample_cell', 'vertex_is_side', '_side_data', 'col_v0', 'col_e1', 'col_e2', 'grid_lo', 'grid_hi',
-                 'grid_range', 'beams', 'front_ids', 'back_pix', 'tex_init', 'sample_tie_rank'] + list(KD_FIELDS)
+                 'grid_range', 'beams', 'front_ids', 'back_pix', 'tex_init', 'sample_tie_rank', 'vertex_tie_rank'] + list(KD_FIELDS)
 _SCALAR_FIELDS = ['name', 'tex_w', 'tex_h', 'collision_mode', 'obs_grad', 'paint_radius', 'a0', 'a1', 'a2', 'lwr', 'max_grid_size',
                   'density', 'n_hull_corrected', 'n_smoothed']
-TABLE_FORMAT_VERSION = 3          # 3: back_pix, tex_init (texture_image), sample_tie_rank
+TABLE_FORMAT_VERSION = 3          # 3: back_pix, tex_init (texture_image), sample_tie_rank, vertex_tie_rank
 
 
 def save_tables(t, path):

@@ -258,11 +258,34 @@ def sparse_sheet(seed=2):
     return v, uv, f, fvt
 
 
+def seam_sheet(seed=1):
+    """The quadratic sheet with a seam: every vertex that triangles on both sides of the line y = 0.42 (local frame) share is written
+    twice, the triangles beyond the line use the copy -- what OBJ exporters do along UV seams (the reference's test.obj has
+    179 such vertices).  Two vertices at one position are equally near to every query: which of them cKDTree.query returns
+    (bpw:526), and with it which triangles the hook point may choose from, is the tree's own business
+    (part_tables._vertex_tie_rank).  Takes the Part_Dict slot of door_lf.urdf (Part_NO 2)."""
+    v, uv, f, fvt = quadratic_sheet(seed)
+    beyond = v[f].mean(axis=1)[:, 1] > 0.42
+    used_near = np.zeros(v.shape[0], dtype=bool)
+    used_far = np.zeros(v.shape[0], dtype=bool)
+    used_near[f[~beyond].ravel()] = True
+    used_far[f[beyond].ravel()] = True
+    shared = np.nonzero(used_near & used_far)[0]
+    copy_of = -np.ones(v.shape[0], dtype=np.int64)
+    copy_of[shared] = v.shape[0] + np.arange(shared.size)
+    v2 = np.concatenate([v, v[shared]], axis=0)
+    f2 = f.copy()
+    sel = f2[beyond]
+    f2[beyond] = np.where(copy_of[sel] >= 0, copy_of[sel], sel)
+    return v2, uv, f2, fvt
+
+
 # 'door_rr_big': the door panel on a 480 x 480 texture, like the reference's Part_NO 8 (door_rr_big.urdf with
 # pattern_big.jpg): ~38 000 front samples, i.e. a part whose coverage masks do not fit four words per lane.
-PARTS = {'door_test': door_panel, 'square': quadratic_sheet, 'door_rr_big': door_panel, 'test': sparse_sheet}
+PARTS = {'door_test': door_panel, 'square': quadratic_sheet, 'door_rr_big': door_panel, 'test': sparse_sheet, 'door_lf': seam_sheet}
 TEXTURES = {'door_test': ((240, 240), 'pattern.jpg'), 'square': ((240, 240), 'pattern.jpg'),
-            'door_rr_big': ((480, 480), 'pattern_big.jpg'), 'test': ((240, 240), 'pattern.jpg')}
+            'door_rr_big': ((480, 480), 'pattern_big.jpg'), 'test': ((240, 240), 'pattern.jpg'),
+            'door_lf': ((240, 240), 'pattern.jpg')}
 
 
 def write_synthetic_parts(root, names=('door_test', 'square')):

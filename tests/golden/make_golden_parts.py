@@ -150,6 +150,30 @@ def reference_meshes(which=('door_test', 'square')):
                                                             bool(ep['done'][-1])), flush=True)
 
 
+def seam_synthetic():
+    """The synthetic sheet with a seam of doubled vertices ('door_lf', Part_NO 2; synth_parts.seam_sheet): two vertices at one
+    position are equally near to every query, and which one cKDTree.query returns decides the triangles the hook point chooses
+    from.  Sweeps across the seam + random episodes, recorded from the reference -> episodes_seam.npz, g0_tables_seam.npz."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root, names=('door_lf',))
+    drv = RefDriver(root, 2)
+    np.savez_compressed(os.path.join(HERE, 'g0_tables_seam.npz'), **table_digest(drv))
+    eps = {}
+    across = ([0] * 14 + [1] * 2 + [2] * 14 + [1] * 2) * 8
+    drv.configure('section', 4, 'anchor', max_points=14350)
+    eps['g17_seam_across'] = drv.episode(30, lambda k, obs: across[k], max_steps=200, want_idx=0)
+    drv.configure('grid', 4, 'anchor', overlap=True, turning=True, max_points=14350)
+    eps['g17_seam_across_grid'] = drv.episode(31, lambda k, obs: across[k], max_steps=120, want_idx=0)
+    drv.configure('section', 4, 'all', max_points=14350)
+    for s in range(4):
+        eps['g17_seam_all_%d' % s] = drv.episode(800 + s, random_policy(120 + s), max_steps=150)
+    drv.configure('section', 4, 'anchor', paint_method='normal', max_points=14350)
+    eps['g17_seam_cone'] = drv.episode(32, lambda k, obs: across[k], max_steps=12, want_idx=0)
+    save_episodes(os.path.join(HERE, 'episodes_seam.npz'), eps)
+    for k, ep in sorted(eps.items()):
+        print('%-24s steps %3d return %8.3f done %s' % (k, len(ep['actions']), float(ep['total_return']), bool(ep['done'][-1])), flush=True)
+
+
 def sparse_synthetic():
     """The coarse synthetic sheet ('test', Part_NO 9): the reference moves vertex rows under its kd-tree there."""
     root = os.path.join(HERE, '_synth_root')
@@ -233,6 +257,8 @@ def hsi_cone_door():
 
 if __name__ == '__main__':
     what = sys.argv[1:] or ['digests', 'big', 'door_rr']
+    if 'seam' in what:
+        seam_synthetic()
     if 'reference_meshes' in what:
         reference_meshes()
     if 'hsi_cone' in what:

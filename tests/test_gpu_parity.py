@@ -61,6 +61,9 @@ def test_gpu_replays_reference_episode(tag, name):
     ('square', dict(obs_mode='grid', paint_method='normal', overlap_penalty=True, max_possible_point=14350, _n=32,
                     _steps=6)),
     ('square', dict(obs_mode='section', paint_method='normal', max_possible_point=14350, _n=768, _steps=8)),
+    # the sheet with a seam of doubled vertices: equally near vertices resolve in the reference tree's order (vertex_rank)
+    ('door_lf', dict(obs_mode='section', max_possible_point=14350)),
+    ('door_lf', dict(obs_mode='grid', overlap_penalty=True, paint_method='normal', max_possible_point=14350, _n=64, _steps=8)),
 ])
 def test_gpu_matches_oracle_on_random_batch(part, kw):
     tables = synthetic_tables(part)

@@ -19,7 +19,7 @@ def sha(a):
 
 
 @pytest.mark.parametrize('tag,name,radius', [('door', 'door_test', 0.051), ('sheet', 'square', 0.051),
-                                             ('sheet_r040', 'square', 0.04)])
+                                             ('sheet_r040', 'square', 0.04), ('seam', 'door_lf', 0.051)])
 def test_tables_match_reference_digests(tag, name, radius):
     """G0: every static table equals what the reference built for the same synthetic mesh (the last case
     with PaintToolProfile.PAINT_RADIUS = 0.04)."""
@@ -292,3 +292,25 @@ def test_texture_image_equals_the_reference(tag, name, part, after_reset):
     assert np.array_equal(img, want[name])
     import hashlib
     assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == str(want[name + '_sha256'])
+
+
+def test_doubled_vertices_resolve_as_the_reference_tree_does():
+    """Vertices written twice in the OBJ (UV seams) are equally near to every query; cKDTree.query (bpw:526) returns the one its
+    own index array lists first.  part_tables._vertex_tie_rank restates that order with scipy's own tree: on the synthetic
+    seam sheet every doubled vertex queried at its own position resolves as scipy resolves it, and not always to the lower
+    index (the rule this project used before: the reference's episodes across the seam did not replay with it)."""
+    from scipy.spatial import cKDTree
+    t = synthetic_tables('door_lf')
+    rows = t._side_data
+    tree = cKDTree(rows)
+    side = np.nonzero(t.vertex_is_side)[0]
+    _, first, counts = np.unique(rows[side], axis=0, return_index=True, return_counts=True)
+    doubled = side[first[counts > 1]]
+    assert len(doubled) >= 40
+    lower_wins = 0
+    for v in doubled:
+        want = int(tree.query(rows[v], k=1)[1])
+        assert part_tables.nearest_side_vertex(t, rows[v]) == want
+        twins = np.nonzero((rows == rows[v]).all(axis=1))[0]
+        lower_wins += int(want == twins.min())
+    assert 0 < lower_wins < len(doubled)                 # neither "lowest index" nor "highest index" is the rule
