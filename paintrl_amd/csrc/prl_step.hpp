@@ -477,9 +477,15 @@ __device__ __forceinline__ void stream_store(T *p, T v) {
 #endif
 }
 
-struct GlobalMasks {
+template <bool TRACK>
+struct GlobalMasksT {
     uint64_t *painted, *last;     // rows of this env
     int n_words, lane;
+    // TRACK: what load() read, so that store() writes back only the words a step changed (a step paints ~7 of the door's 158
+    // words and clears / sets a dozen of the last-shot mask: the rest of the two rows would be rewritten with what it holds --
+    // 2.5 KB per env-step, most of the launch's write traffic; -DPRL_STORE_ALL_WORDS is the A/B switch).  Costs 4 KW vector
+    // registers: the step kernels track (except the atan2-sector variants), the other kernels do not.
+    mutable uint64_t p0[TRACK ? KW_MAX : 1], l0[TRACK ? KW_MAX : 1];
     template <int KW>
     __device__ __forceinline__ void load(uint64_t p[KW_MAX], uint64_t l[KW_MAX]) const {
 #pragma unroll
@@ -488,6 +494,10 @@ struct GlobalMasks {
             const bool in = (int)w < n_words;
             p[k] = in ? stream_load(painted + w) : 0;
             l[k] = in ? stream_load(last + w) : 0;
+            if constexpr (TRACK) {
+                p0[k] = p[k];
+                l0[k] = l[k];
+            }
         }
     }
     template <int KW>
@@ -496,11 +506,22 @@ struct GlobalMasks {
         for (int k = 0; k < KW; ++k) {
             const uint32_t w = lane + 64 * k;
             if ((int)w < n_words) {
-                stream_store(painted + w, p[k]);
-                stream_store(last + w, l[k]);
+#ifdef PRL_STORE_ALL_WORDS
+                constexpr bool changed_only = false;
+#else
+                constexpr bool changed_only = TRACK;
+#endif
+                if constexpr (changed_only) {
+                    if (p[k] != p0[k]) stream_store(painted + w, p[k]);
+                    if (l[k] != l0[k]) stream_store(last + w, l[k]);
+                } else {
+                    stream_store(painted + w, p[k]);
+                    stream_store(last + w, l[k]);
+                }
             }
         }
     }
 };
+typedef GlobalMasksT<false> GlobalMasks;
 
 }  // namespace
