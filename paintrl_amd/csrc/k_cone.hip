@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
     const double new_angle = uni_d(a.cone_aux[2 * (size_t)env]);
     const double pair = a.cone_aux[2 * (size_t)env + 1];
     const int counter_before = rfl(__double2loint(pair)), facet_hint = rfl(__double2hiint(pair));
-    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+    const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0}, valid[KW_MAX] = {0, 0, 0, 0};
     masks.template load<KW>(painted, last);
     uint64_t *row = s_row[wave][0];

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         if (env < a.n_envs) {
             PartRef P = *(const PartDev CAS *)(a.parts + rfl(a.env_part ? a.env_part[env] : 0));
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            const GlobalMasks g = global_masks(a, env, P.n_words, lane);
             const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
             uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
             g.template load<KW>(p, l);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         if (env < a.n_envs) {
             PartRef P = *(const PartDev CAS *)(a.parts + rfl(a.env_part ? a.env_part[env] : 0));
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const GlobalMasks g{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            const GlobalMasks g = global_masks(a, env, P.n_words, lane);
             const LdsMasks m{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
             uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
             m.template load<KW>(p, l);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+    const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
     double delta1, delta2, new_angle;
     decode_discrete_action(C, act, delta1, delta2, new_angle);
     const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
             EnvState S;
             load_state_motion(state_rec, S);
-            const GlobalMasks masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+            const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
             double delta1, delta2, new_angle;
             decode_discrete_action(C, act, delta1, delta2, new_angle);
             const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};

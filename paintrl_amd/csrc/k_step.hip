@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     if (__builtin_amdgcn_s_getreg(63492) & 1) __builtin_amdgcn_s_sleep(PRL_STAGGER);      // four envs that share it)
 #endif
     PROF_BEGIN();
-    const GlobalMasksT<!GENSEC> masks{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, P.n_words, lane};
+    const GlobalMasksT<!GENSEC> masks = global_masks<!GENSEC>(a, env, P.n_words, lane);
+    masks.prefetch();
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     const int dn = step_env<KW, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,

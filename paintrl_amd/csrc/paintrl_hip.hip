@@ -94,6 +94,7 @@ struct PrlBatch {
     CfgDev *cfg_dev = nullptr;
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
+    uint64_t *last_nz = nullptr;          // StepArgs::last_nz (batches of parts with register-resident masks)
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     double *cone_shots = nullptr, *cone_aux = nullptr;      // PAINT_METHOD 'normal' only (StepArgs)
     int *cone_hits = nullptr, *cone_work = nullptr;
@@ -706,6 +707,7 @@ StepArgs base_args(PrlBatch *b) {
     a.mask_stride = b->mask_stride;
     a.painted = b->painted;
     a.last = b->last;
+    a.last_nz = b->last_nz;
     a.thick = b->thick;
     a.state = b->state;
     a.cone_shots = b->cone_shots;
@@ -862,6 +864,8 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->painted), mask_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last), mask_bytes);
+    if (e == hipSuccess && b->kw <= KW_MAX) e = hipMalloc(reinterpret_cast<void **>(&b->last_nz), sizeof(uint64_t) * KW_MAX * (size_t)n_envs);
+    if (e == hipSuccess && b->last_nz) e = hipMemset(b->last_nz, 0, sizeof(uint64_t) * KW_MAX * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->state), state_bytes);
     if (e == hipSuccess && cfg->color_mode == PRL_COLOR_HSI) {
         e = hipMalloc(reinterpret_cast<void **>(&b->thick), mask_bytes * 8);        // one byte per sample
@@ -919,6 +923,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->env_part_dev);
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
+    (void)hipFree(b->last_nz);
     (void)hipFree(b->thick);
     (void)hipFree(b->cone_shots);
     (void)hipFree(b->cone_aux);

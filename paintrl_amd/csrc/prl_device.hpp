@@ -152,6 +152,8 @@ struct StepArgs {
     const int *env_part;          // device, or nullptr
     int n_envs, mask_stride;
     uint64_t *painted, *last;
+    uint64_t *last_nz;            // [n_envs][KW_MAX]: bit w & 63 of word w >> 6 = word w of the env's last-shot row is not zero (parts of
+                                  // up to 16 384 samples; every writer of `last` keeps it, or sets it to all ones)
     uint8_t *thick;               // COLOR_MODE 'HSI': one byte per sample, [n_envs][64 * mask_stride]; else nullptr
     double *state;
     const void *actions;

@@ -114,6 +114,10 @@ __device__ __forceinline__ void store_masks(const StepArgs &a, int env, int n_wo
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const uint32_t w = lane + 64 * k;
+        if (a.last_nz) {                               // StepArgs::last_nz: the words of the last-shot row that are not zero
+            const uint64_t set = ballot64((int)w < n_words && last[k] != 0);
+            if (lane == 0) a.last_nz[(size_t)env * KW_MAX + k] = set;
+        }
         if ((int)w < n_words) {
             pe[w] = painted[k];
             le[w] = last[k];

@@ -481,6 +481,25 @@ template <bool TRACK>
 struct GlobalMasksT {
     uint64_t *painted, *last;     // rows of this env
     int n_words, lane;
+    // StepArgs::last_nz row of this env (or nullptr): which words of the last-shot row are not zero -- a dozen of the door's 158.
+    // TRACK kernels read only those (the row is otherwise 1.2 KB of zeros per env-step) and record the new set; the others
+    // mark every word (the row is then read whole next time).
+    uint64_t *nz;
+    // this lane's bits of `nz` (bit k: word lane + 64 k), fetched by prefetch() when the kernel starts -- with the state
+    // record, not in front of the masks' own loads (read there, the set cost a dependent round trip: 39.7 against 39.3 us)
+    mutable uint32_t mine = ~0u;
+    __device__ __forceinline__ void prefetch() const {
+#ifndef PRL_LOAD_ALL_WORDS                           // (A/B switch)
+        if constexpr (TRACK) {
+            if (nz) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < KW_MAX; ++k) m |= (uint32_t)((nz[k] >> lane) & 1) << k;
+                mine = m;
+            }
+        }
+#endif
+    }
     // TRACK: what load() read, so that store() writes back only the words a step changed (a step paints ~7 of the door's 158
     // words and clears / sets a dozen of the last-shot mask: the rest of the two rows would be rewritten with what it holds --
     // 2.5 KB per env-step, most of the launch's write traffic; -DPRL_STORE_ALL_WORDS is the A/B switch).  Costs 4 KW vector
@@ -493,7 +512,8 @@ struct GlobalMasksT {
             const uint32_t w = lane + 64 * k;
             const bool in = (int)w < n_words;
             p[k] = in ? stream_load(painted + w) : 0;
-            l[k] = in ? stream_load(last + w) : 0;
+            const bool lin = in && ((mine >> k) & 1);
+            l[k] = lin ? stream_load(last + w) : 0;
             if constexpr (TRACK) {
                 p0[k] = p[k];
                 l0[k] = l[k];
@@ -505,6 +525,10 @@ struct GlobalMasksT {
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
             const uint32_t w = lane + 64 * k;
+            if (nz) {
+                const uint64_t set = TRACK ? ballot64((int)w < n_words && l[k] != 0) : ~0ull;
+                if (lane == 0) nz[k] = set;
+            }
             if ((int)w < n_words) {
 #ifdef PRL_STORE_ALL_WORDS
                 constexpr bool changed_only = false;
@@ -523,5 +547,12 @@ struct GlobalMasksT {
     }
 };
 typedef GlobalMasksT<false> GlobalMasks;
+
+// the mask rows of env `env` of the launch (GlobalMasksT above)
+template <bool TRACK = false>
+__device__ __forceinline__ GlobalMasksT<TRACK> global_masks(const StepArgs CAS &a, int env, int n_words, int lane) {
+    uint64_t *nz = a.last_nz ? a.last_nz + (size_t)env * KW_MAX : nullptr;
+    return GlobalMasksT<TRACK>{a.painted + (size_t)env * a.mask_stride, a.last + (size_t)env * a.mask_stride, n_words, lane, nz};
+}
 
 }  // namespace
