@@ -114,7 +114,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
     const double p2 = d0 * e21 - d1 * e20;
     const double det = (e10 * p0 + e11 * p1) + e12 * p2;
     if (!(fabs(det) >= RAY_EPS_DET)) return out;
-    const double inv = 1.0 / det;
+    const double inv = rcp_det(det);
     const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
     const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
     const double q0 = s1 * e12 - s2 * e11;

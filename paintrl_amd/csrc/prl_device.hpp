@@ -44,6 +44,7 @@ typedef const int GAS *gint_p;
 typedef const uint64_t GAS *gu64_p;
 typedef const uint8_t GAS *gu8_p;
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));

@@ -177,12 +177,27 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
         const bool in = s >= lo && s < hi;
         uint64_t b[PAINT_PER_ACTION];
         uint64_t any = 0, unsure = 0;
+        // the five float distances, two shots per instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: the same IEEE operations
+        // in the same order as one shot at a time, 18 instructions instead of 30)
+        float dd5[PAINT_PER_ACTION];
+        static_assert(PAINT_PER_ACTION == 5, "shot pairs below");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x2 cx = {cf[2 * q][0], cf[2 * q + 1][0]}, cy = {cf[2 * q][1], cf[2 * q + 1][1]}, cz = {cf[2 * q][2], cf[2 * q + 1][2]};
+            const f32x2 px = {pf.x, pf.x}, py = {pf.y, pf.y}, pz = {pf.z, pf.z};
+            const f32x2 dx = px - cx, dy = py - cy, dz = pz - cz;
+            const f32x2 dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            dd5[2 * q] = dd.x;
+            dd5[2 * q + 1] = dd.y;
+        }
+        {
+            const float dx = pf.x - cf[4][0], dy = pf.y - cf[4][1], dz = pf.z - cf[4][2];
+            dd5[4] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        }
 #pragma unroll
         for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-            const float dx = pf.x - cf[k][0], dy = pf.y - cf[k][1], dz = pf.z - cf[k][2];
-            const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            b[k] = ballot64(in && dd <= r2_in);
-            unsure |= b[k] ^ ballot64(in && dd <= r2_out);
+            b[k] = ballot64(in && dd5[k] <= r2_in);
+            unsure |= b[k] ^ ballot64(in && dd5[k] <= r2_out);
             any |= b[k];
         }
 #ifdef PRL_FORCE_F64_PAINT

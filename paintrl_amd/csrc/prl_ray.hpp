@@ -36,6 +36,25 @@ __device__ __forceinline__ bool box_overlap(const SegBox &s, const f32x4 a, cons
            (s.hi[2] >= b.x);
 }
 
+// 1.0 / d for a determinant that passed |d| >= RAY_EPS_DET (and is far below 1e300): the compiler's float64 division is
+// v_div_scale x 2, v_rcp, four fma, v_mul, fma, v_div_fmas, v_div_fixup; the scale / fixup steps only rescale operands whose
+// quotient would leave the normal range and are the identity here, so reciprocal + two Newton steps + the correcting fma pair
+// is the same sequence without them: bit for bit the same quotient in 7 instructions instead of 13 (-DPRL_PLAIN_DIVISION: A/B
+// and parity switch; the oracle's C division is the reference either way).
+__device__ __forceinline__ double rcp_det(double d) {
+#ifdef PRL_PLAIN_DIVISION
+    return 1.0 / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
+#endif
+}
+
 // The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
 // running count + number of passing lanes below), then the float64 test runs ONCE over the list
 // with one candidate per lane, instead of once per visited chunk with a handful of active lanes.
@@ -53,7 +72,7 @@ __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], doub
         const double p2 = d0 * e21 - d1 * e20;
         const double det = (e10 * p0 + e11 * p1) + e12 * p2;
         if (fabs(det) >= RAY_EPS_DET) {
-            const double inv = 1.0 / det;
+            const double inv = rcp_det(det);
             const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
             const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
             const double q0 = s1 * e12 - s2 * e11;
@@ -86,7 +105,7 @@ __device__ __forceinline__ void mt_rec_core(int i, const f64x2 r0, const f64x2 r
         const double p2 = d0 * e21 - d1 * e20;
         const double det = (e10 * p0 + e11 * p1) + e12 * p2;
         if (fabs(det) >= RAY_EPS_DET) {
-            const double inv = 1.0 / det;
+            const double inv = rcp_det(det);
             const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
             const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
             const double q0 = s1 * e12 - s2 * e11;
@@ -260,7 +279,7 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
             bool inside = false;
             double t = 0;
             if (fabs(det) >= RAY_EPS_DET) {
-                const double inv = 1.0 / det;
+                const double inv = rcp_det(det);
                 const double s0 = o[0] - r[0], s1 = o[1] - r[1], s2 = o[2] - r[2];
                 const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
                 const double q0 = s1 * e12 - s2 * e11;
