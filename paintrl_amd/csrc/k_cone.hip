@@ -32,7 +32,9 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
     const double new_angle = uni_d(a.cone_aux[2 * (size_t)env]);
     const double pair = a.cone_aux[2 * (size_t)env + 1];
     const int counter_before = rfl(__double2loint(pair)), facet_hint = rfl(__double2hiint(pair));
-    const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
+    // (the rows' words this step leaves alone are not written back, the zero words of the last-shot row not read: GlobalMasksT)
+    const GlobalMasksT<true> masks = global_masks<true>(a, env, P.n_words, lane);
+    masks.prefetch();
     uint64_t painted[KW_MAX] = {0, 0, 0, 0}, last[KW_MAX] = {0, 0, 0, 0}, valid[KW_MAX] = {0, 0, 0, 0};
     masks.template load<KW>(painted, last);
     uint64_t *row = s_row[wave][0];

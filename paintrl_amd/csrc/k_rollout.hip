@@ -107,6 +107,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             uint64_t p[KW_MAX] = {0, 0, 0, 0}, l[KW_MAX] = {0, 0, 0, 0};
             g.template load<KW>(p, l);
             m.template store<KW>(p, l);
+            last_row_untracked(a, env, lane);                 // (the rows come back whole at the end of the fragment)
         }
     }
     FRAG_DECL();
@@ -172,7 +173,8 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
+    const GlobalMasksT<true> masks = global_masks<true>(a, env, P.n_words, lane);      // (changed words only: GlobalMasksT)
+    masks.prefetch();
     double delta1, delta2, new_angle;
     decode_discrete_action(C, act, delta1, delta2, new_angle);
     const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
@@ -248,6 +250,11 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
     __shared__ double s_kd[KD ? POLICY_WAVES : 1][KD ? KD_HEAP * 5 : 1];
     const PolicyFragmentArgs CAS *g0 = (const PolicyFragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int wave0 = rfl((int)(threadIdx.x >> 6));
+    {   // this kernel writes the last-shot rows whole, step by step: say so once (prl_step.hpp last_row_untracked)
+        const StepArgs CAS &a0 = opaque(g0)->f.s;
+        const int env_ = (int)blockIdx.x * POLICY_WAVES + wave0;
+        if (env_ < a0.n_envs) last_row_untracked(a0, env_, (int)(threadIdx.x & 63));
+    }
     for (int t = 0;; ++t) {
         const PolicyFragmentArgs CAS &g = *opaque(g0);
         const int lane = opaque_v((int)(threadIdx.x & 63)), wave = opaque_s(wave0), tid = 64 * wave + lane;

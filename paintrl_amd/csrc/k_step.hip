@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     PROF_BEGIN();
     const GlobalMasksT<!GENSEC> masks = global_masks<!GENSEC>(a, env, P.n_words, lane);
     masks.prefetch();
+    if constexpr (GENSEC) last_row_untracked(a, env, lane);      // (the atan2-sector kernels write the rows whole)
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     const int dn = step_env<KW, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,

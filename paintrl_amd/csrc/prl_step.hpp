@@ -525,9 +525,11 @@ struct GlobalMasksT {
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
             const uint32_t w = lane + 64 * k;
-            if (nz) {
-                const uint64_t set = TRACK ? ballot64((int)w < n_words && l[k] != 0) : ~0ull;
-                if (lane == 0) nz[k] = set;
+            if constexpr (TRACK) {
+                if (nz) {
+                    const uint64_t set = ballot64((int)w < n_words && l[k] != 0);
+                    if (lane == 0) nz[k] = set;
+                }
             }
             if ((int)w < n_words) {
 #ifdef PRL_STORE_ALL_WORDS
@@ -547,6 +549,12 @@ struct GlobalMasksT {
     }
 };
 typedef GlobalMasksT<false> GlobalMasks;
+
+// A kernel that writes last-shot rows without tracking them (the persistent rollout kernels) says so ONCE, before its first
+// store: every word of env `env`'s row counts as non-zero until a tracking kernel has read it whole and recorded the real set.
+__device__ __forceinline__ void last_row_untracked(const StepArgs CAS &a, int env, int lane) {
+    if (a.last_nz && lane < KW_MAX) a.last_nz[(size_t)env * KW_MAX + lane] = ~0ull;
+}
 
 // the mask rows of env `env` of the launch (GlobalMasksT above)
 template <bool TRACK = false>
