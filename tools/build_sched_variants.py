@@ -1,0 +1,44 @@
+"""A/B of compiler scheduling strategies on one unit: copies the product objects, recompiles `unit` with the extra
+-mllvm flags, links tools/_ab/<name>.so.      python tools/build_sched_variants.py [unit]"""
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from paintrl_amd import build as hb  # noqa: E402
+
+VARIANTS = {
+    'c_base': [],
+    'c_maxilp': ['-mllvm', '-amdgpu-sched-strategy=max-ilp'],
+    'c_memclause': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
+    'c_iterilp': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp'],
+    'c_minreg': ['-mllvm', '-amdgpu-sched-strategy=iterative-minreg'],
+    'c_bias100': ['-mllvm', '-amdgpu-schedule-metric-bias=100'],
+    'c_bias0': ['-mllvm', '-amdgpu-schedule-metric-bias=0'],
+    'c_relaxed': ['-mllvm', '-amdgpu-schedule-relaxed-occupancy'],
+    'c_nopost': ['-mllvm', '-enable-post-misched=0'],
+    'c_trackers': ['-mllvm', '-amdgpu-use-amdgpu-trackers'],
+    'c_prealloc': ['-mllvm', '-amdgpu-prealloc-sgpr-spill-vgprs'],
+}
+
+
+def main():
+    unit = sys.argv[1] if len(sys.argv) > 1 else 'k_step3'
+    only = sys.argv[2:] or list(VARIANTS)
+    prod = os.path.join(REPO, 'paintrl_amd', '_obj', 'product')
+    for name in only:
+        flags = VARIANTS[name]
+        d = os.path.join(REPO, 'paintrl_amd', '_obj', 'ab_' + name)
+        if not os.path.isdir(d):
+            shutil.copytree(prod, d)
+        out = os.path.join(REPO, 'tools', '_ab', name + '.so')
+        try:
+            hb.build_named('ab_' + name, out, extra=flags, only=[unit], force=True)
+            print(name, 'ok', flush=True)
+        except Exception as e:      # a strategy this compiler does not know
+            print(name, 'FAILED', e, flush=True)
+
+
+if __name__ == '__main__':
+    main()
