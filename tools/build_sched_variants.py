@@ -20,6 +20,11 @@ VARIANTS = {
     'c_nopost': ['-mllvm', '-enable-post-misched=0'],
     'c_trackers': ['-mllvm', '-amdgpu-use-amdgpu-trackers'],
     'c_prealloc': ['-mllvm', '-amdgpu-prealloc-sgpr-spill-vgprs'],
+    'c_ilp_nopost': ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-enable-post-misched=0'],
+    'c_ilp_nopost_pre': ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-enable-post-misched=0', '-mllvm',
+                         '-amdgpu-prealloc-sgpr-spill-vgprs'],
+    'c_nopost_relaxed': ['-mllvm', '-enable-post-misched=0', '-mllvm', '-amdgpu-schedule-relaxed-occupancy'],
+    'c_ilp_relaxed': ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-amdgpu-schedule-relaxed-occupancy'],
 }
 
 

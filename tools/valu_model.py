@@ -48,7 +48,7 @@ def encoding_class(m):
 def static_mix():
     out = os.path.join(tempfile.mkdtemp(prefix='prl_isa_'), 'k.s')
     subprocess.check_call([hb.hipcc(), '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-std=c++17', '-S', '--cuda-device-only',
-                           '-DPRL_KW=3', '-I', os.path.join(REPO, 'include'), '-I', hb.CSRC, os.path.join(hb.CSRC, 'k_step.hip'),
+                           '-I', os.path.join(REPO, 'include'), '-I', hb.CSRC] + list(next(u[2] for u in hb.UNITS if u[0] == 'k_step3')) + [os.path.join(hb.CSRC, 'k_step.hip'),
                            '-o', out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split('\n')
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and l.rstrip().endswith(':') is False and ':' in l)
