@@ -79,7 +79,7 @@ constexpr int CONE_WALK_STEPS = PRL_WALK_STEPS;
 #define PRL_CONE_JOINT_FROM 5
 #endif
 constexpr int CONE_JOINT_FROM = PRL_CONE_JOINT_FROM;
-#define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane (triangle tolerances are ~1e-9 of an edge)
+// (CONE_MISS_MARGIN: prl_ray.hpp)
 
 // A beam ENTERS a facet for the purposes of the walk from this squared cosine on.  The single-facet criterion (prl_ray.hpp)
 // needs the entry point FACET_EDGE_MARGIN = 1e-6 m clear of the facet's edges and the other facets' tolerance fringes (1e-9 of
@@ -300,34 +300,6 @@ __device__ __forceinline__ int cone_walk_lanes(PartRef P, const double pos[3], c
         state = 3;
     }
     return state;
-}
-
-// The outline test of cone_rays_lanes for ONE beam (pos -> dst, the same on every lane), the edges of the outline over the
-// lanes: whether the beam passes beside the part (then it misses every triangle).
-__device__ __forceinline__ bool beam_outside_outline_wave(PartRef P, const double pos[3], const double dst[3], int lane) {
-    if (P.n_outline <= 0) return false;
-    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
-    const double oz = sel3(pos[0], pos[1], pos[2], P.a0), dz = sel3(d0, d1, d2, P.a0);
-    const double lo = P.slab_lo - CONE_MISS_MARGIN, hi = P.slab_hi + CONE_MISS_MARGIN;
-    double ta = 0.0, tb = 1.0;
-    if (dz != 0.0) {
-        const double t0 = (lo - oz) / dz, t1 = (hi - oz) / dz;
-        ta = fmax(0.0, fmin(t0, t1) - 1e-9);
-        tb = fmin(1.0, fmax(t0, t1) + 1e-9);
-        if (ta > tb) return true;                             // never inside the slab
-    } else if (oz < lo || oz > hi) {
-        return true;
-    }
-    const double o1 = sel3(pos[0], pos[1], pos[2], P.a1), o2 = sel3(pos[0], pos[1], pos[2], P.a2);
-    const double e1 = sel3(d0, d1, d2, P.a1), e2 = sel3(d0, d1, d2, P.a2);
-    const double ax = o1 + ta * e1, ay = o2 + ta * e2, bx = o1 + tb * e1, by = o2 + tb * e2;
-    const f64x2 GAS *ol = reinterpret_cast<const f64x2 GAS *>(P.outline);
-    for (int base = 0; base < P.n_outline; base += 64) {      // (the table is padded to a multiple of 64 rows)
-        const f64x2 pq = ldg(ol, 2 * (base + lane)), nq = ldg(ol, 2 * (base + lane) + 1);
-        const double sa = nq.x * (ax - pq.x) + nq.y * (ay - pq.y), sb = nq.x * (bx - pq.x) + nq.y * (by - pq.y);
-        if (ballot64(base + lane < P.n_outline && sa > CONE_MISS_MARGIN && sb > CONE_MISS_MARGIN) != 0) return true;
-    }
-    return false;
 }
 
 // Beams beside the part, one per lane (`state` 3 -> 2 where proven).  The collision set lies inside the slab [slab_lo,

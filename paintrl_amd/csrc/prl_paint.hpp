@@ -145,7 +145,7 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     band *= 4096.0;
 #endif
     // thresholds rounded outward, so that the float comparisons are at least as cautious as the double ones
-    const float r2_in = nextafterf((float)(r2 - band), -INFINITY), r2_out = nextafterf((float)(r2 + band), INFINITY);
+    const float r2_in = f32_at_or_below(r2 - band), r2_out = f32_at_or_above(r2 + band);
     const f32x4 GAS *s4 = reinterpret_cast<const f32x4 GAS *>(P.samp_f32);
     const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
     const int row_lo = rfl(cy_lo - 1 < 0 ? 0 : cy_lo - 1), row_hi = rfl(cy_hi + 1 > P.sg_ny - 1 ? P.sg_ny - 1 : cy_hi + 1);

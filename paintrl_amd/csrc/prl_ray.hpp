@@ -20,13 +20,35 @@ struct SegBox {
     float lo[3], hi[3];      // axis1, axis2, axis0
 };
 
+// A float at or below / at or above a double, for culling boxes and thresholds that only have to be CAUTIOUS: the nearest
+// float moved outward by 2^-22 of its magnitude (its own rounding error is at most 2^-24 of it) and a tiny absolute step for
+// zero and denormals.  Four instructions; nextafterf is ~43, and a ray that takes the general search paid 12 of them (a tool
+// that has left the part: ten searches a step, every one a miss).  Infinite or NaN input gives +-FLT_MAX: nothing is culled.
+// (-DPRL_EXACT_OUTWARD: the nextafterf form, A/B switch.)
+__device__ __forceinline__ float f32_at_or_below(double x) {
+#ifdef PRL_EXACT_OUTWARD
+    return nextafterf((float)x, -INFINITY);
+#else
+    const float f = (float)x;
+    return fmaxf(f - __builtin_fmaf(fabsf(f), 2.384185791015625e-07f, 1.0e-37f), -3.402823466e+38f);
+#endif
+}
+__device__ __forceinline__ float f32_at_or_above(double x) {
+#ifdef PRL_EXACT_OUTWARD
+    return nextafterf((float)x, INFINITY);
+#else
+    const float f = (float)x;
+    return fminf(f + __builtin_fmaf(fabsf(f), 2.384185791015625e-07f, 1.0e-37f), 3.402823466e+38f);
+#endif
+}
+
 __device__ __forceinline__ SegBox seg_box(const double o3[3], const double d3[3], double tmax) {
     SegBox b;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double e = o3[k] + tmax * d3[k];
-        b.lo[k] = nextafterf((float)fmin(o3[k], e), -INFINITY);
-        b.hi[k] = nextafterf((float)fmax(o3[k], e), INFINITY);
+        b.lo[k] = f32_at_or_below(fmin(o3[k], e));
+        b.hi[k] = f32_at_or_above(fmax(o3[k], e));
     }
     return b;
 }
@@ -53,6 +75,39 @@ __device__ __forceinline__ double rcp_det(double d) {
     const double rem = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(rem, r, r);
 #endif
+}
+
+#define CONE_MISS_MARGIN 1.0e-6      // metres clear of a separating facet plane / outline edge (triangle tolerances are ~1e-9 of an edge)
+// The outline test for ONE segment (pos -> dst, the same on every lane), the edges of the outline over the lanes: whether the
+// segment passes beside the collision set (then it misses every triangle).  The set lies inside the slab [slab_lo, slab_hi] of
+// the third axis and, projected to the principal plane, inside its outline polygon (PartDev::outline, derived on upload): if
+// the stretch of the segment inside the slab (widened by the margin) lies, projected, more than the margin outside one edge
+// of the outline, no triangle can report a hit (their tolerances are ~1e-9 of an edge).  Used by the cone beams' leftover
+// rays (prl_cone.hpp has the one-beam-per-lane form) and by the general search below.
+__device__ __forceinline__ bool beam_outside_outline_wave(PartRef P, const double pos[3], const double dst[3], int lane) {
+    if (P.n_outline <= 0) return false;
+    const double d0 = dst[0] - pos[0], d1 = dst[1] - pos[1], d2 = dst[2] - pos[2];
+    const double oz = sel3(pos[0], pos[1], pos[2], P.a0), dz = sel3(d0, d1, d2, P.a0);
+    const double lo = P.slab_lo - CONE_MISS_MARGIN, hi = P.slab_hi + CONE_MISS_MARGIN;
+    double ta = 0.0, tb = 1.0;
+    if (dz != 0.0) {
+        const double t0 = (lo - oz) / dz, t1 = (hi - oz) / dz;
+        ta = fmax(0.0, fmin(t0, t1) - 1e-9);
+        tb = fmin(1.0, fmax(t0, t1) + 1e-9);
+        if (ta > tb) return true;                             // never inside the slab
+    } else if (oz < lo || oz > hi) {
+        return true;
+    }
+    const double o1 = sel3(pos[0], pos[1], pos[2], P.a1), o2 = sel3(pos[0], pos[1], pos[2], P.a2);
+    const double e1 = sel3(d0, d1, d2, P.a1), e2 = sel3(d0, d1, d2, P.a2);
+    const double ax = o1 + ta * e1, ay = o2 + ta * e2, bx = o1 + tb * e1, by = o2 + tb * e2;
+    const f64x2 GAS *ol = reinterpret_cast<const f64x2 GAS *>(P.outline);
+    for (int base = 0; base < P.n_outline; base += 64) {      // (the table is padded to a multiple of 64 rows)
+        const f64x2 pq = ldg(ol, 2 * (base + lane)), nq = ldg(ol, 2 * (base + lane) + 1);
+        const double sa = nq.x * (ax - pq.x) + nq.y * (ay - pq.y), sb = nq.x * (bx - pq.x) + nq.y * (by - pq.y);
+        if (ballot64(base + lane < P.n_outline && sa > CONE_MISS_MARGIN && sb > CONE_MISS_MARGIN) != 0) return true;
+    }
+    return false;
 }
 
 // The triangles whose own box passes are first compacted (their ids go to a per-wave LDS list, slot =
@@ -386,10 +441,25 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         const double d3[3] = {sel3(d0, d1, d2, P.a1), sel3(d0, d1, d2, P.a2), sel3(d0, d1, d2, P.a0)};
         const f32x4 GAS *boxes = reinterpret_cast<const f32x4 GAS *>(P.col_bbox);
         const f32x4 GAS *chunk_boxes = reinterpret_cast<const f32x4 GAS *>(P.col_chunk_bbox);
-        for (int stage = 0; stage < 2; ++stage) {
+        // The tool beside the part -- a fifth of all env-steps of a random walk, every ray of theirs -- is certified a miss by
+        // the set's outline (one read, ~70 instructions) instead of by two stages of box and triangle tests that find nothing
+        // (-DPRL_NO_OUTLINE_MISS: A/B and parity switch).  Then: a segment whose box meets no chunk of the set misses it too.
+#ifndef PRL_NO_OUTLINE_MISS
+        if (beam_outside_outline_wave(P, o, e, lane)) {
+            WCNT(1, 1);
+            t_out = INFINITY;
+            hint = -1;
+            return -1;
+        }
+#endif
+        const SegBox sb_all = seg_box(o3, d3, 1.0);
+        uint64_t any_chunk = 0;
+        for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64)
+            any_chunk |= ballot64(box_overlap(sb_all, ldg(chunk_boxes, 2 * (cbase + lane)), ldg(chunk_boxes, 2 * (cbase + lane) + 1)));
+        for (int stage = any_chunk ? 0 : 2; stage < 2; ++stage) {
             const double tmax = stage == 0 ? 0.125 : 1.0;
             if (stage == 1) WCNT(1, 1);
-            const SegBox sb = seg_box(o3, d3, tmax);
+            const SegBox sb = stage == 0 ? seg_box(o3, d3, tmax) : sb_all;
             int n_cand = 0;
             for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
                 const f32x4 ca = ldg(chunk_boxes, 2 * (cbase + lane)), cb = ldg(chunk_boxes, 2 * (cbase + lane) + 1);
