@@ -113,7 +113,6 @@ template <int KW>
 __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double x2, const uint64_t painted[KW_MAX],
                                                     int slot0, int lane, uint64_t &tot_l, uint64_t &und_l) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
     // Pass 1, one word per lane and slot: a word whose box lies in one sector is counted whole.  A word
     // that straddles only the vertical line x1 (its row is clear of x2) is resolved by its own lane
     // below; only the rest -- the words of the row that x2 crosses -- is classified sample by sample.
@@ -216,6 +215,49 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     // Pass 3: the words that straddle the tool on both axes or on x2 only, one sample per lane, four words per trip
     // (their loads travel together).  32-bit work only: the uniform valid / painted words become lane predicates
     // (inverse ballot) and the counters are four 8-bit fields (a lane sees at most 64 straddling words per call).
+    // (-DPRL_OBS_SCALAR_MASKS, A/B: the six compares of a word as lane masks and the sector rule + eight population counts
+    // as scalar arithmetic on them -- ~10 vector instructions a word instead of ~35, ~55 scalar ones more: 39.2 against
+    // 37.6 us, profiles/r04_ab_log.txt: the scalar instructions are not free, a wave issues them in its own order.)
+#ifdef PRL_OBS_SCALAR_MASKS
+    uint64_t tot_sc = 0, und_sc = 0;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        uint64_t sm = smask[k];
+        while (sm) {                                // wave-uniform loop over the words that straddle the tool
+            WCNT(6, 1);
+            int L[4];
+            uint64_t vs[4];
+            double xs[4], ys[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool has = sm != 0;
+                L[q] = has ? __builtin_ctzll(sm) : 0;
+                sm &= sm - 1;                       // (0 stays 0)
+                const int w2 = L[q] + 64 * (slot0 + k);
+                xs[q] = ldg(sx, (w2 << 6) + lane);
+                ys[q] = ldg(sy, (w2 << 6) + lane);
+                vs[q] = has ? P.word_valid[w2] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint64_t pw = bcast_u64(painted[k], L[q]);
+                const uint64_t gx = ballot64(xs[q] > x1), lx = ballot64(xs[q] < x1), gy = ballot64(ys[q] > x2), ly = ballot64(ys[q] < x2);
+                const uint64_t on_tool = ballot64(xs[q] == x1 && ys[q] == x2);            // bpw:1032: the tool's own sample is skipped
+                const uint64_t c = vs[q] & ~on_tool, u = c & ~pw;
+                const uint64_t s0 = gx & gy, s1 = lx & gy, s2 = lx & ly, s3 = ~(s0 | s1 | s2);
+                tot_sc += (uint64_t)__popcll(c & s0) | ((uint64_t)__popcll(c & s1) << 16) | ((uint64_t)__popcll(c & s2) << 32) |
+                          ((uint64_t)__popcll(c & s3) << 48);
+                und_sc += (uint64_t)__popcll(u & s0) | ((uint64_t)__popcll(u & s1) << 16) | ((uint64_t)__popcll(u & s2) << 32) |
+                          ((uint64_t)__popcll(u & s3) << 48);
+            }
+        }
+    }
+    if (lane == (slot0 & 63)) {
+        tot_l += tot_sc;
+        und_l += und_sc;
+    }
+#else
+    uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         uint64_t sm = smask[k];
@@ -252,6 +294,7 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
         tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
         und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
     }
+#endif
 }
 
 // section / discrete tail: out[0..g-1] are written by the caller; the pose part follows

@@ -20,6 +20,11 @@ VARIANTS = {
     'c_nopost': ['-mllvm', '-enable-post-misched=0'],
     'c_trackers': ['-mllvm', '-amdgpu-use-amdgpu-trackers'],
     'c_prealloc': ['-mllvm', '-amdgpu-prealloc-sgpr-spill-vgprs'],
+    'c_skip4': ['-mllvm', '-amdgpu-skip-threshold=4'],
+    'c_skip32': ['-mllvm', '-amdgpu-skip-threshold=32'],
+    'c_skip100': ['-mllvm', '-amdgpu-skip-threshold=100'],
+    'c_O2': ['-O2'],
+    'c_setprio': ['-mllvm', '-amdgpu-set-wave-priority=true'],
     'c_ilp_nopost': ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-enable-post-misched=0'],
     'c_ilp_nopost_pre': ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-enable-post-misched=0', '-mllvm',
                          '-amdgpu-prealloc-sgpr-spill-vgprs'],
