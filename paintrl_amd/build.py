@@ -156,7 +156,10 @@ def build_library(force=False, verbose=False):
 # replaced by its general counterpart.  The product library never defines these macros.
 VARIANTS = {
     'force_paint_row_trips_wide_band': ['-DPRL_PAINT_ONE_ROW_PER_TRIP', '-DPRL_WIDE_PAINT_BAND'],
-    'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY'],
+    # (+ the general ray search without the outline's miss certificate, culling boxes by nextafterf, the determinant's
+    # reciprocal as a plain division: the round-4 shortcuts against their plain forms)
+    'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY', '-DPRL_NO_OUTLINE_MISS', '-DPRL_EXACT_OUTWARD',
+                             '-DPRL_PLAIN_DIVISION'],
 }
 
 

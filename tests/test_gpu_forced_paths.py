@@ -2,7 +2,8 @@
 
 __graft_entry__.build() also compiles two diagnostic variants of the library in which the fast paths are
 disabled or stressed (whole-table scans instead of ring searches and the general two-stage ray instead of the
-convex-neighbourhood path; the painter walking one sample-grid row per trip instead of four, with the uncertainty
+convex-neighbourhood path, without the outline's miss certificate, with culling boxes rounded by nextafterf and the
+determinant's reciprocal as a plain division; the painter walking one sample-grid row per trip instead of four, with the uncertainty
 band of its float pre-filter widened 4096-fold so that the float64 confirmation runs constantly).  The parity suites are run against
 each variant in a fresh child process (PAINTRL_LIB selects the library before anything is loaded); the product
 build never defines these macros.

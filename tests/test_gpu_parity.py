@@ -179,6 +179,51 @@ def test_gpu_ray_batch_matches_numpy_and_oracle():
     env.close()
 
 
+def test_gpu_rays_grazing_the_outline():
+    """The general ray search certifies a miss by the collision set's outline (prl_ray.hpp beam_outside_outline_wave,
+    margin 1e-6 m): rays along and near the silhouette -- nanometres to millimetres inside and outside every outline
+    edge, parallel to the third axis and tilted -- must agree with the brute-force numpy ray and the oracle."""
+    from scipy.spatial import ConvexHull
+    from paintrl_amd import geometry as geo
+    tables = synthetic_tables('door_test')
+    env = _gpu_env(tables, 1, None)
+    a0, a1, a2 = tables.a0, tables.a1, tables.a2
+    v0, e1, e2 = (np.asarray(x) for x in (tables.col_v0, tables.col_e1, tables.col_e2))
+    corners = np.concatenate([v0, v0 + e1, v0 + e2])
+    hull = ConvexHull(corners[:, [a1, a2]])
+    poly = corners[hull.vertices][:, [a1, a2]]                       # counter-clockwise
+    zlo, zhi = corners[:, a0].min(), corners[:, a0].max()
+    rng = np.random.RandomState(5)
+    o_list, d_list = [], []
+    for i in range(len(poly)):
+        p0, p1 = poly[i], poly[(i + 1) % len(poly)]
+        e = p1 - p0
+        nrm = np.array([e[1], -e[0]]) / np.linalg.norm(e)            # outward of a CCW polygon
+        for s in (0.0, 0.03, 0.5, 0.97, 1.0):
+            for off in (-1e-3, -1e-5, -2e-6, -1e-7, -1e-9, 0.0, 1e-9, 1e-7, 9e-7, 1.1e-6, 2e-6, 1e-5, 1e-3):
+                q = p0 + s * e + off * nrm
+                for tilt in (0.0, 1e-3, -0.05):
+                    o = np.zeros(3)
+                    o[a1], o[a2], o[a0] = q[0], q[1], zhi + 0.1
+                    d = o.copy()
+                    d[a0] = zlo - 0.1
+                    d[a1] += tilt * rng.uniform(-1, 1)
+                    d[a2] += tilt * rng.uniform(-1, 1)
+                    o_list.append(o)
+                    d_list.append(d)
+    o, d = np.array(o_list), np.array(d_list)
+    idx, t, pos = geo.ray_closest_hit(v0, e1, e2, o, d)
+    gi, gt, gp = env.ray_test_batch(o, d)
+    gi, gt, gp = gi.cpu().numpy(), gt.cpu().numpy(), gp.cpu().numpy()
+    assert (idx >= 0).sum() > 100 and (idx < 0).sum() > 100
+    assert np.array_equal(gi, idx)
+    hit = idx >= 0
+    assert np.array_equal(gt[hit], t[hit]) and np.array_equal(gp[hit], pos[hit])
+    oi, ot, op = oracle.Oracle(tables, 1).ray_batch(o, d)
+    assert np.array_equal(oi, idx) and np.array_equal(ot[hit], t[hit])
+    env.close()
+
+
 def test_gpu_mixed_part_batch():
     """Config 5: door and sheet envs interleaved in one batch, each equal to its oracle."""
     from paintrl_amd.batched_env import BatchedPaintEnv
