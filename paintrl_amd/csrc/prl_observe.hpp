@@ -126,12 +126,12 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
             const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), w);
             valid[k] = ldg(P.word_valid, w);
             const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
-            if ((xg || xl) && (yg || yl)) {
-                const int idx = (xg && yg) ? 0 : ((xl && yg) ? 1 : ((xl && yl) ? 2 : 3));
+            if ((xg | xl) & (yg | yl)) {            // (bitwise on purpose, here and below: `&&` / `||` on lane predicates become branches)
+                const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
                 tot_l += (uint64_t)__popcll(valid[k]) << (16 * idx);
                 und_l += (uint64_t)__popcll(valid[k] & ~painted[k]) << (16 * idx);
             } else if (valid[k] != 0) {
-                vline[k] = yg || yl;
+                vline[k] = yg | yl;
                 above[k] = yg;
                 straddle = !vline[k];
             }
@@ -187,15 +187,15 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
                                    (gb[k].z < x1) + (gb[k].w < x1);
                     pos[k] = grp[k] < 8 ? 8 * grp[k] + in : 64;
                     // the first sample not left of x1 lies in this group: it equals x1 iff some sample of the group does
-                    eq[k] = grp[k] < 8 && (ga[k].x == x1 || ga[k].y == x1 || ga[k].z == x1 || ga[k].w == x1 || gb[k].x == x1 ||
-                                           gb[k].y == x1 || gb[k].z == x1 || gb[k].w == x1);
+                    eq[k] = (grp[k] < 8) & ((ga[k].x == x1) | (ga[k].y == x1) | (ga[k].z == x1) | (ga[k].w == x1) | (gb[k].x == x1) |
+                                         (gb[k].y == x1) | (gb[k].z == x1) | (gb[k].w == x1));
                 }
             }
 #pragma unroll
             for (int kk = 0; kk < G; ++kk) {
                 const int k = k0 + kk;
                 int ub = pos[kk];
-                if (ballot64(eq[kk] && vline[k])) {                 // a sample exactly on the line: the run of equals ends at samp_ub
+                if (ballot64(eq[kk] & vline[k])) {                 // a sample exactly on the line: the run of equals ends at samp_ub
                     const int at = ((vline[k] ? lane + 64 * (slot0 + k) : 0) << 6) + (pos[kk] < 64 ? pos[kk] : 63);
                     if (eq[kk]) ub = (int)ldg(P.samp_ub, at);
                 }
@@ -279,9 +279,9 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t pw = bcast_u64(painted[k], L[q]);
-                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs[q]) && !(xs[q] == x1 && ys[q] == x2);
+                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vs[q]) & !((xs[q] == x1) & (ys[q] == x2));
                 const bool gy = ys[q] > x2, lx = xs[q] < x1;
-                const uint32_t sh = (xs[q] > x1 && gy) ? 0u : ((lx && gy) ? 8u : ((lx && ys[q] < x2) ? 16u : 24u));
+                const uint32_t sh = ((xs[q] > x1) & gy) ? 0u : ((lx & gy) ? 8u : ((lx & (ys[q] < x2)) ? 16u : 24u));
                 const uint32_t one = cnt ? (1u << sh) : 0u;
                 tot_s += one;
                 und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;

@@ -196,8 +196,8 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
         }
 #pragma unroll
         for (int k = 0; k < PAINT_PER_ACTION; ++k) {
-            b[k] = ballot64(in && dd5[k] <= r2_in);
-            unsure |= b[k] ^ ballot64(in && dd5[k] <= r2_out);
+            b[k] = ballot64(in & (dd5[k] <= r2_in));
+            unsure |= b[k] ^ ballot64(in & (dd5[k] <= r2_out));
             any |= b[k];
         }
 #ifdef PRL_FORCE_F64_PAINT
@@ -211,7 +211,7 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
             for (int k = 0; k < PAINT_PER_ACTION; ++k) {
                 const double dx = x - cen_lds[3 * k], dy = y - cen_lds[3 * k + 1], dz = z - cen_lds[3 * k + 2];
                 const double dd = (dx * dx + dy * dy) + dz * dz;
-                b[k] = ballot64(in && dd <= r2);
+                b[k] = ballot64(in & (dd <= r2));
                 any |= b[k];
             }
         }

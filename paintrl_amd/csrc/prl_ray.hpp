@@ -135,8 +135,8 @@ __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], doub
             const double q2 = s0 * e11 - s1 * e10;
             const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
             const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= tmax &&
-                (t < best_t || (t == best_t && rk < best_r))) {
+            if ((u >= -RAY_EPS_BARY) & (v >= -RAY_EPS_BARY) & ((u + v) <= 1.0 + RAY_EPS_BARY) & (t >= 0.0) & (t <= tmax) &
+                ((t < best_t) | ((t == best_t) & (rk < best_r)))) {
                 best_t = t;
                 best_r = rk;
                 best_i = i;
@@ -151,46 +151,41 @@ __device__ __forceinline__ void mt_one(PartRef P, int i, const double o[3], doub
 __device__ __forceinline__ void mt_rec_core(int i, const f64x2 r0, const f64x2 r1, const f64x2 r2, const f64x2 r3, const f64x2 r4,
                                             const f64x2 r5, int rk, const double o[3], double d0, double d1, double d2, double dd,
                                             double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
-    interior = false;
-    if (i >= 0) {
-        const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
-        const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
-        const double p0 = d1 * e22 - d2 * e21;
-        const double p1 = d2 * e20 - d0 * e22;
-        const double p2 = d0 * e21 - d1 * e20;
-        const double det = (e10 * p0 + e11 * p1) + e12 * p2;
-        if (fabs(det) >= RAY_EPS_DET) {
-            const double inv = rcp_det(det);
-            const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
-            const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
-            const double q0 = s1 * e12 - s2 * e11;
-            const double q1 = s2 * e10 - s0 * e12;
-            const double q2 = s0 * e11 - s1 * e10;
-            const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
-            const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
-            if (u >= -RAY_EPS_BARY && v >= -RAY_EPS_BARY && (u + v) <= 1.0 + RAY_EPS_BARY && t >= 0.0 && t <= 1.0 &&
-                (t < best_t || (t == best_t && rk < best_r))) {
-                best_t = t;
-                best_r = rk;
-                best_i = i;
-                best_det = det;
-                interior = u >= m && v >= m && (u + v) <= 1.0 - m && orient * det > 0 &&
-                           det * det >= FACET_MIN_COS2 * dd * nn;
-            }
-        }
+    // Straight-line on purpose: every lane evaluates the whole test (a lane without a facet on whatever record it was handed, a
+    // degenerate determinant on infinities and NaNs that fail every comparison) and the conditions meet in ONE lane predicate
+    // at the end -- nested per-lane `if`s are regions of their own (exec mask saved, branch, restored: three per round here).
+    const double v00 = r0.x, v01 = r0.y, v02 = r1.x, e10 = r1.y, e11 = r2.x, e12 = r2.y;
+    const double e20 = r3.x, e21 = r3.y, e22 = r4.x, m = r4.y, nn = r5.x, orient = r5.y;
+    const double p0 = d1 * e22 - d2 * e21;
+    const double p1 = d2 * e20 - d0 * e22;
+    const double p2 = d0 * e21 - d1 * e20;
+    const double det = (e10 * p0 + e11 * p1) + e12 * p2;
+    const double inv = rcp_det(det);
+    const double s0 = o[0] - v00, s1 = o[1] - v01, s2 = o[2] - v02;
+    const double u = ((s0 * p0 + s1 * p1) + s2 * p2) * inv;
+    const double q0 = s1 * e12 - s2 * e11;
+    const double q1 = s2 * e10 - s0 * e12;
+    const double q2 = s0 * e11 - s1 * e10;
+    const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
+    const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
+    const bool hit = (i >= 0) & (fabs(det) >= RAY_EPS_DET) & (u >= -RAY_EPS_BARY) & (v >= -RAY_EPS_BARY) & ((u + v) <= 1.0 + RAY_EPS_BARY) &
+                     (t >= 0.0) & (t <= 1.0) & ((t < best_t) | ((t == best_t) & (rk < best_r)));
+    interior = hit & (u >= m) & (v >= m) & ((u + v) <= 1.0 - m) & (orient * det > 0) & (det * det >= FACET_MIN_COS2 * dd * nn);
+    if (hit) {
+        best_t = t;
+        best_r = rk;
+        best_i = i;
+        best_det = det;
     }
 }
 
 __device__ __forceinline__ void mt_rec(PartRef P, int i, const double o[3], double d0, double d1, double d2, double dd,
                                        double &best_t, int &best_r, int &best_i, double &best_det, bool &interior) {
-    f64x2 r0 = {0, 0}, r1 = r0, r2 = r0, r3 = r0, r4 = r0, r5 = r0;
-    int rk = 0;
-    if (i >= 0) {
-        const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
-        const int i6 = i * 6;
-        r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4), r5 = ldg(r, i6 + 5);
-        rk = ldg(P.col_rank, i);
-    }
+    // (a lane without a facet reads record 0: one load sequence for the wave, no region under a per-lane condition)
+    const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.col_rec);
+    const int ic = i >= 0 ? i : 0, i6 = ic * 6;
+    const f64x2 r0 = ldg(r, i6), r1 = ldg(r, i6 + 1), r2 = ldg(r, i6 + 2), r3 = ldg(r, i6 + 3), r4 = ldg(r, i6 + 4), r5 = ldg(r, i6 + 5);
+    const int rk = ldg(P.col_rank, ic);
     mt_rec_core(i, r0, r1, r2, r3, r4, r5, rk, o, d0, d1, d2, dd, best_t, best_r, best_i, best_det, interior);
 }
 
@@ -237,7 +232,7 @@ __device__ __forceinline__ int ray_winner_lane(double best_t, int best_r, double
     const uint64_t tie = ballot64(best_t == tmin);
     if ((tie & (tie - 1)) == 0) return __builtin_ctzll(tie);
     const int rmin = wave_min_i(best_t == tmin ? best_r : 0x7fffffff);        // equal t: lowest reference index
-    return __builtin_ctzll(ballot64(best_t == tmin && best_r == rmin));
+    return __builtin_ctzll(ballot64((best_t == tmin) & (best_r == rmin)));
 }
 
 // Returns the collision-set position of the facet hit (= the new `hint`; its reference index is PartDev::col_rank of it), or -1.

@@ -49,7 +49,7 @@ __device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const dou
         if (k0) {
             const double dx = x0 - pt[0], dy = y0 - pt[1], dz = z0 - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && r0 < best_rank)) {
+            if ((dd < best_d) | ((dd == best_d) & (r0 < best_rank))) {
                 best_d = dd;
                 best_rank = r0;
                 best_idx = v0;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void nv_scan(PartRef P, int begin, int end, const dou
         if (k1) {
             const double dx = x1 - pt[0], dy = y1 - pt[1], dz = z1 - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && r1 < best_rank)) {
+            if ((dd < best_d) | ((dd == best_d) & (r1 < best_rank))) {
                 best_d = dd;
                 best_rank = r1;
                 best_idx = v1;
@@ -92,23 +92,26 @@ __device__ __forceinline__ void ring_block_scan(PartRef P, int bound, const doub
             if (ca >= rpre[r]) va = rbeg[r] + (ca - rpre[r]);
             if (cb >= rpre[r]) vb = rbeg[r] + (cb - rpre[r]);
         }
-        double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
-        int ra = 0, rb = 0;
-        if (ka) load_vertex(P, va, ax, ay, az, ra);
-        if (kb) load_vertex(P, vb, bx, by, bz, rb);
-        if (ka) {
+        // (lanes without a candidate read vertex 0 and are masked in the comparison: a load or a distance under a per-lane
+        // condition is a region of its own -- exec mask saved, branch, restored -- and there were six of them per trip)
+        double ax, ay, az, bx = 0, by = 0, bz = 0;
+        int ra, rb = 0;
+        const bool second = c0 + 64 < total;            // wave-uniform: anyone with a second candidate?
+        load_vertex(P, ka ? va : 0, ax, ay, az, ra);
+        if (second) load_vertex(P, kb ? vb : 0, bx, by, bz, rb);
+        {
             const double dx = ax - pt[0], dy = ay - pt[1], dz = az - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && ra < best_rank)) {
+            if (ka & ((dd < best_d) | ((dd == best_d) & (ra < best_rank)))) {
                 best_d = dd;
                 best_rank = ra;
                 best_idx = va;
             }
         }
-        if (kb) {
+        if (second) {
             const double dx = bx - pt[0], dy = by - pt[1], dz = bz - pt[2];
             const double dd = (dx * dx + dy * dy) + dz * dz;
-            if (dd < best_d || (dd == best_d && rb < best_rank)) {
+            if (kb & ((dd < best_d) | ((dd == best_d) & (rb < best_rank)))) {
                 best_d = dd;
                 best_rank = rb;
                 best_idx = vb;
@@ -330,7 +333,7 @@ __device__ int nearest_sample_wave(PartRef P, const double pt[3], int lane) {
         dmin = wave_min_nonneg_d(best_d);
     }
     const int rmin = wave_min_i(best_d == dmin ? best_rank : 0x7fffffff);
-    const uint64_t win = ballot64(best_d == dmin && best_rank == rmin && best_idx >= 0);
+    const uint64_t win = ballot64((best_d == dmin) & (best_rank == rmin) & (best_idx >= 0));
     if (win == 0) return -1;
     return __builtin_amdgcn_readlane(best_idx, rfl(__builtin_ctzll(win)));
 }
@@ -400,13 +403,15 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     const bool coop = false;                          // (profiles/r04_ab_log.txt) -- the step is bound by instruction issue
 #endif
     if (coop) record_gather<TRI_REC / 2>(r2, ti, n_cand, lane, gather);
-    if (ti >= 0) {
+    {
+        // (straight-line: a lane without a candidate evaluates triangle 0 and is masked in the predicates at the end)
+        const bool cand = ti >= 0;
         f64x2 q0, q1, q2, q3, q4, q5, q6;
         if (coop) {
-            const f64x2 *g = gather + lane * (TRI_REC / 2);
+            const f64x2 *g = gather + (cand ? lane : 0) * (TRI_REC / 2);
             q0 = g[0], q1 = g[1], q2 = g[2], q3 = g[3], q4 = g[4], q5 = g[5], q6 = g[6];
         } else {
-            const int t8 = ti * (TRI_REC / 2);
+            const int t8 = (cand ? ti : 0) * (TRI_REC / 2);
             q0 = ldg(r2, t8), q1 = ldg(r2, t8 + 1), q2 = ldg(r2, t8 + 2), q3 = ldg(r2, t8 + 3), q4 = ldg(r2, t8 + 4), q5 = ldg(r2, t8 + 5),
             q6 = ldg(r2, t8 + 6);
         }
@@ -423,10 +428,11 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
             v = -1;
             w = -1;
         }
-        inside = 0 <= u && u <= 1 && 0 <= v && v <= 1 && 0 <= w && w <= 1;
-        m = v < u ? v : u;
-        m = w < m ? w : m;
-        ok = m >= -1.0;
+        inside = cand & (0 <= u) & (u <= 1) & (0 <= v) & (v <= 1) & (0 <= w) & (w <= 1);
+        double mm = v < u ? v : u;
+        mm = w < mm ? w : mm;
+        m = cand ? mm : -INFINITY;
+        ok = cand & (mm >= -1.0);
     }
     int j;
     const uint64_t in_mask = ballot64(inside);
@@ -438,7 +444,7 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
             j = 0;                                                   // nothing beat -1: the first candidate stays
         } else {
             const double mx = wave_max_d(ok ? m : -INFINITY);
-            j = 63 - __builtin_clzll(ballot64(ok && m == mx));       // last one reaching the maximum
+            j = 63 - __builtin_clzll(ballot64(ok & (m == mx)));       // last one reaching the maximum
         }
     }
     // the chosen triangle's normal, quaternion and centre offset: one wave-uniform read of its record's tail
