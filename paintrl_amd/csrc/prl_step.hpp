@@ -316,8 +316,17 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         // arbiter serves its oldest wave first: of the four envs that share a SIMD the youngest then ends 14 us after
         // the oldest (27.7 / 31.3 / 36.0 / 41.7 us, tools/wave_trace.py) and the launch waits for it.  With the wave
         // that is behind served first the four end within 6 us of each other: 47.9 -> 42.8 us per step.
-        if (shot <= 1) PRIO_BY_PROGRESS(3);
+#ifndef PRL_PRIO_HI
+#define PRL_PRIO_HI 1                      // (shots 0 .. PRL_PRIO_HI at level 3; A/B: 0, 2, 3, and -DPRL_PRIO_C -- profiles/r04_ab_log.txt)
+#endif
+#ifdef PRL_PRIO_C
+        if (shot == 0) PRIO_BY_PROGRESS(3);
+        else if (shot <= 2) PRIO_BY_PROGRESS(2);
+        else PRIO_BY_PROGRESS(1);
+#else
+        if (shot <= PRL_PRIO_HI) PRIO_BY_PROGRESS(3);
         else PRIO_YOUNG_OLD(3, 2, shot);
+#endif
         double center[3], quat[4];                         // rob:277-278 shot centre
 #if defined(PRL_UNIT_STEP) && !defined(PRL_KEEP_PART)
         // (k_step.hip: the part's table pointers are read again in every shot -- scalar loads from the constant cache --
@@ -339,7 +348,11 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     shots_end(P, S, X);
+#ifdef PRL_PRIO_C
+    PRIO_BY_PROGRESS(0);
+#else
     PRIO_YOUNG_OLD(2, 1, 5);
+#endif
     // the last-shot mask waits in this wave's LDS rows where the kernel provides them (wl.lastrow), not in registers
     const bool rows = !BIG && !HSI && wl.lastrow != nullptr;
     if constexpr (!BIG) {

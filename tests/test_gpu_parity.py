@@ -179,13 +179,14 @@ def test_gpu_ray_batch_matches_numpy_and_oracle():
     env.close()
 
 
-def test_gpu_rays_grazing_the_outline():
+@pytest.mark.parametrize('part', ['door_test', 'square'])
+def test_gpu_rays_grazing_the_outline(part):
     """The general ray search certifies a miss by the collision set's outline (prl_ray.hpp beam_outside_outline_wave,
     margin 1e-6 m): rays along and near the silhouette -- nanometres to millimetres inside and outside every outline
     edge, parallel to the third axis and tilted -- must agree with the brute-force numpy ray and the oracle."""
     from scipy.spatial import ConvexHull
     from paintrl_amd import geometry as geo
-    tables = synthetic_tables('door_test')
+    tables = synthetic_tables(part)
     env = _gpu_env(tables, 1, None)
     a0, a1, a2 = tables.a0, tables.a1, tables.a2
     v0, e1, e2 = (np.asarray(x) for x in (tables.col_v0, tables.col_e1, tables.col_e2))

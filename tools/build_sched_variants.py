@@ -20,6 +20,16 @@ VARIANTS = {
     'c_nopost': ['-mllvm', '-enable-post-misched=0'],
     'c_trackers': ['-mllvm', '-amdgpu-use-amdgpu-trackers'],
     'c_prealloc': ['-mllvm', '-amdgpu-prealloc-sgpr-spill-vgprs'],
+    'c_prio1': ['-DPRL_PRIO_SLOT=1'],
+    'c_prio3': ['-DPRL_PRIO_SLOT=3'],
+    'c_prio4': ['-DPRL_PRIO_SLOT=4'],
+    'c_noprio': ['-DPRL_NO_PRIO'],
+    'c_priorot': ['-DPRL_PRIO_ROTATE'],
+    'c_hi0': ['-DPRL_PRIO_SLOT=4', '-DPRL_PRIO_HI=0'],
+    'c_hi2': ['-DPRL_PRIO_SLOT=4', '-DPRL_PRIO_HI=2'],
+    'c_hi3': ['-DPRL_PRIO_SLOT=4', '-DPRL_PRIO_HI=3'],
+    'c_prioC': ['-DPRL_PRIO_C'],
+    'c_hi2y': ['-DPRL_PRIO_HI=2'],
     'c_skip4': ['-mllvm', '-amdgpu-skip-threshold=4'],
     'c_skip32': ['-mllvm', '-amdgpu-skip-threshold=32'],
     'c_skip100': ['-mllvm', '-amdgpu-skip-threshold=100'],
