@@ -8,6 +8,15 @@
 //                              shots at all (wrong results;
 //                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
 //   PRL_NO_PRIO, PRL_PRIO_SLOT=<s>  no s_setprio by progress / youngest-wave bias from hardware slot s (prl_step.hpp)
+//   PRL_PRIO_HI=<n>, PRL_PRIO_C, PRL_PRIO_ROTATE   other splits of the four priority levels over a step's phases (A/B)
+//   round-4 A/B switches, each measured in profiles/r04_ab_log.txt (the default is the faster form):
+//     PRL_FACET_TILE, PRL_RECORD_GATHER, PRL_WIDE_FACET_LOAD, PRL_PAINT_PIPELINE, PRL_NT_MASKS, PRL_STAGGER, PRL_OBS_SCALAR_MASKS
+//                              opt-in forms that lost (LDS tile, gathers through LDS, whole-record scalar test, pipelined
+//                              painter, non-temporal masks, staggered starts, observation pass 3 on scalar lane masks)
+//     PRL_STORE_ALL_WORDS, PRL_PLAIN_DIVISION, PRL_EXACT_OUTWARD, PRL_NO_OUTLINE_MISS
+//                              the plain forms of shortcuts that are on (whole mask rows written back, the compiler's float64
+//                              division, nextafterf for outward rounding, the general ray search without the outline's
+//                              miss certificate); the last three are part of the forced-general parity variant
 //   PRL_OLD_BALLOT             HIP's __ballot instead of the builtin (prl_device.hpp)
 //   PRL_WALK_STEPS, PRL_CONE_JOINT_FROM, PRL_FINE_CELL, PRL_HG_CELL, PRL_BEAM_OCC, PRL_BEAM_WAVES, PRL_FAR_OCC, PRL_FAR_WGS, PRL_FAR_WAVES,
 //   PRL_REST_WGS, PRL_BFS_LANES   tuning constants of the cone-beam painter (prl_cone.hpp, paintrl_hip.hip, k_cone_beams.hip);
