@@ -170,3 +170,22 @@ def test_cone_beams_full_size_8_steps_equals_oracle():
     orc = oracle.Oracle(tables, n, start_points=sp, threads=16, paint_method='normal')
     _run(env, orc, np.full(n, len(sp)), 8, 808, 1)
     env.close()
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('PAINTRL_SOAK_STEPS'), reason='soak run: set PAINTRL_SOAK_STEPS (e.g. 400)')
+@pytest.mark.parametrize('part,starts,seed', [('door_test', 'anchor', 11), ('door_test', 'all', 12), ('square', 'all', 13)])
+def test_soak_many_steps_equals_oracle(part, starts, seed):
+    """Not part of the default suite (minutes of oracle time): the headline batch over PAINTRL_SOAK_STEPS steps -- dozens of
+    episode ends per env, every row against the oracle.  `PAINTRL_SOAK_STEPS=400 pytest tests/test_gpu_full_size.py -k soak`;
+    the last run is recorded in profiles/."""
+    import os
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    steps = int(os.environ['PAINTRL_SOAK_STEPS'])
+    tables = synthetic_tables(part)
+    sp = start_points_for(tables, starts)
+    n = 4096
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16)
+    ends, fullest = _run(env, orc, np.full(n, len(sp)), steps, seed, n)
+    print('soak %s / %s: %d steps, %d episode ends (%.1f per env), fullest mask %.2f' % (part, starts, steps, ends, ends / n, fullest))
+    env.close()
