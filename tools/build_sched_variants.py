@@ -30,6 +30,7 @@ VARIANTS = {
     'c_hi3': ['-DPRL_PRIO_SLOT=4', '-DPRL_PRIO_HI=3'],
     'c_prioC': ['-DPRL_PRIO_C'],
     'c_hi2y': ['-DPRL_PRIO_HI=2'],
+    'c_twobatch': ['-DPRL_FACET_TWO_BATCH'],
     'c_skip4': ['-mllvm', '-amdgpu-skip-threshold=4'],
     'c_skip32': ['-mllvm', '-amdgpu-skip-threshold=32'],
     'c_skip100': ['-mllvm', '-amdgpu-skip-threshold=100'],
