@@ -31,6 +31,12 @@ VARIANTS = {
     'c_prioC': ['-DPRL_PRIO_C'],
     'c_hi2y': ['-DPRL_PRIO_HI=2'],
     'c_twobatch': ['-DPRL_FACET_TWO_BATCH'],
+    'c_ra_local': ['-mllvm', '-enable-local-reassign'],
+    'c_ra_prio': ['-mllvm', '-greedy-regclass-priority-trumps-globalness'],
+    'c_ra_rev': ['-mllvm', '-greedy-reverse-local-assignment'],
+    'c_ra_size': ['-mllvm', '-split-spill-mode=size'],
+    'c_ra_speed': ['-mllvm', '-split-spill-mode=speed'],
+    'c_ra_evict': ['-mllvm', '-regalloc-eviction-max-interference-cutoff=40'],
     'c_skip4': ['-mllvm', '-amdgpu-skip-threshold=4'],
     'c_skip32': ['-mllvm', '-amdgpu-skip-threshold=32'],
     'c_skip100': ['-mllvm', '-amdgpu-skip-threshold=100'],
