@@ -122,11 +122,28 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * (slot0 + k);
         bool straddle = false;
-        if (w < P.n_words) {
+        if constexpr (KW < 4) {
+            // (straight-line: a lane beyond the part's words reads word 0 and carries an empty `valid`)
+            const bool inw = w < P.n_words;
+            const int wc = inw ? w : 0;
+            const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), wc);
+            const uint64_t vw = ldg(P.word_valid, wc);
+            valid[k] = inw ? vw : 0;
+            const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
+            const bool whole = (xg | xl) & (yg | yl);        // (bitwise on purpose, here and below: `&&` / `||` on lane predicates become branches)
+            const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
+            const uint64_t cv = whole ? valid[k] : 0;
+            tot_l += (uint64_t)__popcll(cv) << (16 * idx);
+            und_l += (uint64_t)__popcll(cv & ~painted[k]) << (16 * idx);
+            const bool rest = !whole & (valid[k] != 0);
+            vline[k] = rest & (yg | yl);
+            above[k] = yg;
+            straddle = rest & !(yg | yl);
+        } else if (w < P.n_words) {                  // (four slots: the straight-line form costs the KW = 4 kernels two spilled registers)
             const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), w);
             valid[k] = ldg(P.word_valid, w);
             const bool xg = bb.x > x1, xl = bb.y < x1, yg = bb.z > x2, yl = bb.w < x2;
-            if ((xg | xl) & (yg | yl)) {            // (bitwise on purpose, here and below: `&&` / `||` on lane predicates become branches)
+            if ((xg | xl) & (yg | yl)) {
                 const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
                 tot_l += (uint64_t)__popcll(valid[k]) << (16 * idx);
                 und_l += (uint64_t)__popcll(valid[k] & ~painted[k]) << (16 * idx);
