@@ -123,7 +123,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
     const double v = ((d0 * q0 + d1 * q1) + d2 * q2) * inv;
     const double t = ((e20 * q0 + e21 * q1) + e22 * q2) * inv;
     const bool front = orient * det > 0;                      // the beam meets this facet's plane from outside
-    const bool solid = front && det * det >= CONE_MIN_COS2 * dd * nn;
+    const bool solid = front & (det * det >= CONE_MIN_COS2 * dd * nn);        // (bitwise between lane predicates: no branch)
     out.solid = solid;    // ... at more than a grazing angle
     if (!solid) {
         // The walk has reached the hull's horizon (or grazes).  Two certificates that the beam misses the whole set, by
@@ -133,7 +133,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
         const double so = ((s0 * n0 + s1 * n1) + s2 * n2) * orient;                     // origin, outward if > 0
         const double se = so + ((d0 * n0 + d1 * n1) + d2 * n2) * orient;                // end point
         const double clear = CONE_MISS_MARGIN * CONE_MISS_MARGIN * nn;                  // (distance margin)^2 |n|^2
-        if (so > 0 && se > 0 && so * so > clear && se * se > clear) {
+        if ((so > 0) & (se > 0) & (so * so > clear) & (se * se > clear)) {
             out.code = 2;
             return out;
         }
@@ -142,7 +142,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
         // faces away.  The plane through such an edge that contains the beam's direction supports the hull (its
         // normal lies between the two facets' outward normals), so a LINE that runs on its outer side, more than the
         // margin away, misses the hull -- most beams that miss pass beside the part and end exactly like this.
-        if (!front && prev >= 0 && orient * det < 0 && det * det >= CONE_SIL_MIN_COS2 * dd * nn) {
+        if (!front & (prev >= 0) & (orient * det < 0) & (det * det >= CONE_SIL_MIN_COS2 * dd * nn)) {
             const int k = nb.x == prev ? 0 : (nb.y == prev ? 1 : (nb.z == prev ? 2 : -1));
             if (k >= 0) {
                 // edge k of this facet (part_fill: 0 = v0 .. v0 + e2, 1 = v0 .. v0 + e1, 2 = v0 + e1 .. v0 + e2): a point
@@ -155,7 +155,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
                 const double m0 = g1 * d2 - g2 * d1, m1 = g2 * d0 - g0 * d2, m2 = g0 * d1 - g1 * d0;               // edge x beam
                 const double side_o = (a0 * m0 + a1 * m1) + a2 * m2, side_p = (c0 * m0 + c1 * m1) + c2 * m2;
                 const double mm = (m0 * m0 + m1 * m1) + m2 * m2;
-                if (side_o * side_p < 0 && side_o * side_o > CONE_MISS_MARGIN * CONE_MISS_MARGIN * mm) {
+                if ((side_o * side_p < 0) & (side_o * side_o > CONE_MISS_MARGIN * CONE_MISS_MARGIN * mm)) {
                     out.code = 2;
                     return out;
                 }
@@ -171,7 +171,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
         out.code = -4;
         return out;
     }
-    if (u >= m && v >= m && (u + v) <= 1.0 - m) {
+    if ((u >= m) & (v >= m) & ((u + v) <= 1.0 - m)) {
         if (!solid) {                                        // a grazing entry decides nothing (the walk may pass through such facets)
             out.code = -5;
             return out;
@@ -185,7 +185,7 @@ __device__ __forceinline__ WalkStep cone_walk_step(PartRef P, int i, int prev, c
     }
     // outside the triangle (or within the edge margin): cross the edge that is violated most
     const double w = 1.0 - u - v;
-    const int e = (u <= v && u <= w) ? 0 : ((v <= w) ? 1 : 2);         // 0: u smallest, 1: v, 2: w = 1 - u - v
+    const int e = ((u <= v) & (u <= w)) ? 0 : ((v <= w) ? 1 : 2);         // 0: u smallest, 1: v, 2: w = 1 - u - v
     out.next = e == 0 ? nb.x : (e == 1 ? nb.y : nb.z);
     out.code = 0;
     return out;
@@ -500,13 +500,13 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.fg_o1, P.fg_inv, P.fg_nx), icy = cell_coord(h2, P.fg_o2, P.fg_inv, P.fg_ny);
     const double f1 = (h1 - P.fg_o1) * P.fg_inv - (double)icx, f2 = (h2 - P.fg_o2) * P.fg_inv - (double)icy;   // place in the cell
-    const bool in_cell = f1 >= 0.0 && f1 < 1.0 && f2 >= 0.0 && f2 < 1.0;      // (cell_coord clamps far outside the grid)
+    const bool in_cell = (f1 >= 0.0) & (f1 < 1.0) & (f2 >= 0.0) & (f2 < 1.0);      // (cell_coord clamps far outside the grid)
     const f32x4 GAS *rec = reinterpret_cast<const f32x4 GAS *>(P.fg_rec32);
     const float qx = (float)pt[0], qy = (float)pt[1], qz = (float)pt[2];
     const double mq = fmax(fmax(fabs(pt[0]), fabs(pt[1])), fmax(fabs(pt[2]), P.samp_absmax));
     const float E = (float)(mq * 1.1920929e-7 * 1.001);              // 2^-23 M, rounded up
     int result = want ? -2 : -1;
-    const bool open = want && mq < 1.0e6 && in_cell;
+    const bool open = want & (mq < 1.0e6) & in_cell;
     if (ballot64(open) == 0) return result;
     int cx0 = f1 < 0.5 ? icx - 1 : icx, cx1 = cx0 + 1, cy0 = f2 < 0.5 ? icy - 1 : icy, cy1 = cy0 + 1;
     // the block's border is this far from the point, in cells, wherever it is not the grid's own (0.5 .. 1): every sample
@@ -514,7 +514,7 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     const double reach = fmin(fmin(f1 < 0.5 ? f1 + 1.0 : f1, f1 < 0.5 ? 1.0 - f1 : 2.0 - f1), fmin(f2 < 0.5 ? f2 + 1.0 : f2, f2 < 0.5 ? 1.0 - f2 : 2.0 - f2));
     cx0 = cx0 < 0 ? 0 : cx0, cx1 = cx1 > P.fg_nx - 1 ? P.fg_nx - 1 : cx1;
     cy0 = cy0 < 0 ? 0 : cy0, cy1 = cy1 > P.fg_ny - 1 ? P.fg_ny - 1 : cy1;
-    const int rows = (open && cx0 <= cx1 && cy0 <= cy1) ? cy1 - cy0 + 1 : 0;
+    const int rows = (open & (cx0 <= cx1) & (cy0 <= cy1)) ? cy1 - cy0 + 1 : 0;
     // the record ranges of the two rows travel together
     const int b0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx0) : 0, e0 = rows > 0 ? ldg(P.fg_start, cy0 * P.fg_nx + cx1 + 1) : 0;
     const int b1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx0) : 0, e1 = rows > 1 ? ldg(P.fg_start, (cy0 + 1) * P.fg_nx + cx1 + 1) : 0;
@@ -548,29 +548,29 @@ __device__ __forceinline__ int nearest_sample_lane_f32(PartRef P, const double p
     const float t1 = __uint_as_float(k1 & ~NN_KEY_PLACE) * NN_KEY_SLACK;
     const float lim1 = t1 + nn_band(t1, E);
     const float t2 = __uint_as_float(k2 & ~NN_KEY_PLACE), t3 = __uint_as_float(k3 & ~NN_KEY_PLACE);
-    const bool c2 = open && k2 < NN_KEY_INF && t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1;
-    const bool c3 = open && k3 < NN_KEY_INF && t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1;
-    const bool m1 = open && k1 < NN_KEY_INF, m2 = c2 && !c3;
+    const bool c2 = open & (k2 < NN_KEY_INF) & (t2 - nn_band(t2 * NN_KEY_SLACK, E) <= lim1);
+    const bool c3 = open & (k3 < NN_KEY_INF) & (t3 - nn_band(t3 * NN_KEY_SLACK, E) <= lim1);
+    const bool m1 = open & (k1 < NN_KEY_INF), m2 = c2 & !c3;
     if (m1) nn_key_measure(P, k1, ((k1 >> 7) & 1u) ? b1 : b0, pt, best_d, best_rank, best_pos);
     if (ballot64(m2) != 0) {
         if (m2) {
             double dd;
             int rk, ps;
             nn_key_measure(P, k2, ((k2 >> 7) & 1u) ? b1 : b0, pt, dd, rk, ps);
-            if (dd < best_d || (dd == best_d && rk < best_rank)) {
+            if ((dd < best_d) | ((dd == best_d) & (rk < best_rank))) {
                 best_d = dd;
                 best_pos = ps;
             }
         }
     }
     const double lim = reach * P.fg_accept;
-    if (open && best_pos >= 0) far_bound = __double2float_ru(best_d);
+    if (open & (best_pos >= 0)) far_bound = __double2float_ru(best_d);
     // three the float distances cannot order, a row beyond a key's places, a nearest sample beyond the block's reach: -2
-    if (open && !(c3 || wide) && best_pos >= 0 && best_d <= lim * lim) result = best_pos;
+    if (open & !(c3 | wide) & (best_pos >= 0) & (best_d <= lim * lim)) result = best_pos;
     // a point that has seen no sample at all (its block is empty: the hull over a window of the part): the distance to the
     // seed sample of its cell (fg_seed) is the bound the far kernel starts with -- two dependent reads that cost a wave of
     // this kernel nothing it does not hide, and were a fifth of a search's chain there
-    const bool blind = want && result == -2 && !(far_bound < INFINITY);
+    const bool blind = want & (result == -2) & !(far_bound < INFINITY);
     if (ballot64(blind) != 0) {
         if (blind) {
             const int gx = icx < 0 ? 0 : (icx > P.fg_nx - 1 ? P.fg_nx - 1 : icx), gy = icy < 0 ? 0 : (icy > P.fg_ny - 1 ? P.fg_ny - 1 : icy);
