@@ -693,26 +693,26 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
             const bool has = c < nf * 4;
             const int node = cur[has ? c >> 2 : 0];
             const int q = c & 3, px = 2 * (node & 0xfff) + (q & 1), py = 2 * ((node >> 12) & 0xfff) + (q >> 1);
-            const bool in = has && px < cnx && py < cny;
+            const bool in = has & (px < cnx) & (py < cny);
             const int n = off + (in ? py * cnx + px : 0);
             const f32x4 lo = ldg(boxes, 2 * n), hi = ldg(boxes, 2 * n + 1);      // (a copy of the upper levels in LDS: no faster)
             const double ax = (double)lo.x - pt[0], bx = pt[0] - (double)hi.x, ay = (double)lo.y - pt[1], by = pt[1] - (double)hi.y,
                          az = (double)lo.z - pt[2], bz = pt[2] - (double)hi.z;
             const double ex = fmax(fmax(ax, bx), 0.0), ey = fmax(fmax(ay, by), 0.0), ez = fmax(fmax(az, bz), 0.0);
             const double d2 = (ex * ex + ey * ey) + ez * ez;         // (an empty node: +inf)
-            const bool keep = in && d2 <= bound;
-            if (keep && lo.x <= hi.x) {                              // the farthest corner of a box that holds samples
+            const bool keep = in & (d2 <= bound);
+            if (keep & (lo.x <= hi.x)) {                              // the farthest corner of a box that holds samples
                 const double fx = fmax(fabs(ax), fabs(bx)), fy = fmax(fabs(ay), fabs(by)), fz = fmax(fabs(az), fabs(bz));
                 tight = fminf(tight, __double2float_ru((fx * fx + fy * fy) + fz * fz));
             }
             int word = (cl << 24) | (py << 12) | px;
             if (cl == 0) {                                           // a cell travels as its record range (sign bit | count << 22 | first)
                 const int b = __float_as_int(lo.w), cnt = __float_as_int(hi.w) - b;
-                if (b < (1 << 22) && cnt < 512) word = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
+                if ((b < (1 << 22)) & (cnt < 512)) word = (int)(0x80000000u | ((unsigned)cnt << 22) | (unsigned)b);
             }
             const unsigned bits = (unsigned)(ballot64(keep) >> (BFS_G * g)) & ((1u << BFS_G) - 1u);
             const int slot = nn + __popc(bits & ((1u << m) - 1u));
-            if (keep && slot < BFS_CAP) nxt[slot] = word;
+            if (keep & (slot < BFS_CAP)) nxt[slot] = word;
             nn += __popc(bits);
         }
         over = over || nn > BFS_CAP;
@@ -754,11 +754,11 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (i0 + q < cnt) {
+                    {   // (straight-line: a lane whose range is through measures its clamped record and is masked in the predicate)
                         const double dx = ra[q].x - pt[0], dy = ra[q].y - pt[1], dz = rb[q].x - pt[2];
                         const double dd = (dx * dx + dy * dy) + dz * dz;
                         const int rk = __double2loint(rb[q].y);
-                        if (dd < best_d || (dd == best_d && rk < best_rank)) {
+                        if ((i0 + q < cnt) & ((dd < best_d) | ((dd == best_d) & (rk < best_rank)))) {
                             best_d = dd;
                             best_rank = rk;
                             best_pos = __double2hiint(rb[q].y);
@@ -772,7 +772,7 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     for (int o = 1; o < BFS_G; o <<= 1) {                            // the group's best
         const double od = __shfl_xor(best_d, o);
         const int ork = __shfl_xor(best_rank, o), ops = __shfl_xor(best_pos, o);
-        if (od < best_d || (od == best_d && ork < best_rank)) {
+        if ((od < best_d) | ((od == best_d) & (ork < best_rank))) {
             best_d = od;
             best_rank = ork;
             best_pos = ops;
