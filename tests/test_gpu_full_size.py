@@ -189,3 +189,37 @@ def test_soak_many_steps_equals_oracle(part, starts, seed):
     ends, fullest = _run(env, orc, np.full(n, len(sp)), steps, seed, n)
     print('soak %s / %s: %d steps, %d episode ends (%.1f per env), fullest mask %.2f' % (part, starts, steps, ends, ends / n, fullest))
     env.close()
+
+
+@pytest.mark.skipif(not __import__('os').environ.get('PAINTRL_SOAK_STEPS'), reason='soak run: set PAINTRL_SOAK_STEPS (e.g. 400)')
+@pytest.mark.parametrize('case', ['grid_overlap_turning', 'mixed', 'cone_beams'])
+def test_soak_other_configurations_equal_oracle(case):
+    """The soak run for BASELINE configs 3 (grid + penalties), 5 (mixed door / sheet) and the cone-beam painter (a twentieth
+    of the steps: its oracle is the slow one)."""
+    import os
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    steps = int(os.environ['PAINTRL_SOAK_STEPS'])
+    n = 4096
+    door = synthetic_tables('door_test')
+    if case == 'mixed':
+        sheet = synthetic_tables('square')
+        sp_d, sp_s = start_points_for(door, 'all'), start_points_for(sheet, 'all')
+        ids = (np.arange(n) % 2).astype(np.int32)
+        env = BatchedPaintEnv([_dt(door, sp_d), _dt(sheet, sp_s)], n, env_part_id=ids, max_possible_point=[9148, 14350],
+                              auto_reset=True)
+        orc = _Slices([oracle.Oracle(door, n // 2, start_points=sp_d, max_possible_point=9148, threads=16),
+                       oracle.Oracle(sheet, n // 2, start_points=sp_s, max_possible_point=14350, threads=16)],
+                      [np.arange(0, n, 2), np.arange(1, n, 2)], n)
+        n_start = np.where(ids == 0, len(sp_d), len(sp_s))
+    else:
+        sp = start_points_for(door, 'anchor')
+        kw = dict(obs_mode='grid', obs_grad=4, overlap_penalty=True, turning_penalty=True) if case == 'grid_overlap_turning' \
+            else dict(paint_method='normal')
+        if case == 'cone_beams':
+            steps = max(8, steps // 20)
+        env = BatchedPaintEnv(_dt(door, sp), n, auto_reset=True, **kw)
+        orc = oracle.Oracle(door, n, start_points=sp, threads=16, **kw)
+        n_start = np.full(n, len(sp))
+    ends, fullest = _run(env, orc, n_start, steps, 77, 1)
+    print('soak %s: %d steps, %d episode ends (%.1f per env), fullest mask %.2f' % (case, steps, ends, ends / n, fullest))
+    env.close()
