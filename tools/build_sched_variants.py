@@ -37,6 +37,11 @@ VARIANTS = {
     'c_ra_size': ['-mllvm', '-split-spill-mode=size'],
     'c_ra_speed': ['-mllvm', '-split-spill-mode=speed'],
     'c_ra_evict': ['-mllvm', '-regalloc-eviction-max-interference-cutoff=40'],
+    'c_far1536': ['-DPRL_FAR_WGS=1536'],
+    'c_far3072': ['-DPRL_FAR_WGS=3072'],
+    'c_far1024': ['-DPRL_FAR_WGS=1024'],
+    'c_rest256': ['-DPRL_REST_WGS=256'],
+    'c_rest1024': ['-DPRL_REST_WGS=1024'],
     'c_skip4': ['-mllvm', '-amdgpu-skip-threshold=4'],
     'c_skip32': ['-mllvm', '-amdgpu-skip-threshold=32'],
     'c_skip100': ['-mllvm', '-amdgpu-skip-threshold=100'],
