@@ -179,7 +179,7 @@ def valu_issue_bound(kernel_us, obs_mode):
         # the instruction counts belong to the kernel of that commit: say so when csrc/ has changed since
         try:
             base = at.split('+')[0]
-            changed = subprocess.check_output(['git', '-C', REPO, 'diff', '--name-only', base, '--', 'paintrl_amd/csrc'],
+            changed = subprocess.check_output(['git', '-C', REPO, 'diff', '--name-only', base, '--', 'paintrl_amd/csrc', 'paintrl_amd/build.py'],
                                               text=True, stderr=subprocess.DEVNULL).strip()
             stale = bool(changed) or at.endswith('+dirty')
         except (subprocess.CalledProcessError, OSError):
@@ -277,6 +277,11 @@ def main():
                          "group's slowest wave then only delays that group); default 1 = one launch per step")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
     ap.add_argument('--paint-method', default='fast', choices=['fast', 'normal'])
+    ap.add_argument('--part', default='door_test',
+                    help="synthetic part (paintrl_amd.synth_parts.PARTS): 'door_test' = the BASELINE door panel (default), 'square' "
+                         "the fine sheet, 'test' the coarse sheet with the reference's stale kd-tree, 'door_rr_big' the door on a "
+                         'larger texture (the large-part kernels: Part_Dict door_lf .. door_rr_big, rge:106-117)')
+    ap.add_argument('--tex', type=int, default=0, help='texture edge of --part (0 = its default); sets the sample count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prewarm', action='store_true')
     args = ap.parse_args()
@@ -300,9 +305,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
-    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240),
-                                           name='door_test')
-    start_mode = 'all' if args.actions == 'sweep' else 'anchor'      # the sweep starts anywhere on the part
+    tex = args.tex or synth_parts.TEXTURES[args.part][0][0]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(args.part), tex_size=(tex, tex), name=args.part)
+    other_part = args.part != 'door_test' or tex != 240
+    if other_part and (args.mixed or args.streams > 1):
+        raise SystemExit('--part / --tex are not combined with --mixed / --streams')
+    # the headline door: _max_possible_point as the reference computes it (rge:240-252, 9 148 of 9 664); other parts: 95 %
+    mpp = 9148 if not other_part else int(0.95 * tables.sample_pos.shape[0])
+    start_mode = 'all' if (args.actions == 'sweep' or other_part) else 'anchor'      # the sweep starts anywhere on the part
     dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, start_mode))
     overlap = args.obs_mode == 'grid'
     common = dict(device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
@@ -321,7 +331,7 @@ def main():
         if args.streams > 1 and (args.policy not in ('random', 'mlp') or args.envs % args.streams):
             raise SystemExit('--streams needs --policy random or mlp and a divisible --envs')
         n_sub = args.envs // args.streams
-        subs = [BatchedPaintEnv(dt, n_sub, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=9148,
+        subs = [BatchedPaintEnv(dt, n_sub, seed=pdist.rank_seed(5678 + 7919 * g, rank), max_possible_point=mpp,
                                 **common) for g in range(args.streams)]
         env = subs[0]
     main_stream = torch.cuda.current_stream(device)
@@ -339,7 +349,7 @@ def main():
     prewarm_steps = 0
     if not args.no_prewarm and PREWARM_SECONDS > 0:
         # a scratch batch of the same shape, stepped untimed: brings the clocks up and the code / tables into cache
-        scratch = BatchedPaintEnv(dt, min(args.envs, ENVS_PER_GPU), seed=1, max_possible_point=9148, **common) \
+        scratch = BatchedPaintEnv(dt, min(args.envs, ENVS_PER_GPU), seed=1, max_possible_point=mpp, **common) \
             if not args.mixed else None
         if scratch is not None:
             scratch.reset()
@@ -485,6 +495,14 @@ def main():
     elapsed = elapsed_all[med]
 
     episodes = sum(int(e.state()['episode'].sum()) for e in subs) - args.envs
+    # which device every rank ran on (a SCALE record can be checked against it)
+    rank_devices = [int(local_rank)]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        rank_devices = [None] * dist.get_world_size()
+        dist.all_gather_object(rank_devices, int(local_rank))
+    occupancy = None
+    if args.paint_method == 'fast' and args.policy in ('random', 'mlp', 'mlp-torch'):
+        occupancy = env.step_occupancy()                 # of one prl_batch_step launch
     if rank == 0:
         n_launch_envs = args.envs // len(subs)
         survey_env, survey_launch, per_env, static, per_launch = algorithmic_bytes(dt, n_launch_envs, env.obs_dim)
@@ -502,7 +520,7 @@ def main():
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         # the committed PMC measurement is for the default workload (section / grid) only
         if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' \
-                and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast':
+                and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast' and not other_part:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get('bytes_per_launch_%s' % args.obs_mode)
@@ -525,13 +543,19 @@ def main():
             'repeats': {'n': REPEATS, 'value_is': 'median', 'values': [world * args.steps / t for t in elapsed_all],
                         'min': world * args.steps / max(elapsed_all), 'max': world * args.steps / min(elapsed_all)},
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'PaintGymEnv Part_NO=0 synthetic door panel%s, OBS_MODE=%r%s, %d envs per GPU, '
+            'config': {'workload': 'PaintGymEnv %s%s, OBS_MODE=%r%s, %d envs per GPU, '
                                    '%s discrete-4 actions, in-kernel auto-reset'
-                                   % (' + sheet (mixed, START_POINT_MODE all)' if args.mixed else '', args.obs_mode,
+                                   % ('Part_NO=0 synthetic door panel' if not other_part else
+                                      "synthetic part '%s' on a %d x %d texture (START_POINT_MODE all)" % (args.part, tex, tex),
+                                      ' + sheet (mixed, START_POINT_MODE all)' if args.mixed else '', args.obs_mode,
                                       ' + OVERLAP_PENALTY' if overlap else '', args.envs, act_desc)
                                    + (", PAINT_METHOD='normal'" if args.paint_method == 'normal' else ''),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
-                       'samples': int(dt.n_samples), 'collision_triangles': int(dt.n_collision),
+                       'part': args.part, 'texture': tex, 'samples': int(dt.n_samples), 'mask_words': int(env.mask_stride),
+                       'stale_kd_nodes': len(getattr(tables, 'kd_split_dim', ())), 'collision_triangles': int(dt.n_collision),
+                       'step_launch_occupancy': occupancy,
+                       'rccl_ranks': (dist_world if (dist.is_initialized() and dist.get_backend() == 'nccl') else 0),
+                       'rank_devices': rank_devices,
                        'episodes_finished_rank0': episodes, 'launches_per_step': len(subs),
                        'prewarm_steps_untimed_scratch_batch': prewarm_steps,
                        'returns_gathers': gatherer.count if gatherer is not None else 0,
@@ -539,12 +563,15 @@ def main():
                                       % (world, dist_world, dist.get_backend() if dist.is_initialized() else 'none')
                                       + (', %d independent env groups per GPU on %d streams' % (len(subs), len(subs))
                                          if len(subs) > 1 else '')},
-            'roofline': {'bound': 'hbm', 'kernel': 'step_kernel' if args.paint_method == 'fast' else 'the five launches of a cone-beam step (path, beams, rest, far, finish)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': ('step_kernel' if env.mask_stride <= 256 else 'step_kernel_big') if args.paint_method == 'fast' else 'the five launches of a cone-beam step (path, beams, rest, far, finish)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS if achieved else None, 'traffic': traffic,
                          'traffic_over_algorithmic': traffic / survey_launch if traffic else None,
                          'traffic_measured_at': traffic_at,
                          'traffic_from': 'profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
-                                         'FETCH_SIZE x2 calibrated on copy_mask_kernel); not measured in this run',
+                                         'FETCH_SIZE x2 calibrated on copy_mask_kernel); not measured in this run.  About 11 MB '
+                                         'of that figure are part tables fetched again in every launch only because rocprofv3 --pmc '
+                                         'invalidates the L2s between dispatches (profiles/r04_l2_cold_under_pmc.txt): an artefact '
+                                         'of counter collection, absent from the unprofiled back-to-back launches this line times',
                          'algorithmic_bytes_per_env_step': survey_env, 'bytes_per_launch': survey_launch,
                          'layout_bytes_per_env_step': per_env, 'layout_static_table_bytes': static,
                          'layout_bytes_per_launch': per_launch,
@@ -556,12 +583,14 @@ def main():
                          'avg_kernel_us_sampled': sampled_us, 'sampled_launches': int(launches),
                          'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
                          if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random' and args.actions == 'random'
-                             and args.paint_method == 'fast' and len(subs) == 1) else
+                             and args.paint_method == 'fast' and len(subs) == 1 and not other_part) else
                          (cone_second_bound(1e3 * ms_per_step) if (args.paint_method == 'normal' and args.envs == ENVS_PER_GPU
                                                                     and not args.mixed and len(subs) == 1) else None)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(tables, n_envs=args.envs, obs_mode=args.obs_mode, overlap=overlap)
+            # (a bounded sample: the oracle's step scales with the part's sample count)
+            out['cpu_baseline'] = cpu_baseline(tables, steps_sample=max(24, int(300 * 9664 / max(9664, dt.n_samples))),
+                                               n_envs=args.envs, obs_mode=args.obs_mode, overlap=overlap)
         print(json.dumps(out, default=lambda o: o.item() if hasattr(o, 'item') else str(o)))
         sys.stdout.flush()
     for e in subs:

@@ -174,6 +174,11 @@ int prl_batch_reset(PrlBatch *batch, const uint8_t *reset_mask, const int32_t *s
 int prl_batch_step(PrlBatch *batch, const void *actions, double *obs, double *reward, uint8_t *done, double *info,
                    double *final_obs, const int32_t *start_idx, void *stream);
 
+/* How a prl_batch_step launch of this batch (PAINT_METHOD 'fast': its one kernel) occupies the chip -- for bench.py's
+ * line, no reference counterpart: out[0] = wavefronts (= envs) per workgroup, out[1] = workgroups resident per CU as the
+ * runtime's occupancy calculator reports them (registers, LDS), out[2] = dynamic LDS bytes per workgroup, out[3] = CUs. */
+int prl_batch_step_occupancy(PrlBatch *batch, int32_t *out /* host, [4] */);
+
 /* Replaces Robot.reset(pose) (rob:366-372, used by spiral.py:38): place env `env_index` at `pos` with tool
  * quaternion `quat` (host pointers, xyzw) and clear its off-part bookkeeping (rob:208-212).  Coverage,
  * step counter and reward accumulators are left as they are, like the reference.  Synchronous. */

@@ -76,6 +76,7 @@ SYMBOLS = {
     'prl_batch_mask_stride': (C.c_int, [_vp]),
     'prl_batch_reset': (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'prl_batch_step': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'prl_batch_step_occupancy': (C.c_int, [_vp, _ip]),
     'prl_batch_set_pose': (C.c_int, [_vp, C.c_int, _dp, _dp]),
     'prl_batch_observe': (C.c_int, [_vp, _vp, _vp]),
     'prl_policy_act': (C.c_int, [C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),

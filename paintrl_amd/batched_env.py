@@ -274,6 +274,15 @@ class BatchedPaintEnv(object):
         _lib.check(self.lib.prl_batch_timing_read(self._batch, C.byref(ms), C.byref(n)), 'prl_batch_timing_read')
         return ms.value, n.value
 
+    def step_occupancy(self):
+        """How one prl_batch_step launch occupies the chip: dict(waves_per_workgroup, workgroups_per_cu, waves_per_cu,
+        dynamic_lds_bytes, compute_units) from the runtime's occupancy calculator (PAINT_METHOD 'fast' kernels)."""
+        out = (C.c_int32 * 4)()
+        with _torch().cuda.device(self.device):
+            _lib.check(self.lib.prl_batch_step_occupancy(self._batch, out), 'prl_batch_step_occupancy')
+        return dict(waves_per_workgroup=out[0], workgroups_per_cu=out[1], waves_per_cu=out[0] * out[1],
+                    dynamic_lds_bytes=out[2], compute_units=out[3])
+
     def close(self):
         if getattr(self, '_batch', None) is not None and self._batch:
             self.lib.prl_batch_destroy(self._batch)

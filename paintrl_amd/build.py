@@ -71,19 +71,22 @@ def _unit_stale(obj, src, flags_line):
 
 
 def _unit_cmd(name, src_file, unit_flags, extra, obj_dir):
+    """(source, object, arguments after the compiler's own path).  The compiler is not part of it: the staleness check must
+    work where hipcc is absent (a GPU box with prebuilt objects) and must not change its mind when the toolchain moves."""
     src = os.path.join(CSRC, src_file)
     obj = os.path.join(obj_dir, name + '.o')
-    return src, obj, [hipcc()] + CFLAGS + list(unit_flags) + list(extra) + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, '-MD', '-MF',
-                                                                            obj + '.d', '-c', src, '-o', obj]
+    return src, obj, CFLAGS + list(unit_flags) + list(extra) + ['-I', os.path.join(_REPO, 'include'), '-I', CSRC, '-MD', '-MF',
+                                                                obj + '.d', '-c', src, '-o', obj]
 
 
 def _compile(name, src_file, unit_flags, extra, obj_dir, force, verbose):
-    src, obj, cmd = _unit_cmd(name, src_file, unit_flags, extra, obj_dir)
-    line = ' '.join(cmd)
+    src, obj, args = _unit_cmd(name, src_file, unit_flags, extra, obj_dir)
+    line = ' '.join(args)
     if not force and not _unit_stale(obj, src, line):
         return obj
+    cmd = [hipcc()] + args
     if verbose:
-        print(line, flush=True)
+        print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(obj + '.flags', 'w') as f:
         f.write(line)
@@ -138,10 +141,10 @@ def is_stale():
         # own age against the sources decides
         return _sources_newer_than(LIBRARY)
     for uname, src_file, uflags in UNITS:
-        src, obj, cmd = _unit_cmd(uname, src_file, uflags, (), obj_dir)
+        src, obj, args = _unit_cmd(uname, src_file, uflags, (), obj_dir)
         if not os.path.isfile(obj) or os.path.getmtime(obj) > os.path.getmtime(LIBRARY):
             return True
-        if _unit_stale(obj, src, ' '.join(cmd)):          # a source or header newer than the object, or other flags
+        if _unit_stale(obj, src, ' '.join(args)):         # a source or header newer than the object, or other flags
             return True
     return False
 

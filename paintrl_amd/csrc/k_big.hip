@@ -3,9 +3,6 @@
 // of n_words words per env in the step kernel, one in reset / observe), sized at launch; everything else is the same
 // device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot)
-#include <mutex>
-#include <unordered_map>
-
 #include "prl_all.hpp"
 
 #define PRL_KW 0
@@ -256,33 +253,17 @@ __global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int l
 
 // Large parts: dynamic LDS = waves x copies x mask_stride words (+ extra bytes per wave); as many waves per workgroup (at
 // most four) as fit the CU's 160 KB NEXT TO the kernel's own static LDS (wave_lds: candidate list, shot centres, section
-// counters, and with the stale tree 20 KB of kd-walk rows) -- asked of the runtime once per kernel and remembered, like the
-// dynamic size already granted (hipFuncSetAttribute is not repeated per launch).
-struct BigKernelInfo {
-    size_t static_lds = 0, dyn_granted = 64 * 1024;
-    bool known = false;
-};
-
-BigKernelInfo &big_kernel_info(const void *kernel) {
-    static std::mutex mu;
-    static std::unordered_map<const void *, BigKernelInfo> table;
-    std::lock_guard<std::mutex> lock(mu);
-    BigKernelInfo &info = table[kernel];
-    if (!info.known) {
-        hipFuncAttributes attr;
-        if (hipFuncGetAttributes(&attr, kernel) == hipSuccess) info.static_lds = attr.sharedSizeBytes;
-        else info.static_lds = 28 * 1024;            // (the largest wave_lds of these kernels)
-        info.known = true;
-    }
-    return info;
-}
+// counters, and with the stale tree 20 KB of kd-walk rows) -- asked of the runtime once per (device, kernel) and remembered,
+// like the dynamic size already granted there (prl_dynlds.hpp).
+size_t big_static_lds(const void *kernel) { return prl_static_lds(kernel); }
+hipError_t big_grant_lds(const void *kernel, size_t lds) { return prl_grant_dyn_lds(kernel, lds); }
 
 constexpr size_t LDS_PER_WORKGROUP = 160 * 1024;
 
 template <typename K>
 int big_waves(K kernel, const StepArgs &a, int copies, size_t extra_per_wave) {
     const size_t per_wave = (size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave;
-    const size_t fixed = big_kernel_info(reinterpret_cast<const void *>(kernel)).static_lds;
+    const size_t fixed = big_static_lds(reinterpret_cast<const void *>(kernel));
     if (fixed >= LDS_PER_WORKGROUP) return 0;
     int waves = per_wave ? (int)((LDS_PER_WORKGROUP - fixed) / per_wave) : 4;
     return waves > 4 ? 4 : waves;
@@ -293,28 +274,42 @@ int launch_big(void (*kernel)(StepArgs, Extra...), const StepArgs &a, int copies
     const int waves = big_waves(kernel, a, copies, extra_per_wave);
     if (waves < 1) return (int)hipErrorInvalidValue;              // (the caller names the part's size in its message)
     const size_t lds = (size_t)waves * ((size_t)copies * a.mask_stride * sizeof(uint64_t) + extra_per_wave);
-    BigKernelInfo &info = big_kernel_info(reinterpret_cast<const void *>(kernel));
-    if (lds > info.dyn_granted) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        info.dyn_granted = lds;
-    }
+    if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(kernel), lds)) return (int)e;
     hipLaunchKernelGGL(kernel, dim3((a.n_envs + waves - 1) / waves), dim3(64 * waves), lds, s, a, extra...);
     return (int)hipGetLastError();
+}
+
+typedef void (*BigStepFn)(StepArgs);
+BigStepFn pick_big_step(const PrlStepSel &sel) {
+    const bool gs = sel.gensec != 0;
+    if (sel.hsi)
+        return sel.kd ? (gs ? step_kernel_big<true, true, true> : step_kernel_big<false, true, true>)
+                      : (gs ? step_kernel_big<true, false, true> : step_kernel_big<false, false, true>);
+    return sel.kd ? (gs ? step_kernel_big<true, true, false> : step_kernel_big<false, true, false>)
+                  : (gs ? step_kernel_big<true, false, false> : step_kernel_big<false, false, false>);
 }
 
 }  // namespace
 
 PRL_HIDDEN int KFN(step)(const void *step_args, const PrlStepSel *sel, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    const bool gs = sel->gensec != 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sel->hsi)
-        return launch_big(sel->kd ? (gs ? step_kernel_big<true, true, true> : step_kernel_big<false, true, true>)
-                                  : (gs ? step_kernel_big<true, false, true> : step_kernel_big<false, false, true>), a, 4, 0, s);
-    return launch_big(sel->kd ? (gs ? step_kernel_big<true, true, false> : step_kernel_big<false, true, false>)
-                              : (gs ? step_kernel_big<true, false, false> : step_kernel_big<false, false, false>), a, 3, 0, s);
+    return launch_big(pick_big_step(*sel), a, sel->hsi ? 4 : 3, 0, static_cast<hipStream_t>(stream));
+}
+
+// what prl_batch_step_occupancy reports: waves per workgroup, workgroups resident per CU, dynamic LDS bytes
+PRL_HIDDEN int KFN(step_occupancy)(const void *step_args, const PrlStepSel *sel, int out[3]) {
+    const StepArgs &a = *static_cast<const StepArgs *>(step_args);
+    const BigStepFn k = pick_big_step(*sel);
+    const int copies = sel->hsi ? 4 : 3, waves = big_waves(k, a, copies, 0);
+    if (waves < 1) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)waves * copies * a.mask_stride * sizeof(uint64_t);
+    if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;
+    int nb = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 64 * waves, lds);
+    out[0] = waves;
+    out[1] = nb;
+    out[2] = (int)lds;
+    return (int)e;
 }
 
 PRL_HIDDEN int KFN(reset)(const void *step_args, int gensec, void *stream) {
@@ -344,10 +339,7 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
 PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double *out, int n_start, int n_words, int gensec) {
     void (*k)(const PartDev *, const CfgDev *, double *) = gensec ? reset_obs_kernel<0, true> : reset_obs_kernel<0, false>;
     const size_t lds = (size_t)4 * n_words * sizeof(uint64_t);
-    if (lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;
     hipLaunchKernelGGL(k, dim3((n_start + 3) / 4), dim3(256), lds, 0, static_cast<const PartDev *>(part_dev),
                        static_cast<const CfgDev *>(cfg_dev), out);
     return (int)hipGetLastError();

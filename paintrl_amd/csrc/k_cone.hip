@@ -184,10 +184,7 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
     if (sel->hsi) {
         void (*k)(StepArgs) = sel->gensec ? cone_finish_kernel<PRL_KW, true, true, 4> : cone_finish_kernel<PRL_KW, false, true, 4>;
         const size_t lds = sizeof(int) * 4 * (size_t)a.cone_nb;        // the four waves' hit lists
-        if (lds > 32 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-        }
+        if (const hipError_t e = prl_grant_dyn_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;      // (once per device)
         hipLaunchKernelGGL(k, grid, block, lds, s, a);
     } else if (sel->gensec) {
         hipLaunchKernelGGL((cone_finish_kernel<PRL_KW, true, false, 4>), grid, block, 0, s, a);

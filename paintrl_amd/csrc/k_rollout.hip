@@ -314,10 +314,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
 
 template <typename Args>
 int launch_dyn(void (*kernel)(Args), const Args &args, int n_envs, int waves, size_t lds, hipStream_t s) {
-    if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
+    if (const hipError_t e = prl_grant_dyn_lds(reinterpret_cast<const void *>(kernel), lds)) return (int)e;      // (once per device, not per launch)
     hipLaunchKernelGGL(kernel, dim3((n_envs + waves - 1) / waves), dim3(64 * waves), lds, s, args);
     return (int)hipGetLastError();
 }

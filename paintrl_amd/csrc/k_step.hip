@@ -145,18 +145,24 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     TRACE_END(env, dn);
 }
 
+typedef void (*StepKernelFn)(StepArgs);
+template <int WAVES>
+StepKernelFn pick_step(const PrlStepSel &sel) {
+    constexpr int KW = PRL_KW;
+    if (sel.kd && sel.hsi && sel.gensec) return step_kernel<KW, true, true, true, WAVES>;
+    if (sel.kd && sel.hsi) return step_kernel<KW, false, true, true, WAVES>;
+    if (sel.kd && sel.gensec) return step_kernel<KW, true, false, true, WAVES>;
+    if (sel.kd) return step_kernel<KW, false, false, true, WAVES>;
+    if (sel.hsi && sel.gensec) return step_kernel<KW, true, true, false, WAVES>;
+    if (sel.hsi) return step_kernel<KW, false, true, false, WAVES>;
+    if (sel.gensec) return step_kernel<KW, true, false, false, WAVES>;
+    return step_kernel<KW, false, false, false, WAVES>;
+}
+
 template <int WAVES>
 void launch_step_w(const StepArgs &a, const PrlStepSel &sel, hipStream_t s) {
-    constexpr int KW = PRL_KW;
     const dim3 grid((a.n_envs + WAVES - 1) / WAVES), block(64 * WAVES);
-    if (sel.kd && sel.hsi && sel.gensec) hipLaunchKernelGGL((step_kernel<KW, true, true, true, WAVES>), grid, block, 0, s, a);
-    else if (sel.kd && sel.hsi) hipLaunchKernelGGL((step_kernel<KW, false, true, true, WAVES>), grid, block, 0, s, a);
-    else if (sel.kd && sel.gensec) hipLaunchKernelGGL((step_kernel<KW, true, false, true, WAVES>), grid, block, 0, s, a);
-    else if (sel.kd) hipLaunchKernelGGL((step_kernel<KW, false, false, true, WAVES>), grid, block, 0, s, a);
-    else if (sel.hsi && sel.gensec) hipLaunchKernelGGL((step_kernel<KW, true, true, false, WAVES>), grid, block, 0, s, a);
-    else if (sel.hsi) hipLaunchKernelGGL((step_kernel<KW, false, true, false, WAVES>), grid, block, 0, s, a);
-    else if (sel.gensec) hipLaunchKernelGGL((step_kernel<KW, true, false, false, WAVES>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<KW, false, false, false, WAVES>), grid, block, 0, s, a);
+    hipLaunchKernelGGL(pick_step<WAVES>(sel), grid, block, 0, s, a);
 }
 
 }  // namespace
@@ -166,6 +172,18 @@ PRL_HIDDEN int KFN(step)(const void *step_args, const PrlStepSel *sel, void *str
     if (sel->wide) launch_step_w<STEP_WAVES_WIDE>(a, *sel, static_cast<hipStream_t>(stream));
     else launch_step_w<STEP_WAVES_NARROW>(a, *sel, static_cast<hipStream_t>(stream));
     return (int)hipGetLastError();
+}
+
+// what prl_batch_step_occupancy reports: waves per workgroup, workgroups resident per CU, dynamic LDS bytes
+PRL_HIDDEN int KFN(step_occupancy)(const void *, const PrlStepSel *sel, int out[3]) {
+    const int waves = sel->wide ? STEP_WAVES_WIDE : STEP_WAVES_NARROW;
+    int nb = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, reinterpret_cast<const void *>(sel->wide ? pick_step<STEP_WAVES_WIDE>(*sel) : pick_step<STEP_WAVES_NARROW>(*sel)), 64 * waves, 0);
+    out[0] = waves;
+    out[1] = nb;
+    out[2] = 0;
+    return (int)e;
 }
 
 PRL_HIDDEN int KFN(reset)(const void *step_args, int gensec, void *stream) {

@@ -1000,6 +1000,22 @@ int prl_batch_step(PrlBatch *b, const void *actions, double *obs, double *reward
     return PRL_OK;
 }
 
+int prl_batch_step_occupancy(PrlBatch *b, int32_t *out) {
+    if (!b || !out) return fail(PRL_E_INVALID, "null argument");
+    if (int rc = check_device(b)) return rc;
+    const StepArgs a = base_args(b);
+    const PrlStepSel sel = step_sel(b);
+    int o[3] = {0, 0, 0};
+    if (int e = PRL_KW_SWITCH(b->kw, step_occupancy)(&a, &sel, o)) return launch_failed(e, "prl_batch_step_occupancy");
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device));
+    out[0] = o[0];
+    out[1] = o[1];
+    out[2] = o[2];
+    out[3] = cus;
+    return PRL_OK;
+}
+
 int prl_batch_set_pose(PrlBatch *b, int env_index, const double *pos, const double *quat) {
     if (!b || !pos || !quat || env_index < 0 || env_index >= b->n_envs) return fail(PRL_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(b->device));

@@ -21,6 +21,7 @@
 
 extern "C" __attribute__((visibility("hidden"))) int prl_set_error_(int code, const char *msg);   // paintrl_hip.hip
 
+#include "prl_dynlds.hpp"
 #include "prl_policy.hpp"
 
 namespace {
@@ -72,8 +73,7 @@ extern "C" int prl_policy_act(const PrlPolicyWeights *w, int n, const double *ob
     const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
     if (lds > 120 * 1024) return prl_set_error_(PRL_E_UNSUPPORTED, "prl_policy_act: layer sizes need more than 120 KB of LDS per 16 envs");
     if (reinterpret_cast<uintptr_t>(w->w2) % 16) return prl_set_error_(PRL_E_INVALID, "prl_policy_act: w2 must be 16-byte aligned");
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(policy_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (prl_grant_dyn_lds(reinterpret_cast<const void *>(policy_act_kernel), lds) != hipSuccess)      // (once per device, not per launch)
         return prl_set_error_(PRL_E_HIP, "prl_policy_act: hipFuncSetAttribute");
     hipLaunchKernelGGL(policy_act_kernel, dim3((n + ROWS - 1) / ROWS), dim3(64 * POLICY_WAVES), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();

@@ -14,6 +14,7 @@
 
 #include "paintrl.h"
 #include "prl_launch.hpp"
+#include "prl_dynlds.hpp"
 
 #include "prl_diag.hpp"
 #include "prl_device.hpp"

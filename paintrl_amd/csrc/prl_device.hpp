@@ -55,7 +55,8 @@ struct PartDev {
     gdouble_p samp_a1, samp_a2;   // = samp[a1], samp[a2]: a dynamic index into samp[] would be a memory load of the pointer
     gdouble_p word_bbox;
     gu64_p word_valid;
-    gint_p samp_rank;             // canonical (reference-order) index of each device sample, pads = INT_MAX
+    gint_p samp_rank;             // tie rank of each device sample: its place in the reference cKDTree's own index array
+                                  // (part_tables._sample_tie_rank; equal distances resolve to the lowest), pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
     // fine sample grid for the cone-beam painter's nearest-sample queries, one query per lane (prl_cone.hpp; derived

@@ -21,6 +21,7 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
 
 #define PRL_K_PROTOS(KW)                                                                                               \
     PRL_HIDDEN int prl_k##KW##_step(const void *step_args, const PrlStepSel *sel, void *stream);                       \
+    PRL_HIDDEN int prl_k##KW##_step_occupancy(const void *step_args, const PrlStepSel *sel, int out[3]);               \
     PRL_HIDDEN int prl_k##KW##_reset(const void *step_args, int gensec, void *stream);                                 \
     PRL_HIDDEN int prl_k##KW##_observe(const void *step_args, int gensec, void *stream);                               \
     PRL_HIDDEN int prl_k##KW##_reset_obs(const void *part_dev, const void *cfg_dev, double *out, int n_start,          \

@@ -277,6 +277,12 @@ def _vertex_tie_rank(side_rows):
     return rank
 
 
+def tie_order_python():
+    """'major.minor' of the interpreter whose set iteration order _sample_tie_rank restates by running it."""
+    import sys
+    return '%d.%d' % sys.version_info[:2]
+
+
 def _sample_tie_rank(pix, pos, insertion, W):
     """Who wins `pixel_kd_tree.query(point, k=1)` (bpw:565) among samples at EQUAL distance -- in practice samples with
     the same 3-D position: texels of different triangles that map to one mesh vertex (109 pairs on the reference's
@@ -291,7 +297,8 @@ def _sample_tie_rank(pix, pos, insertion, W):
     lin = np.array([p[0] + p[1] * W for p in profile], dtype=np.int64)
     canon = pix[:, 0].astype(np.int64) + pix[:, 1].astype(np.int64) * W      # ascending (canonical sample order)
     to_canon = np.searchsorted(canon, lin)
-    assert len(profile) == len(canon) and np.array_equal(canon[to_canon], lin)
+    if len(profile) != len(canon) or not np.array_equal(canon[to_canon], lin):      # (not an assert: -O must not strip it)
+        raise ValueError('_sample_tie_rank: the rasterised pixel set does not match the canonical sample table')
     tree = cKDTree(pos[to_canon])                                    # bpw:620
     rank = np.empty(len(canon), dtype=np.int32)
     rank[to_canon[np.asarray(tree.indices)]] = np.arange(len(canon), dtype=np.int32)
@@ -902,6 +909,9 @@ def save_tables(t, path):
     meta = {k: (getattr(t, k) if not isinstance(getattr(t, k), np.generic) else getattr(t, k).item())
             for k in _SCALAR_FIELDS}
     meta.update(format_version=TABLE_FORMAT_VERSION, ranges=t.ranges, vertices_mutated=[int(v) for v in t.vertices_mutated])
+    # the tie order of equal samples (_sample_tie_rank) is the iteration order of a CPython set of int tuples, which belongs
+    # to the interpreter that built the tables (tuple hashing changed in CPython 3.8): recorded, checked by load_tables
+    meta.update(built_with_python=tie_order_python())
     data['meta'] = np.array(json.dumps(meta))
     for key in ('anchor_points', 'all_points', 'edge_points'):
         data[key] = np.asarray(getattr(t, key), dtype=np.float64).reshape(-1, 2, 3)
@@ -923,6 +933,12 @@ def load_tables(path):
     if meta.get('format_version') != TABLE_FORMAT_VERSION:
         raise ValueError('%s: table format %r, this build reads %d' % (path, meta.get('format_version'),
                                                                        TABLE_FORMAT_VERSION))
+    built = meta.get('built_with_python')
+    if built is not None and built != tie_order_python():
+        import warnings
+        warnings.warn('%s was built under Python %s, this is %s: the tie order of equally distant samples (cone-beam paint, '
+                      'bpw:565 / 641) is the set iteration order of the interpreter that ran the reference; rebuild the tables '
+                      'under the interpreter whose behaviour you want to match' % (path, built, tie_order_python()))
     t = PartTables()
     for k in _ARRAY_FIELDS:
         setattr(t, k, z[k])

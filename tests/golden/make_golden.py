@@ -100,7 +100,7 @@ class RefDriver(object):
     def painted_bits(self):
         return np.packbits(np.array([bool(self.part.get_pixel_status(p)) for p in self.pix]), bitorder='little')
 
-    def episode(self, seed, policy, max_steps=400, want_idx=None, after_reset=None):
+    def episode(self, seed, policy, max_steps=400, want_idx=None, after_reset=None, snap_every=SNAP_EVERY):
         obs0, idx = self.reset(seed)
         while want_idx is not None and idx != want_idx:      # walk seeds until the wanted start comes up
             seed += 1000
@@ -123,7 +123,7 @@ class RefDriver(object):
                 rec['done'].append(done)
                 rec['info'].append([info['reward'], info['penalty']])
                 k += 1
-                if k % SNAP_EVERY == 0 or done:
+                if k % snap_every == 0 or done:
                     rec['snaps'].append(self.painted_bits())
                     rec['snap_steps'].append(k)
         if not rec['snap_steps'] or rec['snap_steps'][-1] != k:
@@ -436,6 +436,43 @@ def main_off_part():
         assert bool(ep['done'][-1]) and int(ep['terminate_counter']) > 1000 and bool(ep['robot_terminate'])
 
 
+def main_every_step():
+    """Three episodes whose painted-texel set is recorded after EVERY step (the other fixtures snapshot every 25 steps and
+    at the end): the headline configuration (door, section, random walk from an anchor + a serpentine), the sheet with the
+    grid observation and OVERLAP_PENALTY (the last-shot set decides the penalty every step), and the door under the cone
+    beams.  -> episodes_door_every_step.npz / episodes_sheet_every_step.npz; nothing else is touched."""
+    root = os.path.join(HERE, '_synth_root')
+    synth_parts.write_synthetic_parts(root)
+    ref_import.load_reference('hull')
+    door = RefDriver(root, 0)
+    eps = {}
+    door.configure('section', 4, 'anchor')
+    for s in range(91, 140):                 # the first of these random walks that stays on the part for 30 steps or more
+        ep = door.episode(611, random_policy(s), max_steps=245, snap_every=1)
+        if len(ep['actions']) >= 30:
+            break
+    eps['e1_door_section_random'] = ep
+    eps['e1_door_section_serpentine'] = door.episode(612, zigzag_policy_grid(), max_steps=90, want_idx=0, snap_every=1)
+    door.configure('section', 4, 'anchor', paint_method='normal')
+    eps['e3_door_cone'] = door.episode(613, zigzag_policy_grid(), max_steps=14, want_idx=0, snap_every=1)
+    save_episodes('door_every_step', eps)
+    door.env.close()
+    sheet = RefDriver(root, 1)
+    eps = {}
+    sheet.configure('grid', 4, 'anchor', overlap=True)
+    eps['e2_sheet_grid_overlap'] = sheet.episode(614, zigzag_policy_grid(), max_steps=80, want_idx=0, snap_every=1)
+    save_episodes('sheet_every_step', eps)
+    for tag in ('door_every_step', 'sheet_every_step'):
+        z = np.load(os.path.join(HERE, 'episodes_%s.npz' % tag), allow_pickle=False)
+        for name in json.loads(str(z['episodes'])):
+            assert len(z[name + '/snap_steps']) == len(z[name + '/actions']), name
+    path = os.path.join(HERE, 'MANIFEST.json')
+    meta = json.load(open(path))
+    meta['python'] = '%d.%d.%d' % sys.version_info[:3]        # (the tie order of equal samples is this interpreter's: part_tables)
+    with open(path, 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def main_timing(procs=8, steps=400):
     """BASELINE.md 4.1 / SURVEY 8d: the reference's own step() on the build container's cores -- `procs` processes x one env,
     `steps` random discrete-4 steps each with reset on done, the time of the stand-in's rayTestBatch (this project's numpy
@@ -480,7 +517,7 @@ def main():
     synth_parts.write_synthetic_parts(root)
     rge, bpw, rob, pte, stub = ref_import.load_reference('hull')
     meta = {'stub_version': stub.STUB_VERSION, 'collision_mode': stub.COLLISION_MODE,
-            'numpy': np.__version__, 'generated_by': 'tests/golden/make_golden.py'}
+            'numpy': np.__version__, 'python': '%d.%d.%d' % sys.version_info[:3], 'generated_by': 'tests/golden/make_golden.py'}
     np.savez_compressed(os.path.join(HERE, 'g1_param_test.npz'), **param_test_golden(pte))
 
     timings = {}
@@ -588,5 +625,7 @@ if __name__ == '__main__':
         main_timing()
     elif '--off-part' in sys.argv:
         main_off_part()
+    elif '--every-step' in sys.argv:
+        main_every_step()
     else:
         main()

@@ -10,11 +10,13 @@ import os
 
 from conftest import GOLDEN
 
-TAGS = [t for t in ('door', 'sheet', 'sheet_tool', 'door_big', 'door_hsi', 'sparse', 'door_term', 'sheet_term', 'door_hsi_cone', 'seam')
+TAGS = [t for t in ('door', 'sheet', 'sheet_tool', 'door_big', 'door_hsi', 'sparse', 'door_term', 'sheet_term', 'door_hsi_cone', 'seam',
+                      'door_every_step', 'sheet_every_step')
         if os.path.isfile(os.path.join(GOLDEN, 'episodes_%s.npz' % t))]
 CASES = [(tag, n) for tag in TAGS for n in sorted(load_episodes(tag))]
 PART = {'door': 'door_test', 'sheet': 'square', 'sheet_tool': 'square', 'door_big': 'door_rr_big', 'door_hsi': 'door_test',
-        'sparse': 'test', 'door_term': 'door_test', 'sheet_term': 'square', 'door_hsi_cone': 'door_test', 'seam': 'door_lf'}
+        'sparse': 'test', 'door_term': 'door_test', 'sheet_term': 'square', 'door_hsi_cone': 'door_test', 'seam': 'door_lf',
+        'door_every_step': 'door_test', 'sheet_every_step': 'square'}
 
 
 def replay(backend_step, backend_reset, ep, exact=True, atol=0.0):
