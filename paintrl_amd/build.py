@@ -31,6 +31,7 @@ UNITS = [('host', 'paintrl_hip.hip', []), ('policy', 'policy_mlp.hip', []), ('k_
 # dependent reads, four to a SIMD): measured 1.4 % (section), 1.8 % (grid), 1.4 % (policy fragment) faster, same results;
 # the cone-beam units lose 1 % with it and keep the default (profiles/r04_ab_log.txt, tools/build_sched_variants.py).
 ILP_SCHED = ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-mllvm', '-amdgpu-schedule-relaxed-occupancy']
+UNITS += [('k_rollout0', 'k_rollout.hip', ['-DPRL_KW=0'] + ILP_SCHED)]          # the fused rollout kernels of large parts (masks in HBM)
 for _kw in (1, 2, 3, 4):
     UNITS += [('k_step%d' % _kw, 'k_step.hip', ['-DPRL_KW=%d' % _kw] + ILP_SCHED), ('k_cone%d' % _kw, 'k_cone.hip', ['-DPRL_KW=%d' % _kw]),
               ('k_rollout%d' % _kw, 'k_rollout.hip', ['-DPRL_KW=%d' % _kw] + ILP_SCHED)]

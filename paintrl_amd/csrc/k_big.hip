@@ -1,7 +1,9 @@
 // k_big.hip -- parts with more than 16 384 samples (door_lf ... door_rr_big, Part_Dict rge:106-117: 18 000 - 71 000
-// front samples) do not fit four mask words per lane.  Their kernels keep the env's masks in LDS instead (three copies
-// of n_words words per env in the step kernel, one in reset / observe), sized at launch; everything else is the same
-// device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
+// front samples) do not fit four mask words per lane.  The ball painter's step (step_kernel_big) leaves the env's mask rows
+// where they are, in HBM / L2 (prl_step.hpp HbmMasks: the painter touches the words of its cell block in place, the
+// observation streams the painted row) -- no LDS for masks, sixteen waves a CU like the small parts' kernel.  COLOR_MODE
+// 'HSI' and the cone beams' finish kernel still work on LDS copies of the rows (BigMasks), sized at launch.  Everything else
+// is the same device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot)
 #include "prl_all.hpp"
 
@@ -49,8 +51,33 @@ __device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, in
                     base + (copies > 3 ? 3 * a.mask_stride : 0)};
 }
 
-template <bool GENSEC, bool KD, bool HSI>
-__global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
+// One launch = one batched step of a large part, COLOR_MODE 'RGB': one wavefront per env, WAVES envs per workgroup, four
+// waves a SIMD -- the small parts' step_kernel with the masks left in HBM.
+template <bool GENSEC, bool KD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void step_kernel_big(StepArgs) {
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (env >= a.n_envs) return;
+    const WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES>();
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
+    const HbmMasks masks = hbm_masks(a, env, P.n_words, lane);
+    double delta1, delta2, new_angle;
+    decode_action(C, a.actions, env, delta1, delta2, new_angle);
+    PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
+    const int dn = step_env<0, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                      new_angle, StepRows{&a}, wl PROF_PASS);
+    store_state_live(state_rec, S, lane, dn != 0);
+}
+
+// COLOR_MODE 'HSI' on a large part: four LDS copies of the rows per env (painted, last, the shot's set, the union of valid sets)
+template <bool GENSEC, bool KD>
+__global__ __launch_bounds__(256, 2) void step_kernel_big_hsi(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -62,12 +89,12 @@ __global__ __launch_bounds__(256, 2) void step_kernel_big(StepArgs) {
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const BigMasks masks = big_masks(a, env, P.n_words, lane, HSI ? 4 : 3);
+    const BigMasks masks = big_masks(a, env, P.n_words, lane, 4);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
-    const int dn = step_env<0, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                    new_angle, StepRows{&a}, wl PROF_PASS);
+    PROF_BEGIN();
+    const int dn = step_env<0, GENSEC, true, true, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                     new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
 
@@ -88,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
         a.painted[(size_t)env * a.mask_stride + w] = hsi ? ldg(P.word_valid, w) : 0;
         a.last[(size_t)env * a.mask_stride + w] = 0;
     }
+    if (lane < a.nz_stride) a.last_nz[(size_t)env * a.nz_stride + lane] = 0;       // (the whole last-shot row is zero: HbmMasks)
     if (hsi) {
         uint64_t *t8 = reinterpret_cast<uint64_t *>(a.thick + (size_t)env * 64 * a.mask_stride);
         for (int i = lane; i < 8 * P.n_words; i += 64) t8[i] = ~0ull;
@@ -100,19 +128,14 @@ __global__ __launch_bounds__(256, 2) void reset_kernel_big(StepArgs a) {
 }
 
 template <bool GENSEC>
-__global__ __launch_bounds__(256, 2) void observe_kernel_big(StepArgs a) {
+__global__ __launch_bounds__(256) void observe_kernel_big(StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
     PartRef P = *(const PartDev CAS *)(a.parts + (a.env_part ? a.env_part[env] : 0));
     CfgRef C = *(const CfgDev CAS *)a.cfg;
     const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
-    extern __shared__ uint64_t big_lds[];
-    uint64_t *painted = big_lds + (size_t)rfl((int)(threadIdx.x >> 6)) * a.mask_stride;
-    for (int w = lane; w < P.n_words; w += 64) painted[w] = a.painted[(size_t)env * a.mask_stride + w];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint64_t GAS *painted = (const uint64_t GAS *)(a.painted + (size_t)env * a.mask_stride);      // the row where it is
     observation_big<GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
                             wave_lds<GENSEC>().cnt);
 }
@@ -280,35 +303,51 @@ int launch_big(void (*kernel)(StepArgs, Extra...), const StepArgs &a, int copies
 }
 
 typedef void (*BigStepFn)(StepArgs);
-BigStepFn pick_big_step(const PrlStepSel &sel) {
+template <int WAVES>
+BigStepFn pick_big_step(const PrlStepSel &sel) {           // COLOR_MODE 'RGB': rows in HBM
     const bool gs = sel.gensec != 0;
-    if (sel.hsi)
-        return sel.kd ? (gs ? step_kernel_big<true, true, true> : step_kernel_big<false, true, true>)
-                      : (gs ? step_kernel_big<true, false, true> : step_kernel_big<false, false, true>);
-    return sel.kd ? (gs ? step_kernel_big<true, true, false> : step_kernel_big<false, true, false>)
-                  : (gs ? step_kernel_big<true, false, false> : step_kernel_big<false, false, false>);
+    return sel.kd ? (gs ? step_kernel_big<true, true, WAVES> : step_kernel_big<false, true, WAVES>)
+                  : (gs ? step_kernel_big<true, false, WAVES> : step_kernel_big<false, false, WAVES>);
+}
+BigStepFn pick_big_step_hsi(const PrlStepSel &sel) {
+    const bool gs = sel.gensec != 0;
+    return sel.kd ? (gs ? step_kernel_big_hsi<true, true> : step_kernel_big_hsi<false, true>)
+                  : (gs ? step_kernel_big_hsi<true, false> : step_kernel_big_hsi<false, false>);
 }
 
 }  // namespace
 
 PRL_HIDDEN int KFN(step)(const void *step_args, const PrlStepSel *sel, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    return launch_big(pick_big_step(*sel), a, sel->hsi ? 4 : 3, 0, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sel->hsi) return launch_big(pick_big_step_hsi(*sel), a, 4, 0, s);
+    if (sel->wide) hipLaunchKernelGGL(pick_big_step<STEP_WAVES_WIDE>(*sel), dim3((a.n_envs + STEP_WAVES_WIDE - 1) / STEP_WAVES_WIDE), dim3(64 * STEP_WAVES_WIDE), 0, s, a);
+    else hipLaunchKernelGGL(pick_big_step<STEP_WAVES_NARROW>(*sel), dim3((a.n_envs + STEP_WAVES_NARROW - 1) / STEP_WAVES_NARROW), dim3(64 * STEP_WAVES_NARROW), 0, s, a);
+    return (int)hipGetLastError();
 }
 
 // what prl_batch_step_occupancy reports: waves per workgroup, workgroups resident per CU, dynamic LDS bytes
 PRL_HIDDEN int KFN(step_occupancy)(const void *step_args, const PrlStepSel *sel, int out[3]) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    const BigStepFn k = pick_big_step(*sel);
-    const int copies = sel->hsi ? 4 : 3, waves = big_waves(k, a, copies, 0);
-    if (waves < 1) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)waves * copies * a.mask_stride * sizeof(uint64_t);
-    if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;
     int nb = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 64 * waves, lds);
+    if (sel->hsi) {
+        const BigStepFn k = pick_big_step_hsi(*sel);
+        const int waves = big_waves(k, a, 4, 0);
+        if (waves < 1) return (int)hipErrorInvalidValue;
+        const size_t lds = (size_t)waves * 4 * a.mask_stride * sizeof(uint64_t);
+        if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 64 * waves, lds);
+        out[0] = waves;
+        out[1] = nb;
+        out[2] = (int)lds;
+        return (int)e;
+    }
+    const int waves = sel->wide ? STEP_WAVES_WIDE : STEP_WAVES_NARROW;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, reinterpret_cast<const void *>(sel->wide ? pick_big_step<STEP_WAVES_WIDE>(*sel) : pick_big_step<STEP_WAVES_NARROW>(*sel)), 64 * waves, 0);
     out[0] = waves;
     out[1] = nb;
-    out[2] = (int)lds;
+    out[2] = 0;
     return (int)e;
 }
 
@@ -319,7 +358,7 @@ PRL_HIDDEN int KFN(reset)(const void *step_args, int gensec, void *stream) {
 
 PRL_HIDDEN int KFN(observe)(const void *step_args, int gensec, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
-    return launch_big(gensec ? observe_kernel_big<true> : observe_kernel_big<false>, a, 1, 0, static_cast<hipStream_t>(stream));
+    return launch_big(gensec ? observe_kernel_big<true> : observe_kernel_big<false>, a, 0, 0, static_cast<hipStream_t>(stream));
 }
 
 // the last launch of a cone-beam step (k_cone_beams.hip) for a large part
@@ -345,10 +384,6 @@ PRL_HIDDEN int KFN(reset_obs)(const void *part_dev, const void *cfg_dev, double 
     return (int)hipGetLastError();
 }
 
-// The fused rollout kernels are not built for large parts: the host side takes those entry points launch by launch
-// (paintrl_hip.hip fused_rollout) and never gets here.
-PRL_HIDDEN int KFN(act_step)(const void *, size_t, int, void *) { return (int)hipErrorNotSupported; }
-PRL_HIDDEN int KFN(rollout_policy)(const void *, size_t, int, void *) { return (int)hipErrorNotSupported; }
-PRL_HIDDEN int KFN(rollout_fragment)(const void *, int, void *) { return (int)hipErrorNotSupported; }
+// (the fused rollout kernels of large parts: k_rollout.hip compiled with -DPRL_KW=0)
 
 #include "prl_diag_export.hpp"

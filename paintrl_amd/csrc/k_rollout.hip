@@ -1,6 +1,7 @@
 // k_rollout.hip -- the rollout paths: policy + env step in one launch (act_step_kernel), whole fragments in ONE
 // persistent launch with the policy (rollout_policy_kernel) or with given actions (rollout_fragment_kernel).
-// Compiled once per mask width (-DPRL_KW=1..4), see prl_launch.hpp.  KD: parts of the batch may carry the reference's
+// Compiled once per mask width (-DPRL_KW=1..4, and -DPRL_KW=0 for parts beyond 16 384 samples: their mask rows stay in HBM,
+// prl_step.hpp HbmMasks, so these kernels carry no mask LDS for them), see prl_launch.hpp.  KD: parts of the batch may carry the reference's
 // stale vertex kd-tree (bpw:943-946; the reference's own sheet `square.urdf` does), walked in per-wave LDS rows.
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot; fragment 21.4 -> 21.8 k,
                                            // given actions 29.5 -> 30.3 k steps/s)
@@ -10,7 +11,7 @@
 #include "prl_policy.hpp"
 
 #ifndef PRL_KW
-#error "compile with -DPRL_KW=1..4 (paintrl_amd/build.py)"
+#error "compile with -DPRL_KW=0..4 (paintrl_amd/build.py)"
 #endif
 
 namespace {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
     const FragmentArgs CAS *f0 = (const FragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane0 = threadIdx.x & 63, wave0 = rfl((int)(threadIdx.x >> 6));
     const int lane = lane0, wave = wave0, env0 = blockIdx.x * FRAG_WAVES, env = env0 + wave;
-    {   // coverage masks: HBM -> LDS, once
+    if constexpr (KW != 0) {   // coverage masks: HBM -> LDS, once
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
         if (env < a.n_envs) {
@@ -125,7 +126,11 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             PartRef P = *(const PartDev CAS *)(a.parts + part_id);
             CfgRef C = *(const CfgDev CAS *)a.cfg;
             uint64_t *mask_lds = reinterpret_cast<uint64_t *>(lds) + (size_t)wave * 2 * a.mask_stride;
-            const LdsMasks masks{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
+            // (large parts: the rows stay in HBM and are worked on in place)
+            const auto masks = [&] {
+                if constexpr (KW == 0) return hbm_masks(a, env, P.n_words, lane);
+                else return LdsMasks{mask_lds, mask_lds + a.mask_stride, P.n_words, lane};
+            }();
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
             EnvState S;
             load_state_motion(state_rec, S);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
         FRAG_COUNT();
     }
     FRAG_FLUSH();
-    {   // coverage masks: LDS -> HBM
+    if constexpr (KW != 0) {   // coverage masks: LDS -> HBM
         const FragmentArgs CAS &f = *opaque(f0);
         const StepArgs CAS &a = f.s;
         if (env < a.n_envs) {
@@ -173,8 +178,11 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const GlobalMasksT<true> masks = global_masks<true>(a, env, P.n_words, lane);      // (changed words only: GlobalMasksT)
-    masks.prefetch();
+    const auto masks = [&] {
+        if constexpr (KW == 0) return hbm_masks(a, env, P.n_words, lane);      // (large parts: rows worked on in place)
+        else return global_masks<true>(a, env, P.n_words, lane);                // (changed words only: GlobalMasksT)
+    }();
+    if constexpr (KW != 0) masks.prefetch();
     double delta1, delta2, new_angle;
     decode_discrete_action(C, act, delta1, delta2, new_angle);
     const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
     {   // this kernel writes the last-shot rows whole, step by step: say so once (prl_step.hpp last_row_untracked)
         const StepArgs CAS &a0 = opaque(g0)->f.s;
         const int env_ = (int)blockIdx.x * POLICY_WAVES + wave0;
-        if (env_ < a0.n_envs) last_row_untracked(a0, env_, (int)(threadIdx.x & 63));
+        if constexpr (KW != 0)
+            if (env_ < a0.n_envs) last_row_untracked(a0, env_, (int)(threadIdx.x & 63));
     }
     for (int t = 0;; ++t) {
         const PolicyFragmentArgs CAS &g = *opaque(g0);
@@ -298,7 +307,10 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
             EnvState S;
             load_state_motion(state_rec, S);
-            const GlobalMasks masks = global_masks(a, env, P.n_words, lane);
+            const auto masks = [&] {
+                if constexpr (KW == 0) return hbm_masks(a, env, P.n_words, lane);      // (large parts: rows worked on in place)
+                else return global_masks(a, env, P.n_words, lane);
+            }();
             double delta1, delta2, new_angle;
             decode_discrete_action(C, act, delta1, delta2, new_angle);
             const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
@@ -335,7 +347,7 @@ PRL_HIDDEN int KFN(rollout_policy)(const void *policy_fragment_args, size_t poli
 
 PRL_HIDDEN int KFN(rollout_fragment)(const void *fragment_args, int kd, void *stream) {
     const FragmentArgs &f = *static_cast<const FragmentArgs *>(fragment_args);
-    const size_t lds = (size_t)FRAG_WAVES * 2 * f.s.mask_stride * sizeof(uint64_t);      // both masks of sixteen envs
+    const size_t lds = PRL_KW == 0 ? 0 : (size_t)FRAG_WAVES * 2 * f.s.mask_stride * sizeof(uint64_t);      // both masks of sixteen envs
     return launch_dyn(kd ? rollout_fragment_kernel<PRL_KW, true> : rollout_fragment_kernel<PRL_KW, false>, f, f.s.n_envs, FRAG_WAVES, lds,
                       static_cast<hipStream_t>(stream));
 }

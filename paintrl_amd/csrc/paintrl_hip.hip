@@ -94,7 +94,8 @@ struct PrlBatch {
     CfgDev *cfg_dev = nullptr;
     int *env_part_dev = nullptr;
     uint64_t *painted = nullptr, *last = nullptr;
-    uint64_t *last_nz = nullptr;          // StepArgs::last_nz (batches of parts with register-resident masks)
+    uint64_t *last_nz = nullptr;          // StepArgs::last_nz
+    int nz_stride = 0;                    // words of it per env: KW_MAX (register-resident masks), (mask_stride + 63) / 64 (large parts)
     uint8_t *thick = nullptr;      // COLOR_MODE 'HSI' only
     double *cone_shots = nullptr, *cone_aux = nullptr;      // PAINT_METHOD 'normal' only (StepArgs)
     int *cone_hits = nullptr, *cone_work = nullptr;
@@ -708,6 +709,7 @@ StepArgs base_args(PrlBatch *b) {
     a.painted = b->painted;
     a.last = b->last;
     a.last_nz = b->last_nz;
+    a.nz_stride = b->nz_stride;
     a.thick = b->thick;
     a.state = b->state;
     a.cone_shots = b->cone_shots;
@@ -864,8 +866,9 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->painted), mask_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last), mask_bytes);
-    if (e == hipSuccess && b->kw <= KW_MAX) e = hipMalloc(reinterpret_cast<void **>(&b->last_nz), sizeof(uint64_t) * KW_MAX * (size_t)n_envs);
-    if (e == hipSuccess && b->last_nz) e = hipMemset(b->last_nz, 0, sizeof(uint64_t) * KW_MAX * (size_t)n_envs);
+    b->nz_stride = b->kw <= KW_MAX ? KW_MAX : (b->mask_stride + 63) / 64;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last_nz), sizeof(uint64_t) * b->nz_stride * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMemset(b->last_nz, 0, sizeof(uint64_t) * b->nz_stride * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->state), state_bytes);
     if (e == hipSuccess && cfg->color_mode == PRL_COLOR_HSI) {
         e = hipMalloc(reinterpret_cast<void **>(&b->thick), mask_bytes * 8);        // one byte per sample
@@ -1085,12 +1088,12 @@ static int check_rollout_batch(PrlBatch *b, const char *who) {
     return PRL_OK;
 }
 
-// The fused rollout kernels (k_rollout.hip) are built around the ball painter's step with register-resident masks and the
-// 4-sector observation; every other configuration (cone beams, COLOR_MODE 'HSI', atan2 sectors, parts beyond 16 384
-// samples) takes the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
+// The fused rollout kernels (k_rollout.hip) are built around the ball painter's step (masks in registers, or for parts beyond
+// 16 384 samples in HBM) and the 4-sector observation; every other configuration (cone beams, COLOR_MODE 'HSI', atan2
+// sectors) takes the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
 static bool fused_rollout(const PrlBatch *b) {
     const PrlConfig &c = b->cfg;
-    return b->kw <= KW_MAX && c.color_mode == PRL_COLOR_RGB && c.paint_method == PRL_PAINT_FAST && !general_section(c);
+    return c.color_mode == PRL_COLOR_RGB && c.paint_method == PRL_PAINT_FAST && !general_section(c);
 }
 
 static int check_policy(const PrlBatch *b, const PrlPolicyWeights *w, const char *who) {
@@ -1204,7 +1207,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     f.done = done;
     f.info = info;
     f.action = action;
-    const size_t lds = (size_t)POLICY_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
+    const size_t lds = b->kw > KW_MAX ? 0 : (size_t)POLICY_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
     if (lds > 120 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
     if (int e = PRL_KW_SWITCH(b->kw, rollout_fragment)(&f, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_rollout_fragment");
     return PRL_OK;

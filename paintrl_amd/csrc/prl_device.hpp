@@ -43,6 +43,7 @@ typedef const float GAS *gfloat_p;
 typedef const int GAS *gint_p;
 typedef const uint64_t GAS *gu64_p;
 typedef const uint8_t GAS *gu8_p;
+typedef uint64_t GAS *gu64_rw_p;                          // a mask row in HBM, read and written (HbmMasks)
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: loadable through GAS pointers
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -154,8 +155,9 @@ struct StepArgs {
     const int *env_part;          // device, or nullptr
     int n_envs, mask_stride;
     uint64_t *painted, *last;
-    uint64_t *last_nz;            // [n_envs][KW_MAX]: bit w & 63 of word w >> 6 = word w of the env's last-shot row is not zero (parts of
-                                  // up to 16 384 samples; every writer of `last` keeps it, or sets it to all ones)
+    uint64_t *last_nz;            // [n_envs][nz_stride]: bit w & 63 of word w >> 6 = word w of the env's last-shot row is not zero (every
+                                  // writer of `last` keeps it, or sets it to all ones)
+    int nz_stride;                // KW_MAX for parts of up to 16 384 samples, (mask_stride + 63) / 64 for larger ones (HbmMasks)
     uint8_t *thick;               // COLOR_MODE 'HSI': one byte per sample, [n_envs][64 * mask_stride]; else nullptr
     double *state;
     const void *actions;

@@ -38,10 +38,10 @@ __device__ __forceinline__ double py_floor_div(double vx, double wx) {
 
 // bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
 // is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
-// `lds_painted`: the LDS-resident mask of a large part, or nullptr (then the register slots `painted` are used).
-template <int KW>
+// `lds_painted`: the mask row of a large part (LDS copy or the env's row in HBM), or nullptr (then the register slots `painted` are used).
+template <int KW, typename PW>
 __device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
-                                     const uint64_t *lds_painted, int lane, int *cnt /* LDS: [2][64] for this wave */,
+                                     PW lds_painted, int lane, int *cnt /* LDS: [2][64] for this wave */,
                                      double *out) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
     cnt[lane] = 0;
@@ -366,7 +366,7 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         return;
     }
     if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
-        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, nullptr, lane, cnt_lds, out);
+        section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, static_cast<const uint64_t *>(nullptr), lane, cnt_lds, out);
         if (lane == 0) section_pose_tail(mode, C.obs_grad, np0, np1, out);
         return;
     } else {
@@ -383,11 +383,12 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
     }
 }
 
-// The same observation for a part with more than 16 384 samples: the painted mask lives in LDS (`painted`,
-// n_words words) and is walked 64 words at a time; counts can exceed 16 bits, so the per-lane 16-bit fields (at most
-// 64 x 18 per lane) are split into 32-bit halves before the wave sums.
-template <bool GENSEC>
-__device__ void observation_big(PartRef P, CfgRef C, const double pose[3], const uint64_t *painted, int lane,
+// The same observation for a part with more than 16 384 samples: the painted mask is a row of n_words words -- an LDS copy
+// (`const uint64_t *`) or the env's row in HBM (`uint64_t GAS *`: coalesced 8-byte loads, 8.9 KB per env-step at 71 000
+// samples) -- walked 64 words per lane slot; counts can exceed 16 bits, so the per-lane 16-bit fields (at most 64 x 25 per
+// lane) are split into 32-bit halves before the wave sums.
+template <bool GENSEC, typename PW>
+__device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW painted, int lane,
                                 double *out, int *cnt_lds) {
     double x1, x2, np0, np1;
     normalized_pose(P, C, pose, x1, x2, np0, np1);
@@ -442,10 +443,16 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], const
         return;
     } else {
         uint64_t tot_l = 0, und_l = 0;
-        for (int k = 0; k < n_slots; ++k) {
-            const int w = lane + 64 * k;
-            const uint64_t pk[KW_MAX] = {w < P.n_words ? painted[w] : 0, 0, 0, 0};
-            section4_accumulate<1>(P, x1, x2, pk, k, lane, tot_l, und_l);
+        // three lane slots a trip, like the door's own kernel (KW = 3): their box, pivot and group probes travel together
+        constexpr int G = 3;
+        for (int k = 0; k < n_slots; k += G) {
+            uint64_t pk[KW_MAX] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int w = lane + 64 * (k + j);
+                pk[j] = w < P.n_words ? painted[w] : 0;
+            }
+            section4_accumulate<G>(P, x1, x2, pk, k, lane, tot_l, und_l);
         }
         uint64_t t01 = (tot_l & 0xffffull) | ((tot_l & 0xffff0000ull) << 16), t23 = ((tot_l >> 32) & 0xffffull) | ((tot_l >> 48) << 32);
         uint64_t u01 = (und_l & 0xffffull) | ((und_l & 0xffff0000ull) << 16), u23 = ((und_l >> 32) & 0xffffull) | ((und_l >> 48) << 32);

@@ -40,6 +40,7 @@ __device__ __forceinline__ void set_word(uint64_t cur[KW_MAX], int w, uint64_t b
 // the masks in registers: word w lives in lane w & 63, slot w >> 6 ...
 template <int KW>
 struct RegWords {
+    static constexpr bool HBM = false;
     uint64_t *painted;            // [KW_MAX] register arrays of the caller
     const uint64_t *last;
     uint64_t *new_last;
@@ -55,7 +56,7 @@ struct RegWords {
                 lw = bcast_u64(last[k], owner);
             }
     }
-    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw, uint64_t, uint64_t) const {
         const int owner = w & 63, slot = w >> 6;
 #pragma unroll
         for (int k = 0; k < KW; ++k)
@@ -71,6 +72,7 @@ struct RegWords {
 // read instead of a lane broadcast per word.  `new_last` must be zero on entry.
 template <int KW>
 struct RowWords {
+    static constexpr bool HBM = false;
     uint64_t *painted;            // [KW_MAX] registers of the caller
     const uint64_t *last;         // LDS, word w at [w]
     uint64_t *new_last;           // LDS
@@ -83,7 +85,7 @@ struct RowWords {
             if (k == slot) pw = bcast_u64(painted[k], owner);
         lw = last[w];
     }
-    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw, uint64_t, uint64_t) const {
         const int owner = w & 63, slot = w >> 6;
 #pragma unroll
         for (int k = 0; k < KW; ++k)
@@ -94,6 +96,7 @@ struct RowWords {
 
 // ... larger ones (the 480 x 480 textures: up to ~70 000 samples) keep them in LDS for the length of the kernel.
 struct LdsWords {
+    static constexpr bool HBM = false;
     uint64_t *painted;            // [n_words] in LDS
     const uint64_t *last;
     uint64_t *new_last;           // zero on entry
@@ -102,11 +105,38 @@ struct LdsWords {
         pw = painted[w];
         lw = last[w];
     }
-    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw) const {
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw, uint64_t, uint64_t) const {
         if (lane == 0) {
             painted[w] = pw;
             new_last[w] = lw;
         }
+    }
+};
+
+// ... or leave them where they are: the env's rows in HBM / L2 (step_kernel_big, round 5).  A step paints a few dozen of
+// a large part's hundreds to 1 100 words: the painter reads the painted and the last-shot word of each word it visits (one load
+// each, every lane the same address: a single request, issued with the word's sample records) and lane 0 writes back what
+// changed.  The last-shot row of a step is zero outside the words its last shot touched; which words are not zero is kept as a
+// bit set per env (StepArgs::last_nz, one bit per word: lane k of the wave holds words 64 k .. 64 k + 63), so that the words a
+// step does NOT visit are cleared one by one instead of the row being rewritten (HbmMasks::paint_done, prl_step.hpp).
+//   vis: words this step's painter visited;  nzn: those of them whose new last-shot word is not zero.
+struct HbmWords {
+    static constexpr bool HBM = true;
+    gu64_rw_p painted, last;             // rows of this env
+    int lane;
+    uint64_t *vis, *nzn;                 // this lane's tracking words (registers of the caller)
+    __device__ __forceinline__ void get(int w, uint64_t &pw, uint64_t &lw) const {
+        pw = painted[w];
+        lw = last[w];
+    }
+    __device__ __forceinline__ void put(int w, uint64_t pw, uint64_t lw, uint64_t pw_old, uint64_t lw_old) const {
+        if (lane == 0) {
+            if (pw != pw_old) painted[w] = pw;
+            if (lw != lw_old) last[w] = lw;
+        }
+        const uint64_t bit = lane == (w >> 6) ? 1ull << (w & 63) : 0;
+        *vis |= bit;
+        *nzn |= lw != 0 ? bit : 0;
     }
 };
 
@@ -138,6 +168,9 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     }
     // (a NaN centre hits nothing and is ignored by fmin / fmax; five of them leave the inverted range: cell -2 as for a single NaN)
     const bool none = !(lo1 <= hi1);
+    // HbmWords: how far a word's box may lie from the centres' box and still hold a sample within the radius (a hair more)
+    const double reach_r = radius * (1.0 + 1.0e-9) + 1.0e-12;
+    const double reach_lo1 = lo1 - reach_r, reach_hi1 = hi1 + reach_r, reach_lo2 = lo2 - reach_r, reach_hi2 = hi2 + reach_r;
     const int cx_lo = none ? -2 : cell_coord(lo1, P.sg_o1, P.sg_inv, P.sg_nx), cx_hi = none ? -2 : cell_coord(hi1, P.sg_o1, P.sg_inv, P.sg_nx);
     const int cy_lo = none ? -2 : cell_coord(lo2, P.sg_o2, P.sg_inv, P.sg_ny), cy_hi = none ? -2 : cell_coord(hi2, P.sg_o2, P.sg_inv, P.sg_ny);
     double band = 16.0 * radius * 1.1920928955078125e-07 * (P.samp_absmax + radius) + 9.5367431640625e-07 * r2;
@@ -172,6 +205,8 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     // round trips a step).  Measured slower -- the step is bound by instruction issue, not by these waits -- and off.
     auto do_word = [&](int w, const f32x4 pf, int lo, int hi) {
         WCNT(5, 1);
+        uint64_t pw, lw;
+        if constexpr (Words::HBM) words.get(w, pw, lw);      // (requested with the records, needed after the distance tests)
         const int s = (w << 6) + lane;
         // every cell row starts on a word boundary (device_tables), so a word holds samples of one row only: [lo, hi)
         const bool in = (s >= lo) & (s < hi);
@@ -219,9 +254,9 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
                 any |= b[k];
             }
         }
-        uint64_t pw, lw;
-        words.get(w, pw, lw);
+        if constexpr (!Words::HBM) words.get(w, pw, lw);
         if (any == 0 && lw == 0) return;         // nothing to record for this word
+        const uint64_t pw_old = pw, lw_old = lw;
         // bpw:572-577 shot by shot (count newly painted, paint, valid = affected minus last shot, last =
         // affected), folded: the newly painted samples of the five shots are the union minus what was
         // painted before, and each shot's valid set only looks one shot back
@@ -232,7 +267,7 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
         for (int k = 1; k < PAINT_PER_ACTION; ++k) uw |= b[k] & ~b[k - 1];
         lw = b[PAINT_PER_ACTION - 1];
         pixel_counter += __popcll(uw);
-        words.put(w, pw, lw);
+        words.put(w, pw, lw, pw_old, lw_old);
     };
     // the words of the trip's rows as a bit set relative to the first (rows are consecutive in memory: a few dozen words)
     int base = -1;
@@ -280,9 +315,32 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
         for (int r = 0; r < TRIP; ++r) {
             if (re[r] <= rb[r]) continue;
             const int wlast = (re[r] - 1) >> 6;
-            for (int w = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1; w <= wlast; ++w) {
-                do_word(w, ldg(s4, (w << 6) + lane), rb[r], re[r]);
-                done_w = w;
+            const int wfirst = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1;
+            if constexpr (Words::HBM) {
+                // Large parts: a row's stretch of the cell block is dozens of words (70 654 samples: ~17 a row, ~70 a step) of
+                // which the five balls reach a third.  One word per lane first: a word whose box (principal plane) lies more
+                // than the radius beyond the centres' own box holds no sample within the radius of any centre -- |dx| > r gives
+                // dx dx > r r whatever dy, dz add -- so its hit sets are empty and the painter would leave it as it found it,
+                // except for clearing its last-shot word: HbmMasks::paint does that for every word not visited.
+                const f64x4 GAS *wb4 = reinterpret_cast<const f64x4 GAS *>(P.word_bbox);
+                for (int wb = wfirst; wb <= wlast; wb += 64) {
+                    const int wi = wb + lane;
+                    const bool inr = wi <= wlast;
+                    const f64x4 bb = ldg(wb4, inr ? wi : wb);
+                    const bool reach = inr & !((bb.x > reach_hi1) | (bb.y < reach_lo1) | (bb.z > reach_hi2) | (bb.w < reach_lo2));
+                    uint64_t m = ballot64(reach);
+                    while (m) {
+                        const int w = wb + __builtin_ctzll(m);
+                        m &= m - 1;
+                        do_word(w, ldg(s4, (w << 6) + lane), rb[r], re[r]);
+                    }
+                }
+                done_w = wlast > done_w ? wlast : done_w;
+            } else {
+                for (int w = wfirst; w <= wlast; ++w) {
+                    do_word(w, ldg(s4, (w << 6) + lane), rb[r], re[r]);
+                    done_w = w;
+                }
             }
         }
     }

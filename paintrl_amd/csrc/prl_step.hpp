@@ -380,11 +380,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
                             succeeded_f, pixel_counter);
     } else {
         if constexpr (BIG) {
-            paint_shots_union(P, C.paint_radius, cen, lane, LdsWords{masks.painted, masks.last, masks.new_last, lane},
-                              succeeded, pixel_counter);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            masks.paint(P, C.paint_radius, cen, succeeded, pixel_counter);      // (LDS copies: BigMasks, rows in HBM: HbmMasks)
         } else if (rows) {
 #if !defined(PRL_CUT) || PRL_CUT < 2
             paint_shots_union(P, C.paint_radius, cen, lane, RowWords<KW>{painted, wl.lastrow, wl.lastrow + 64 * KW, lane}, succeeded,
@@ -463,6 +459,66 @@ struct BigMasks {
             g_last[w] = new_last[w];
         }
     }
+    // bpw:568-577 fast_paint + _paint for the five shots on the LDS copies
+    __device__ __forceinline__ void paint(PartRef P, double radius, const double *cen, int &succeeded, int &pixel_counter) const {
+        paint_shots_union(P, radius, cen, lane, LdsWords{painted, last, new_last, lane}, succeeded, pixel_counter);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // lane 0 wrote the words, every lane reads them
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+// The masks of an env of a LARGE part left where they are -- rows in HBM / L2, no LDS copy (round 5: step_kernel_big, the
+// fused rollout kernels of large parts).  Three LDS copies of a 70 654-sample part's rows (door_rr_big, rge:116) were 26.6 KB
+// per env: four waves a CU, four generations of waves for a 4 096-env launch, and 2 x 17.7 KB of copying per env-step for a
+// step that paints a few dozen words.  Here the painter reads and writes the words of its cell block in place (HbmWords,
+// prl_paint.hpp), the observation streams the painted row with coalesced 8-byte loads, and the last-shot row is kept zero
+// outside the last shot's words by clearing exactly the words that were not zero before and were not visited now:
+//   nz: this env's row of StepArgs::last_nz, one bit per word of the last-shot row that may be non-zero (lane k holds the
+//       bits of words 64 k .. 64 k + 63; rows of up to 64 x 64 words).  Every writer of `last` of a large part keeps it exact
+//       or sets it to all ones (reset_kernel_big: zero, it clears the row).
+struct HbmMasks {
+    gu64_rw_p painted, last;                      // HBM rows of this env (the names finish_step reads)
+    gu64_rw_p nz;
+    int n_words, lane;
+    mutable uint64_t old_nz = 0, vis = 0, nzn = 0;    // this lane's words of: the set on entry | visited by the painter | non-zero after it
+    __device__ __forceinline__ int nz_words() const { return (n_words + 63) >> 6; }
+    template <int KW>
+    __device__ __forceinline__ void load(uint64_t *, uint64_t *) const {      // (called when the kernel starts: the set arrives under the shots)
+        old_nz = lane < nz_words() ? nz[lane] : 0;
+        vis = 0;
+        nzn = 0;
+    }
+    // zeroes the words of the last-shot row named by this lane's `set` bits (lane k: words 64 k ..): one store instruction per
+    // lane that names any, its 64 words over the 64 lanes
+    __device__ __forceinline__ void zero_last(uint64_t set) const {
+        uint64_t m = ballot64(set != 0);
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint64_t sk = bcast_u64(set, k);
+            if ((sk >> lane) & 1) last[64 * k + lane] = 0;
+        }
+    }
+    __device__ __forceinline__ void paint(PartRef P, double radius, const double *cen, int &succeeded, int &pixel_counter) const {
+        paint_shots_union(P, radius, cen, lane, HbmWords{painted, last, lane, &vis, &nzn}, succeeded, pixel_counter);
+        // bpw:575-576: the last shot's set replaces the previous one -- what was set before and not visited now is cleared
+        zero_last(old_nz & ~vis);
+        if (lane < nz_words() && nzn != old_nz) nz[lane] = nzn;
+        old_nz = nzn;
+        // lane 0 wrote the words, the observation's lanes read them: same CU, same L1 -- ordered once the stores have left
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __device__ __forceinline__ void clear() const {               // reset: nothing painted, no last shot
+        for (int w = lane; w < n_words; w += 64) painted[w] = 0;
+        zero_last(old_nz);
+        if (lane < nz_words() && old_nz != 0) nz[lane] = 0;
+        old_nz = 0;
+    }
+    __device__ __forceinline__ void all_painted(PartRef) const {}
+    template <int KW>
+    __device__ __forceinline__ void store(const uint64_t *, const uint64_t *) const {}
 };
 
 // The masks of env `env` in HBM: word w of a mask is read / written by lane w & 63 into slot w >> 6.
@@ -488,6 +544,12 @@ __device__ __forceinline__ void stream_store(T *p, T v) {
 #else
     *p = v;
 #endif
+}
+
+// the mask rows of env `env` of the launch, left in HBM (HbmMasks)
+__device__ __forceinline__ HbmMasks hbm_masks(const StepArgs CAS &a, int env, int n_words, int lane) {
+    return HbmMasks{(gu64_rw_p)(a.painted + (size_t)env * a.mask_stride), (gu64_rw_p)(a.last + (size_t)env * a.mask_stride),
+                    (gu64_rw_p)(a.last_nz + (size_t)env * a.nz_stride), n_words, lane};
 }
 
 template <bool TRACK>

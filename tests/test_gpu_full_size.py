@@ -159,6 +159,26 @@ def test_mixed_door_sheet_30_steps_with_auto_reset_equals_oracle():
     env.close()
 
 
+@pytest.mark.parametrize('tex,kw,steps', [
+    (480, dict(obs_mode='section', overlap_penalty=True), 24),          # 38 224 samples (door_rf class), the last-shot row in use
+    (652, dict(obs_mode='section'), 10),                                # 70 411 samples (door_rr_big, rge:116)
+])
+def test_large_part_full_size_with_auto_reset_equals_oracle(tex, kw, steps):
+    """Seven of the reference's ten parts exceed 16 384 samples (Part_Dict rge:106-117) and take step_kernel_big: the mask rows
+    stay in HBM, the painter works on the words of its cell block in place, the last-shot row is kept by its set of non-zero
+    words.  4 096 envs with auto-reset from the 'all' start table, every row against the oracle, every painted bit at the end."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables('door_rr_big', tex_size=(tex, tex))
+    sp = start_points_for(tables, 'all')
+    n = 4096
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True, max_possible_point=mpp, **kw)
+    assert env.mask_stride > 256
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16, max_possible_point=mpp, **kw)
+    _run(env, orc, np.full(n, len(sp)), steps, 909, n // 16)
+    env.close()
+
+
 def test_cone_beams_full_size_8_steps_equals_oracle():
     """PAINT_METHOD 'normal' (rob:251-285, bpw:562-566) at the launch shape of the benchmark: 4 096 envs, 8 steps with
     auto-reset, anchor starts (off-part shots, the window and the rim of the door all occur)."""
