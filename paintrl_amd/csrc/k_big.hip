@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
+        {
+            const WaveLds wl_ = wave_lds<GENSEC>();
+            observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wl_.cnt, wl_.cand);
+        }
     } else {
         uint64_t painted[KW_MAX] = {0, 0, 0, 0};
 #pragma unroll
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void observe_kernel_big(StepArgs a) {
     CfgRef C = *(const CfgDev CAS *)a.cfg;
     const EnvState S = *reinterpret_cast<const EnvState *>(a.state + (size_t)env * PRL_STATE_DOUBLES);
     const uint64_t GAS *painted = (const uint64_t GAS *)(a.painted + (size_t)env * a.mask_stride);      // the row where it is
-    observation_big<GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad),
-                            wave_lds<GENSEC>().cnt);
+    const WaveLds wl = wave_lds<GENSEC>();
+    observation_big<GENSEC>(P, C, S.pose, painted, lane, a.obs + (size_t)env * obs_dim_of(C.obs_mode, C.obs_grad), wl.cnt, wl.cand);
 }
 
 // PAINT_METHOD 'normal' on a large part: the finish kernel of k_cone.hip with the masks in LDS (painted, last, the union of

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void reset_obs_kernel(const PartDev *part, con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wave_lds<GENSEC>().cnt);
+        {
+            const WaveLds wl_ = wave_lds<GENSEC>();
+            observation_big<GENSEC>(P, C, pose, m, lane, out + (size_t)s * od, wl_.cnt, wl_.cand);
+        }
     } else {
         uint64_t painted[KW_MAX] = {0, 0, 0, 0};
 #pragma unroll

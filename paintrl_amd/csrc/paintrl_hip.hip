@@ -457,6 +457,46 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         }
         UP(samp_ub, ub.data(), ub.size());
         UP(word_pivot, pivot.data(), pivot.size());
+        // float copy of the samples' axis-a2 coordinate (nearest float): the observation's pass over the words that straddle
+        // the tool's horizontal line only (prl_observe.hpp section4_accumulate, pass 3a)
+        const double *y = t->sample_xyz[d.a2];
+        std::vector<float> yf((size_t)t->n_samples_pad);
+        for (int i = 0; i < t->n_samples_pad; ++i) yf[(size_t)i] = (float)y[i];
+        UP(samp_a2_f32, yf.data(), yf.size());
+        // per word: its cell row and number of valid samples, and a float interval around its a1 range (section4_big).  Cell
+        // rows must start on word boundaries and hold exactly the samples whose a2 coordinate falls into them by the device's
+        // own cell arithmetic: the observation of a large part classifies whole rows against the tool's row.
+        std::vector<int32_t> info((size_t)d.n_words, 0);
+        std::vector<float> x32((size_t)d.n_words * 2);
+        std::vector<int> row_of((size_t)d.n_words, -1);
+        for (int r = 0; r < d.sg_ny; ++r) {
+            const int b = t->sgrid_start[(size_t)r * d.sg_nx], e = t->sgrid_start[(size_t)(r + 1) * d.sg_nx];
+            if (b % 64 && e > b) return fail(PRL_E_INVALID, "sample grid row %d does not start on a 64-sample boundary", r);
+            for (int w = b / 64; w < (e + 63) / 64 && w < d.n_words; ++w) row_of[(size_t)w] = r;
+        }
+        if (d.sg_ny > 0xffff) return fail(PRL_E_UNSUPPORTED, "sample grid of %d rows", d.sg_ny);
+        for (int w = 0; w < d.n_words; ++w) {
+            const uint64_t vw = t->word_valid[w];
+            int nv = 0;
+            double lo = INFINITY, hi = -INFINITY;
+            for (int j = 0; j < 64; ++j)
+                if ((vw >> j) & 1) {
+                    ++nv;
+                    const size_t i = (size_t)w * 64 + j;
+                    lo = std::min(lo, x[i]);
+                    hi = std::max(hi, x[i]);
+                    if (row_of[(size_t)w] < 0 || cell_coord(y[i], d.sg_o2, d.sg_inv, d.sg_ny) != row_of[(size_t)w])
+                        return fail(PRL_E_INVALID, "sample %zu does not lie in the cell row its word belongs to", i);
+                }
+            info[(size_t)w] = (int32_t)(((uint32_t)nv << 16) | (uint32_t)(row_of[(size_t)w] < 0 ? 0 : row_of[(size_t)w]));
+            float flo = (float)lo, fhi = (float)hi;
+            if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+            if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+            x32[(size_t)w * 2] = flo;
+            x32[(size_t)w * 2 + 1] = fhi;
+        }
+        UP(word_info, info.data(), info.size());
+        UP(word_x32, x32.data(), x32.size());
     }
     {   // fine grid over the real samples for the lane-parallel nearest-sample query (prl_cone.hpp): ~2.6 samples a cell
         const double *x1 = t->sample_xyz[d.a1], *x2 = t->sample_xyz[d.a2];

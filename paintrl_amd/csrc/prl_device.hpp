@@ -60,6 +60,10 @@ struct PartDev {
                                   // (part_tables._sample_tie_rank; equal distances resolve to the lowest), pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
+    gfloat_p samp_a2_f32;         // [n_samples_pad]: the a2 coordinate rounded to the nearest float (derived in part_fill)
+    // large parts' observation (prl_observe.hpp section4_big; derived in part_fill):
+    gint_p word_info;             // [n_words]: the word's cell row (low 16 bits) | its number of valid samples << 16
+    gfloat_p word_x32;            // [n_words][2]: float interval holding the a1 coordinates of its valid samples (rounded outward)
     // fine sample grid for the cone-beam painter's nearest-sample queries, one query per lane (prl_cone.hpp; derived
     // in part_fill): cells of ~2.6 samples, fg_rec = the samples sorted by cell as (x, y, z, {i32 rank, i32 device pos})
     double fg_o1, fg_o2, fg_inv, fg_accept;       // fg_accept = 0.99 * cell edge
@@ -264,6 +268,11 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// a wave-uniform 64-bit value that arrived in vector registers (a load every lane made from the same address)
+__device__ __forceinline__ uint64_t uni_u64(uint64_t v) {
+    return ((uint64_t)(uint32_t)rfl((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)v);
+}
+
 __device__ __forceinline__ uint64_t bcast_u64(uint64_t v, int src) {
     src = rfl(src);
     int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
@@ -453,7 +462,7 @@ __device__ __forceinline__ void tcp_orn_norm(const double pose[3], const double 
     n[2] = bcast_d(q, 2);
 }
 
-__device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {
+__host__ __device__ __forceinline__ int cell_coord(double x, double origin, double inv, int n) {
     double f = floor((x - origin) * inv);
     f = f < -2.0 ? -2.0 : f;                       // NaN stays NaN -> comparison below sends it out of range
     f = f > (double)(n + 1) ? (double)(n + 1) : f;

@@ -118,10 +118,16 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     // below; only the rest -- the words of the row that x2 crosses -- is classified sample by sample.
     bool vline[KW_MAX] = {false, false, false, false}, above[KW_MAX] = {false, false, false, false};
     uint64_t valid[KW_MAX] = {0, 0, 0, 0}, smask[KW_MAX] = {0, 0, 0, 0};
+#ifdef PRL_OBS_YPASS
+    uint64_t ymask[KW_MAX] = {0, 0, 0, 0}, xgmask[KW_MAX] = {0, 0, 0, 0};      // pass 3a: straddles x2 only | of those: right of x1
+#endif
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * (slot0 + k);
         bool straddle = false;
+#ifdef PRL_OBS_YPASS
+        bool yonly = false, xright = false;
+#endif
         if constexpr (KW < 4) {
             // (straight-line: a lane beyond the part's words reads word 0 and carries an empty `valid`)
             const bool inw = w < P.n_words;
@@ -139,6 +145,10 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
             vline[k] = rest & (yg | yl);
             above[k] = yg;
             straddle = rest & !(yg | yl);
+#ifdef PRL_OBS_YPASS
+            yonly = straddle & (xg | xl);
+            xright = xg;
+#endif
         } else if (w < P.n_words) {                  // (four slots: the straight-line form costs the KW = 4 kernels two spilled registers)
             const f64x4 bb = ldg(reinterpret_cast<const f64x4 GAS *>(P.word_bbox), w);
             valid[k] = ldg(P.word_valid, w);
@@ -151,9 +161,19 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
                 vline[k] = yg | yl;
                 above[k] = yg;
                 straddle = !vline[k];
+#ifdef PRL_OBS_YPASS
+                yonly = straddle & (xg | xl);
+                xright = xg;
+#endif
             }
         }
+#ifdef PRL_OBS_YPASS
+        ymask[k] = ballot64(yonly);
+        xgmask[k] = ballot64(yonly & xright);
+        smask[k] = ballot64(straddle & !yonly);
+#else
         smask[k] = ballot64(straddle);
+#endif
     }
     // Pass 2: the samples of a word ascend on axis a1 (device_tables), so { xs < x1 } is a prefix and
     // { xs > x1 } a suffix of the word.  The owning lane finds the prefix length in two round trips, all its rows at
@@ -163,6 +183,9 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     // (four slots' probes at once are 64 vector registers of pivots: KW = 4 takes them two slots at a time -- one round trip
     // more for the reference's 14 482-sample sheet, and no spilled registers)
     constexpr int G = KW == 4 ? 2 : KW;
+#if defined(PRL_OBS_CUT) && PRL_OBS_CUT >= 2           // (timing builds, wrong results: the observation's passes cut away one by one)
+    if (false)
+#endif
 #pragma unroll
     for (int k0 = 0; k0 < KW; k0 += G) {
         bool any = false;
@@ -275,6 +298,65 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
     }
 #else
     uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane for the straddling words
+#if defined(PRL_OBS_CUT) && PRL_OBS_CUT >= 1
+#pragma unroll
+    for (int k = 0; k < KW; ++k) smask[k] = 0;
+#endif
+#ifdef PRL_OBS_YPASS
+    // [-DPRL_OBS_YPASS, A/B switch, OFF: bit-equal results, the door's step 36.4 against 36.1 us without it (two more lane masks
+    // per slot held across pass 2: profiles/r05_ab_log.txt); the large parts' own pass 3 (section4_big) is built this way.]
+    // Pass 3a: most of those words -- every word of the row x2 crosses but the one x1 crosses too -- lie wholly left or right
+    // of the tool (their box says which): only the a2 coordinate is needed, and a float copy of it decides unless it comes
+    // within a float's spacing of x2 (nearest-float rounding is monotone: f(ys) > the float at or above x2 implies ys > x2,
+    // f(ys) < the float at or below x2 implies ys < x2); a word with such a sample is redone in float64.  4 bytes a sample
+    // instead of 16, a dozen vector instructions a word instead of 35 -- on a 70 654-sample part the row is 65 words.
+    // The tool's own sample (bpw:1032) cannot be here: a word that does not straddle x1 holds no sample with xs == x1.
+    {
+        const float y_lo = f32_at_or_below(x2), y_hi = f32_at_or_above(x2);
+        gfloat_p yf32 = P.samp_a2_f32;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            uint64_t sm = ymask[k];
+            const uint64_t xgm = xgmask[k];
+            while (sm) {
+                WCNT(6, 1);
+                int L[4];
+                uint64_t vs[4];
+                float yf[4];
+                bool amb = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool has = sm != 0;
+                    L[q] = has ? __builtin_ctzll(sm) : 0;
+                    sm &= sm - 1;
+                    const int w2 = L[q] + 64 * (slot0 + k);
+                    yf[q] = ldg(yf32, (w2 << 6) + lane);
+                    vs[q] = has ? P.word_valid[w2] : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) amb |= (yf[q] >= y_lo) & (yf[q] <= y_hi) & __builtin_amdgcn_inverse_ballot_w64(vs[q]);
+                const bool redo = ballot64(amb) != 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bool gy = yf[q] > y_hi, ly = yf[q] < y_lo;
+                    if (redo) {                                     // (rare: a sample within a float's spacing of the line)
+                        const double yd = ldg(sy, ((L[q] + 64 * (slot0 + k)) << 6) + lane);
+                        gy = yd > x2;
+                        ly = yd < x2;
+                    }
+                    const uint64_t pw = bcast_u64(painted[k], L[q]);
+                    const bool right = (xgm >> L[q]) & 1;           // wave-uniform
+                    // bpw:1034-1043:  (>, >) -> 0, (<, >) -> 1, (<, <) -> 2, else 3
+                    const uint32_t up = right ? 0u : 8u, down = right ? 24u : 16u;
+                    const uint32_t sh = gy ? up : (ly ? down : 24u);
+                    const uint32_t one = __builtin_amdgcn_inverse_ballot_w64(vs[q]) ? (1u << sh) : 0u;
+                    tot_s += one;
+                    und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
+                }
+            }
+        }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         uint64_t sm = smask[k];
@@ -383,13 +465,173 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
     }
 }
 
+// ---------------------------------------------------------------- 4-sector rule on a LARGE part's row of words
+// A 70 654-sample part (door_rr_big, rge:116) has 1 100 mask words.  Walking them three lane slots at a time through
+// section4_accumulate cost 57 us of a 105 us step: 19 us of it the first pass (48 bytes of box / valid / painted a word, the
+// box and valid tables thrashing the L1 of sixteen envs a CU), 16 us the second (six rounds of two dependent probes for ~18
+// words), 21 us the third.  Here:
+//   1. one word per lane and slot, 20 bytes a word: a float interval of its a1 range (rounded outward: a word it places left
+//      or right of x1 is there; the others are looked at exactly below), the word's cell ROW and its number of valid samples
+//      in one int (PartDev::word_info), its painted word.  The samples of cell row r are those with cell_coord(a2) == r, and
+//      cell_coord is monotone: a row above the tool's row holds only samples with a2 > x2, a row below only a2 < x2 -- no box
+//      needed on that axis.  Pads are never painted, so the unpainted count of a whole word is valid - popcount(painted).
+//   2. the words that straddle x1 outside the tool's row (one a row) are collected in this wave's LDS list and resolved
+//      TOGETHER, one word per lane: the two probes of section4_accumulate's pass 2, once instead of once per slot group.
+//   3. the words of the tool's own row, in order, four a trip: those the float interval places left or right of x1 need the
+//      a2 coordinate only (float copy, float64 where a sample comes within a float's spacing of x2: section4_accumulate
+//      pass 3a), the one or two that straddle x1 as well are classified on both float64 coordinates.
+// Same counts as section4_accumulate bit for bit (tests/test_gpu_big_parts.py, test_gpu_full_size.py against the oracle).
+// tot / und: per-lane 4 x 16-bit fields (at most 64 x 25 a lane), as there.
+template <typename PW>
+__device__ void section4_big(PartRef P, double x1, double x2, PW painted, int lane, int *list /* LDS, 64 ints */, uint64_t &tot_l,
+                             uint64_t &und_l) {
+    gdouble_p sx = P.samp_a1, sy = P.samp_a2;
+    const float x1_lo = f32_at_or_below(x1), x1_hi = f32_at_or_above(x1);
+    const int cy2 = cell_coord(x2, P.sg_o2, P.sg_inv, P.sg_ny);
+    const bool x2ok = x2 == x2;                        // (NaN: no row is above or below, every word is looked at per sample -> sector 3)
+    const f32x2 GAS *xbox = reinterpret_cast<const f32x2 GAS *>(P.word_x32);
+    const int n_slots = (P.n_words + 63) >> 6;
+    int n_list = 0;
+    // pass 2 for the words collected so far: lane i takes entry i = word | above << 30
+    auto resolve = [&](int n) {
+        const bool act = lane < n;
+        const int e = act ? list[lane] : 0;
+        const int w = e & 0x3fffffff;
+        const bool above = (e >> 30) & 1;
+        const f64x4 GAS *pv = reinterpret_cast<const f64x4 GAS *>(P.word_pivot);
+        const f64x4 GAS *sx4 = reinterpret_cast<const f64x4 GAS *>(sx);
+        const f64x4 pa = ldg(pv, 2 * w), pb = ldg(pv, 2 * w + 1);
+        const uint64_t v = act ? ldg(P.word_valid, w) : 0, pw = painted[w];
+        const int grp = (pa.x < x1) + (pa.y < x1) + (pa.z < x1) + (pa.w < x1) + (pb.x < x1) + (pb.y < x1) + (pb.z < x1) + (pb.w < x1);
+        const int g8 = grp < 8 ? grp : 7;                            // grp = 8: the whole word lies left of x1
+        const f64x4 ga = ldg(sx4, 16 * w + 2 * g8), gb = ldg(sx4, 16 * w + 2 * g8 + 1);
+        const int in = (ga.x < x1) + (ga.y < x1) + (ga.z < x1) + (ga.w < x1) + (gb.x < x1) + (gb.y < x1) + (gb.z < x1) + (gb.w < x1);
+        const int pos = grp < 8 ? 8 * grp + in : 64;
+        const bool eq = act & (grp < 8) & ((ga.x == x1) | (ga.y == x1) | (ga.z == x1) | (ga.w == x1) | (gb.x == x1) | (gb.y == x1) |
+                                           (gb.z == x1) | (gb.w == x1));
+        int ub = pos;
+        if (ballot64(eq)) {                                          // a sample exactly on the line: the run of equals ends at samp_ub
+            const int at = (w << 6) + (pos < 64 ? pos : 63);
+            if (eq) ub = (int)ldg(P.samp_ub, at);
+        }
+        if (x1 != x1) ub = 64;                                       // NaN: nothing is greater either
+        const uint64_t lt = pos >= 64 ? ~0ull : ((1ull << pos) - 1);
+        const uint64_t ng = ub >= 64 ? ~0ull : ((1ull << ub) - 1);
+        const uint64_t u = v & ~pw;
+        const uint64_t vg = __popcll(v & ~ng), vl = __popcll(v & lt), ve = __popcll(v) - vg - vl;
+        const uint64_t ug = __popcll(u & ~ng), ul = __popcll(u & lt), ue = __popcll(u) - ug - ul;
+        // above the line  > -> 0, < -> 1, == -> 3;  below it  < -> 2, else 3  (bpw:1034-1043)
+        tot_l += above ? (vg | (vl << 16) | (ve << 48)) : ((vl << 32) | ((vg + ve) << 48));
+        und_l += above ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
+    };
+    for (int k = 0; k < n_slots; ++k) {
+        const int w = lane + 64 * k;
+        const bool inw = w < P.n_words;
+        const int wc = inw ? w : 0;
+        const uint32_t info = ldg(P.word_info, wc);
+        const f32x2 xb = ldg(xbox, wc);
+        const uint64_t pw = inw ? painted[wc] : 0;
+        const int nv = inw ? (int)(info >> 16) : 0, row = (int)(info & 0xffffu);
+        const bool xg = xb.x > x1_hi, xl = xb.y < x1_lo, yg = (row > cy2) & x2ok, yl = row < cy2;
+        const bool whole = (xg | xl) & (yg | yl);
+        const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
+        const uint64_t c = whole ? (uint64_t)nv : 0, pc = whole ? (uint64_t)__popcll(pw) : 0;
+        tot_l += c << (16 * idx);
+        und_l += (c - pc) << (16 * idx);
+        const bool vline = !whole & (nv > 0) & (yg | yl);
+        const uint64_t vm = ballot64(vline);
+        if (vm) {
+            const int np = __popcll(vm);
+            if (n_list + np > 64) {                                   // (more rows than a part has: kept for generality)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                resolve(n_list);
+                __builtin_amdgcn_wave_barrier();
+                n_list = 0;
+            }
+            if (vline)
+                list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0))] = w | (yg ? 1 << 30 : 0);
+            n_list += np;
+        }
+    }
+    if (n_list) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the lanes that found the words wrote the list, lanes 0.. read it
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        resolve(n_list);
+    }
+    // pass 3: the tool's own row of cells
+    if (cy2 >= 0 && cy2 < P.sg_ny) {
+        const int ws0 = P.sg_start[cy2 * P.sg_nx] >> 6, ws1 = (P.sg_start[(cy2 + 1) * P.sg_nx] + 63) >> 6;
+        const float y_lo = f32_at_or_below(x2), y_hi = f32_at_or_above(x2);
+        gfloat_p yf32 = P.samp_a2_f32;
+        uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane; widened every 64 words
+        int since = 0;
+        for (int w0 = ws0; w0 < ws1; w0 += 4) {
+            uint64_t vs[4], pws[4];
+            float yf[4];
+            bool side[4], right[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = w0 + q < ws1 ? w0 + q : ws1 - 1;
+                const f32x2 xb = reinterpret_cast<const f32x2 CAS *>((uint64_t)P.word_x32)[w];      // (wave-uniform: a scalar load)
+                right[q] = xb.x > x1_hi;
+                side[q] = right[q] | (xb.y < x1_lo);
+                yf[q] = ldg(yf32, (w << 6) + lane);
+                vs[q] = w0 + q < ws1 ? P.word_valid[w] : 0;
+                pws[q] = uni_u64(painted[w]);                        // (every lane the same word: one request)
+            }
+            bool amb = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) amb |= side[q] & (yf[q] >= y_lo) & (yf[q] <= y_hi) & __builtin_amdgcn_inverse_ballot_w64(vs[q]);
+            const bool redo = ballot64(amb) != 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int w = w0 + q < ws1 ? w0 + q : ws1 - 1;
+                const bool cnt0 = __builtin_amdgcn_inverse_ballot_w64(vs[q]);
+                uint32_t sh;
+                bool cnt = cnt0;
+                if (side[q]) {                                        // wave-uniform: left or right of the tool as a whole
+                    bool gy = yf[q] > y_hi, ly = yf[q] < y_lo;
+                    if (redo) {                                       // (rare: a sample within a float's spacing of the line)
+                        const double yd = ldg(sy, (w << 6) + lane);
+                        gy = yd > x2;
+                        ly = yd < x2;
+                    }
+                    const uint32_t up = right[q] ? 0u : 8u, down = right[q] ? 24u : 16u;
+                    sh = gy ? up : (ly ? down : 24u);
+                } else {                                              // straddles both lines: both coordinates, float64
+                    const double xs = ldg(sx, (w << 6) + lane), ys = ldg(sy, (w << 6) + lane);
+                    cnt = cnt0 & !((xs == x1) & (ys == x2));          // bpw:1032: the tool's own sample is skipped
+                    const bool gy = ys > x2, lx = xs < x1;
+                    sh = ((xs > x1) & gy) ? 0u : ((lx & gy) ? 8u : ((lx & (ys < x2)) ? 16u : 24u));
+                }
+                const uint32_t one = cnt ? (1u << sh) : 0u;
+                tot_s += one;
+                und_s += __builtin_amdgcn_inverse_ballot_w64(pws[q]) ? 0u : one;
+            }
+            since += 4;
+            if (since >= 252 || w0 + 4 >= ws1) {                      // the 8-bit fields hold 255: widen into the 16-bit ones
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
+                    und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
+                }
+                tot_s = und_s = 0;
+                since = 0;
+            }
+        }
+    }
+}
+
 // The same observation for a part with more than 16 384 samples: the painted mask is a row of n_words words -- an LDS copy
 // (`const uint64_t *`) or the env's row in HBM (`uint64_t GAS *`: coalesced 8-byte loads, 8.9 KB per env-step at 71 000
 // samples) -- walked 64 words per lane slot; counts can exceed 16 bits, so the per-lane 16-bit fields (at most 64 x 25 per
 // lane) are split into 32-bit halves before the wave sums.
 template <bool GENSEC, typename PW>
 __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW painted, int lane,
-                                double *out, int *cnt_lds) {
+                                double *out, int *cnt_lds, int *list_lds /* this wave's 64-int row (WaveLds::cand) */) {
     double x1, x2, np0, np1;
     normalized_pose(P, C, pose, x1, x2, np0, np1);
     const int mode = C.obs_mode;
@@ -443,7 +685,7 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW pa
         return;
     } else {
         uint64_t tot_l = 0, und_l = 0;
-        // three lane slots a trip, like the door's own kernel (KW = 3): their box, pivot and group probes travel together
+#ifdef PRL_BIG_OBS_BY_SLOTS                          // (A/B and parity switch: the small parts' passes, three lane slots a trip)
         constexpr int G = 3;
         for (int k = 0; k < n_slots; k += G) {
             uint64_t pk[KW_MAX] = {0, 0, 0, 0};
@@ -454,6 +696,9 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW pa
             }
             section4_accumulate<G>(P, x1, x2, pk, k, lane, tot_l, und_l);
         }
+#else
+        section4_big(P, x1, x2, painted, lane, list_lds, tot_l, und_l);
+#endif
         uint64_t t01 = (tot_l & 0xffffull) | ((tot_l & 0xffff0000ull) << 16), t23 = ((tot_l >> 32) & 0xffffull) | ((tot_l >> 48) << 32);
         uint64_t u01 = (und_l & 0xffffull) | ((und_l & 0xffff0000ull) << 16), u23 = ((und_l >> 32) & 0xffffull) | ((und_l >> 48) << 32);
         t01 = wave_sum_u64(t01);

@@ -7,7 +7,8 @@
 
 Loads each library into its own ctypes handle, then alternates timed runs (same GPU, same process, one HIP event
 pair around 300 back-to-back launches) so that device-to-device and DVFS differences cancel.  Builds nothing.
-PRL_ENVS / PRL_OBS select the batch size and the observation mode.
+PRL_ENVS / PRL_OBS select the batch size and the observation mode, PRL_PART / PRL_TEX the synthetic part and its texture
+edge (default: the door on 240 x 240; `PRL_PART=door_rr_big PRL_TEX=652` = the 70 654-sample class of the large-part kernels).
 """
 import os
 import sys
@@ -26,8 +27,12 @@ def main():
     libs = [os.path.abspath(a) for a in sys.argv[1:]]
     n = int(os.environ.get('PRL_ENVS', '4096'))
     obs = os.environ.get('PRL_OBS', 'section')
-    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
-    dt = DeviceTables(tables)
+    part = os.environ.get('PRL_PART', 'door_test')
+    tex = int(os.environ.get('PRL_TEX', '0')) or synth_parts.TEXTURES[part][0][0]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(part), tex_size=(tex, tex), name=part)
+    other = part != 'door_test' or tex != 240
+    dt = DeviceTables(tables, start_points=part_tables.start_points(tables, 'all') if other else None)
+    mpp = int(0.95 * tables.sample_pos.shape[0]) if other else 9148
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (400, n), generator=gen, device='cuda', dtype=torch.int32)
@@ -35,7 +40,7 @@ def main():
     for path in libs:
         hb.LIBRARY = path
         _lib._lib = None
-        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, obs_mode=obs, overlap_penalty=obs == 'grid')
+        env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, obs_mode=obs, overlap_penalty=obs == 'grid', max_possible_point=mpp)
         env.reset()
         for k in range(100):
             env.step_raw(acts[k])

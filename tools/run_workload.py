@@ -23,10 +23,15 @@ def main():
     ap.add_argument('--envs', type=int, default=4096)
     ap.add_argument('--paint-method', default='fast', choices=['fast', 'normal'])
     ap.add_argument('--fragment', action='store_true', help='the steps as ONE launch of the persistent fragment kernel (given actions)')
+    ap.add_argument('--part', default='door_test')
+    ap.add_argument('--tex', type=int, default=0)
     a = ap.parse_args()
-    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
-    env = BatchedPaintEnv(DeviceTables(tables), a.envs, auto_reset=True, seed=5678, obs_mode=a.obs_mode,
-                          overlap_penalty=a.obs_mode == 'grid', paint_method=a.paint_method)
+    tex = a.tex or synth_parts.TEXTURES[a.part][0][0]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(a.part), tex_size=(tex, tex), name=a.part)
+    other = a.part != 'door_test' or tex != 240
+    env = BatchedPaintEnv(DeviceTables(tables, start_points=part_tables.start_points(tables, 'all') if other else None), a.envs,
+                          auto_reset=True, seed=5678, obs_mode=a.obs_mode, overlap_penalty=a.obs_mode == 'grid',
+                          paint_method=a.paint_method, max_possible_point=int(0.95 * tables.sample_pos.shape[0]) if other else 9148)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (a.steps, a.envs), generator=gen, device='cuda', dtype=torch.int32)
