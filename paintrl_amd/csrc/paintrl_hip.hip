@@ -236,15 +236,22 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         UP(kd_points, t->kd_points, t->n_kd_points);
         {   // the leaves' vertex records in tree order (derived): a leaf scan reads its points' x y z | {vertex, 0} in ONE round
             // trip instead of two (the point's vertex id, then that vertex's record); a parked row (-1) keeps id -1
+            std::vector<int32_t> leaf_of((size_t)t->n_kd_points, 0);         // the leaf (node index) each tree-order point belongs to
+            for (int i = 0; i < d.n_kd_nodes; ++i) {
+                const int32_t *nd = t->kd_node + 4 * (size_t)i;
+                if (nd[0] < 0)
+                    for (int p = nd[1]; p < nd[2]; ++p) leaf_of[(size_t)p] = i;
+            }
             std::vector<double> kr((size_t)t->n_kd_points * 4, 0.0);
             for (int i = 0; i < t->n_kd_points; ++i) {
                 const int v = t->kd_points[i];
                 if (v >= 0)
                     for (int k = 0; k < 3; ++k) kr[(size_t)i * 4 + k] = t->vertex_xyz[k][v];
-                const int32_t pair[2] = {v, 0};
+                const int32_t pair[2] = {v, leaf_of[(size_t)i]};
                 std::memcpy(&kr[(size_t)i * 4 + 3], pair, sizeof pair);
             }
             UP(kd_rec, kr.data(), kr.size());
+            d.n_kd_points = t->n_kd_points;
         }
         for (int k = 0; k < 6; ++k) d.kd_box[k] = t->kd_box[k];
     }

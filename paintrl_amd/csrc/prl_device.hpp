@@ -106,7 +106,8 @@ struct PartDev {
     gint_p kd_node;               // [n][4] split dim | lesser or first point | greater or end | 0
     gdouble_p kd_split;
     gint_p kd_points;
-    gdouble_p kd_rec;             // [n_kd_points][4]: x y z | {i32 vertex or -1, 0} of the leaves' points in tree order (derived in part_fill)
+    gdouble_p kd_rec;             // [n_kd_points][4]: x y z | {i32 vertex or -1, i32 the leaf's node} of the leaves' points in tree order (derived in part_fill)
+    int n_kd_points;
     double kd_box[6];
     int n_triangles;
     gdouble_p tri_rec;            // [n_triangles][TRI_REC]: the 16 doubles of the host table + derived tail (part_fill)
@@ -209,7 +210,9 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
 constexpr int KD_HEAP = 64;         // queued cells of the stale kd-tree walk (5 doubles each)
 constexpr int KD_LDS_NODES = 64;    // trees of at most this many nodes are walked from a copy in LDS (kd_stage, prl_search.hpp)
-constexpr int KD_ROW = KD_HEAP * 5 + 3 * KD_LDS_NODES;      // doubles per wave: the queue | nodes as int4 | split values
+constexpr int KD_ROW = KD_HEAP * 5 + 5 * KD_LDS_NODES;      // doubles per wave: the queue | nodes as int4 | split values | per leaf: smallest
+                                                            // distance of the query, first point reaching it (kd_leaf_results)
+constexpr int KD_STAGE_POINTS = 512;                        // trees of at most this many points have their leaves' results staged per query
 
 // Convex collision sets: the records of ONE facet's vertex neighbourhood (the facet itself in lane 0, PartDev::col_nbr) staged
 // in this wave's LDS -- the "LDS-staged triangle tile" of the ray (prl_ray.hpp).  A sub-shot's ray ends on the facet the

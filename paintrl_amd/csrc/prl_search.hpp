@@ -187,10 +187,64 @@ __device__ __forceinline__ void kd_stage(PartRef P, double *heap, int lane) {
     }
 }
 
+// Round 5: every leaf's result for THIS query at once.  The walk visits two to six leaves, and each visit was a dependent
+// global round trip (the leaf's point records) and two wave-wide reductions (smallest distance, first lane reaching it) in
+// the middle of a serial chain -- 5 us a query on the coarse sheet (the reference's square.urdf class: 17-33 nodes, a few
+// hundred points).  The distance of the query to EVERY point of the tree is one round trip with all loads in flight
+// (ceil(points / 64) records a lane); each leaf's minimum is an LDS atomic minimum on the distance's bit pattern (squared
+// distances are >= +0: they order like unsigned integers), the first point reaching it a second one on (point << 32 | vertex).
+// The walk then reads a leaf's result from LDS: same visiting order, same strict comparisons, same answer.
+// lmin[node], lfirst[node]: this wave's rows behind the staged tree (KD_ROW).
+__device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], int lane, unsigned long long *lmin, unsigned long long *lfirst) {
+    if (lane < P.n_kd_nodes) {
+        lmin[lane] = 0x7ff0000000000000ull;          // +inf
+        lfirst[lane] = ~0ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.kd_rec);
+    // (two passes over the records instead of one with the distances kept: eight trips' worth of them were 32 vector registers,
+    // and the second read comes from L1)
+    auto measure = [&](int p, int &v, int &leaf) -> unsigned long long {
+        const bool in = p < P.n_kd_points;
+        const f64x2 a = ldg(r, 2 * (in ? p : 0)), b = ldg(r, 2 * (in ? p : 0) + 1);
+        v = in ? __double2loint(b.y) : -1;                           // -1: a row parked at (10, 10, 10)
+        leaf = __double2hiint(b.y);
+        const double d0 = a.x - pt[0], d1 = a.y - pt[1], d2 = b.x - pt[2];
+        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
+        return (unsigned long long)__double_as_longlong(dd + 0.0);
+    };
+    for (int p0 = 0; p0 < P.n_kd_points; p0 += 64) {
+        int v, leaf;
+        const unsigned long long bits = measure(p0 + lane, v, leaf);
+        if (v >= 0) atomicMin(&lmin[leaf], bits);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int p0 = 0; p0 < P.n_kd_points; p0 += 64) {
+        int v, leaf;
+        const unsigned long long bits = measure(p0 + lane, v, leaf);
+        if (v >= 0 && bits == lmin[leaf]) atomicMin(&lfirst[leaf], ((unsigned long long)(uint32_t)(p0 + lane) << 32) | (uint32_t)v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap, bool has_copy) {
     const bool staged = has_copy && P.n_kd_nodes <= KD_LDS_NODES;           // (kd_stage ran in shots_begin)
     const i32x4 *lds_node = reinterpret_cast<const i32x4 *>(heap + KD_HEAP * 5);
     const double *lds_split = heap + KD_HEAP * 5 + 2 * KD_LDS_NODES;
+    unsigned long long *lmin = reinterpret_cast<unsigned long long *>(heap + KD_HEAP * 5 + 3 * KD_LDS_NODES);
+    unsigned long long *lfirst = lmin + KD_LDS_NODES;
+#ifndef PRL_KD_SCAN_LEAVES                           // (A/B and parity switch: the leaves scanned where the walk visits them)
+    const bool leaves_ready = staged && P.n_kd_points <= KD_STAGE_POINTS;
+#else
+    const bool leaves_ready = false;
+#endif
+    if (leaves_ready) kd_leaf_results(P, pt, lane, lmin, lfirst);
     double side0, side1, side2;
     {
         const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
@@ -209,6 +263,13 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
         const i32x4 nd = staged ? lds_node[node] : ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), node);
         const int nd0 = rfl(nd.x), nd1 = rfl(nd.y), nd2 = rfl(nd.z);
         if (nd0 < 0) {                                              // leaf: points nd1 .. nd2 - 1
+            if (leaves_ready) {                                     // its smallest distance and the first point (tree order) reaching it
+                const double dmin = __longlong_as_double((long long)lmin[node]);
+                if (dmin < dub) {
+                    dub = dmin;
+                    best = rfl((int)(uint32_t)lfirst[node]);
+                }
+            } else
             for (int i0 = nd1; i0 < nd2; i0 += 64) {
                 const int i = i0 + lane;
                 int v = -1;                                         // -1: a row parked at (10, 10, 10)
