@@ -21,6 +21,7 @@
 // The extra HBM traffic (10 MB of hit lists written and read per 4 096-env step) is 3 us at HBM speed.
 #include "prl_all.hpp"
 #include "prl_cone.hpp"
+#include "prl_pair.hpp"
 
 namespace {
 
@@ -150,6 +151,145 @@ __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     if (lane == 0) {
         a.cone_aux[2 * (size_t)env] = new_angle;
         a.cone_aux[2 * (size_t)env + 1] = __hiloint2double(X.facet_hint, counter_before);
+    }
+}
+
+// The tool path of ONE env by the whole wave (the body of cone_path_kernel): also what the pair kernel below falls back to.
+template <bool KD>
+__device__ void cone_path_env(const StepArgs CAS &a, int env, int lane, const WaveLds &wl) {
+    const int part_id = a.env_part ? a.env_part[env] : 0;
+    PartRef P = *(const PartDev CAS *)(a.parts + part_id);
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
+    double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+    EnvState S;
+    load_state_motion(state_rec, S);
+    double delta1, delta2, new_angle;
+    decode_action(C, a.actions, env, delta1, delta2, new_angle);
+    const int counter_before = S.terminate_counter;
+    ShotCtx X;
+    shots_begin<KD>(P, S, delta1, delta2, X, lane, wl);
+    double *shots = a.cone_shots + (size_t)env * PAINT_PER_ACTION * 8;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        double center[3], quat[4];
+        sub_shot<KD>(P, lane, S, X, wl, center, quat);
+        double v = __hiloint2double(0, X.facet_hint);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v = lane == k ? X.cur_pose[k] : v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v = lane == 3 + k ? quat[k] : v;
+        if (lane < 8) shots[8 * shot + lane] = v;
+    }
+    shots_end(P, S, X);
+    {
+        const double *src = reinterpret_cast<const double *>(&S);
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v = lane == k ? src[k] : v;
+        v = lane == 10 ? src[10] : v;
+        v = lane == 11 ? src[11] : v;
+        if (lane < 7 || lane == 10 || lane == 11) state_rec[lane] = v;
+    }
+    if (lane == 0) {
+        a.cone_aux[2 * (size_t)env] = new_angle;
+        a.cone_aux[2 * (size_t)env + 1] = __hiloint2double(X.facet_hint, counter_before);
+    }
+}
+
+// [-DPRL_CONE_PATH_PAIRS: round-5 experiment, prl_pair.hpp]  Two envs per wave: lanes 0-31 walk env 2 j, lanes 32-63 env 2 j + 1.
+template <bool KD, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void cone_path_pair_kernel(StepArgs) {
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const int env0 = rfl(2 * (blockIdx.x * WAVES + (threadIdx.x >> 6)));
+    if (blockIdx.x == 0) {                                                 // the work lists of this step start empty
+        if (threadIdx.x == 0) a.cone_work[0] = 0;
+        for (int i = threadIdx.x; i < 2 * WORK_LISTS; i += 64 * WAVES) far_counters(a)[16 * i] = 0;      // (far, then ray counters)
+    }
+    if (env0 >= a.n_envs) return;
+    const WaveLds wl = wave_lds<false, KD, 0, WAVES>();
+    const int pa = a.env_part ? a.env_part[env0] : 0, pb = (a.env_part && env0 + 1 < a.n_envs) ? a.env_part[env0 + 1] : pa;
+    PartRef P = *(const PartDev CAS *)(a.parts + pa);
+    const bool pairs = env0 + 1 < a.n_envs && pa == pb && P.col_convex && P.nbr_width <= 32 && P.adj_width <= 32;
+    if (!pairs) {                                                          // (a last odd env, two parts in one wave, wide tables)
+        cone_path_env<KD>(a, env0, lane, wl);
+        if (env0 + 1 < a.n_envs) cone_path_env<KD>(a, env0 + 1, lane, wl);
+        return;
+    }
+    CfgRef C = *(const CfgDev CAS *)a.cfg;
+    const bool upper = lane >= 32;
+    const int l32 = lane & 31, env = env0 + (upper ? 1 : 0);
+    // both envs' entry state by the one-env code (scalar loads, wave-uniform arithmetic), then one value per lane
+    PairCtx X;
+    double new_angle_l;
+    int counter_before_l, step_pair_l;                                      // (record double 11 = {last_on_part, step_counter}: the counter goes back as read)
+    uint32_t episode_l;
+    double quat_l[4];
+    {
+        EnvState SA, SB;
+        load_state_motion(a.state + (size_t)env0 * PRL_STATE_DOUBLES, SA);
+        load_state_motion(a.state + (size_t)(env0 + 1) * PRL_STATE_DOUBLES, SB);
+        double d1a, d2a, naa, d1b, d2b, nab;
+        decode_action(C, a.actions, env0, d1a, d2a, naa);
+        decode_action(C, a.actions, env0 + 1, d1b, d2b, nab);
+        double na[3], nb[3];
+        tcp_orn_norm(SA.pose, SA.quat, na);
+        tcp_orn_norm(SB.pose, SB.quat, nb);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            X.cur_pose[k] = upper ? SB.pose[k] : SA.pose[k];
+            X.cur_norm[k] = upper ? nb[k] : na[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) quat_l[k] = upper ? SB.quat[k] : SA.quat[k];
+        X.d1 = upper ? uni_d(d1b) : uni_d(d1a);
+        X.d2 = upper ? uni_d(d2b) : uni_d(d2a);
+        new_angle_l = upper ? uni_d(nab) : uni_d(naa);
+        const double delta_2 = X.d2 * P.lwr;                              // (prl_step.hpp shots_begin)
+        X.dvec[0] = P.a1 == 0 ? X.d1 : (P.a2 == 0 ? delta_2 : -0.0);
+        X.dvec[1] = P.a1 == 1 ? X.d1 : (P.a2 == 1 ? delta_2 : -0.0);
+        X.dvec[2] = P.a1 == 2 ? X.d1 : (P.a2 == 2 ? delta_2 : -0.0);
+        const int ha = (SA.facet_hint >= 0 && SA.facet_hint < P.n_col_pad) ? SA.facet_hint : -1;
+        const int hb = (SB.facet_hint >= 0 && SB.facet_hint < P.n_col_pad) ? SB.facet_hint : -1;
+        X.facet_hint = upper ? hb : ha;
+        X.last_tri = -1;
+        X.last_on_part = upper ? SB.last_on_part : SA.last_on_part;
+        X.terminate_counter = upper ? SB.terminate_counter : SA.terminate_counter;
+        X.terminate = upper ? SB.terminate : SA.terminate;
+        counter_before_l = X.terminate_counter;
+        step_pair_l = upper ? SB.step_counter : SA.step_counter;
+        episode_l = upper ? SB.episode : SA.episode;
+        if constexpr (KD)
+            if (wl.kd_staged) kd_stage(P, wl.kd_heap, lane);
+    }
+    double *shots = a.cone_shots + (size_t)env * PAINT_PER_ACTION * 8;
+    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+        pair_sub_shot<KD>(P, lane, X, wl, quat_l);
+        // lanes 0..7 of each half write their env's record: pos, quat, {facet hint, 0}
+        double v = __hiloint2double(0, X.facet_hint);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v = l32 == k ? X.cur_pose[k] : v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v = l32 == 3 + k ? quat_l[k] : v;
+        if (l32 < 8) shots[8 * shot + l32] = v;
+    }
+    // the tool quaternion of the final pose (prl_step.hpp shots_end): quat_l holds it -- the hooked triangle's record tail, or
+    // get_pose_orn of the normal after a miss, the same arithmetic either way.  The motion part of the record goes back:
+    // doubles 0..6 and the int pairs at 10, 11
+    {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v = l32 == k ? X.cur_pose[k] : v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v = l32 == 3 + k ? quat_l[k] : v;
+        v = l32 == 10 ? __hiloint2double(X.terminate_counter, X.terminate) : v;
+        v = l32 == 11 ? __hiloint2double(step_pair_l, X.last_on_part) : v;
+        (void)episode_l;
+        double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
+        if (l32 < 7 || l32 == 10 || l32 == 11) state_rec[l32] = v;
+    }
+    if (l32 == 0) {
+        a.cone_aux[2 * (size_t)env] = new_angle_l;
+        a.cone_aux[2 * (size_t)env + 1] = __hiloint2double(X.facet_hint, counter_before_l);
     }
 }
 
@@ -399,6 +539,16 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
 PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifdef PRL_CONE_PATH_PAIRS
+    {
+        constexpr int W = PRL_CONE_PATH_PAIRS;                             // waves (= env pairs) per workgroup
+        const dim3 grid(((a.n_envs + 1) / 2 + W - 1) / W), block(64 * W);
+        if (kd) hipLaunchKernelGGL((cone_path_pair_kernel<true, W>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((cone_path_pair_kernel<false, W>), grid, block, 0, s, a);
+        (void)wide;
+        return (int)hipGetLastError();
+    }
+#endif
     if (wide) {
         const dim3 grid((a.n_envs + STEP_WAVES_WIDE - 1) / STEP_WAVES_WIDE), block(64 * STEP_WAVES_WIDE);
         if (kd) hipLaunchKernelGGL((cone_path_kernel<true, STEP_WAVES_WIDE>), grid, block, 0, s, a);
