@@ -271,6 +271,13 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// reg[lane `slot`] = val for wave-uniform val and slot (v_writelane_b32: the lane select goes through M0 -- with the value in a
+// scalar register too the instruction would read two of them, one more than the constant bus of this family allows)
+__device__ __forceinline__ int writelane_i(int val, int slot, int reg) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(val), "s"(slot) : "m0");
+    return reg;
+}
+
 // a wave-uniform 64-bit value that arrived in vector registers (a load every lane made from the same address)
 __device__ __forceinline__ uint64_t uni_u64(uint64_t v) {
     return ((uint64_t)(uint32_t)rfl((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)v);

@@ -407,6 +407,9 @@ __device__ __forceinline__ void section_pose_tail(int mode, int g, double np0, d
     }
 }
 
+template <typename PW>
+__device__ void section4_big(PartRef P, double x1, double x2, PW painted, int lane, int *list, uint64_t &tot_l, uint64_t &und_l);
+
 // GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
 // its registers or code.  Masks in registers (parts with at most 16 384 samples).
 template <int KW, bool GENSEC>
@@ -453,7 +456,21 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         return;
     } else {
         uint64_t tot_l = 0, und_l = 0;             // 4 x 16-bit counters per lane (total / unpainted per sector)
+#ifdef PRL_OBS_ROW                                  // (A/B switch: the large parts' three passes on an LDS copy of the painted row)
+        {
+            __shared__ uint64_t s_obsrow[MAX_WAVES_PER_WG][64 * KW];
+            __shared__ int s_obslist[MAX_WAVES_PER_WG][64];
+            const int wv = rfl((int)(threadIdx.x >> 6));
+#pragma unroll
+            for (int k = 0; k < KW; ++k) s_obsrow[wv][lane + 64 * k] = painted[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            section4_big(P, x1, x2, static_cast<const uint64_t *>(s_obsrow[wv]), lane, s_obslist[wv], tot_l, und_l);
+        }
+#else
         section4_accumulate<KW>(P, x1, x2, painted, 0, lane, tot_l, und_l);
+#endif
         tot_l = wave_sum_u64(tot_l);
         und_l = wave_sum_u64(und_l);
         if (lane < 4) {                             // the four ratios in four lanes: one division sequence

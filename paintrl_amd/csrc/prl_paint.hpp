@@ -316,7 +316,12 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
             if (re[r] <= rb[r]) continue;
             const int wlast = (re[r] - 1) >> 6;
             const int wfirst = (rb[r] >> 6) > done_w ? (rb[r] >> 6) : done_w + 1;
-            if constexpr (Words::HBM) {
+#ifdef PRL_PAINT_PREPASS                              // (A/B switch: the word-box pre-pass for the register-resident masks too)
+            constexpr bool prepass = true;
+#else
+            constexpr bool prepass = Words::HBM;
+#endif
+            if constexpr (prepass) {
                 // Large parts: a row's stretch of the cell block is dozens of words (70 654 samples: ~17 a row, ~70 a step) of
                 // which the five balls reach a third.  One word per lane first: a word whose box (principal plane) lies more
                 // than the radius beyond the centres' own box holds no sample within the radius of any centre -- |dx| > r gives

@@ -259,6 +259,76 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
     }
     double mind = (side0 + side1) + side2, dub = INFINITY;
     int node = 0, best = -1, n_heap = 0;
+#ifdef PRL_KD_WALK_REGS                              // (A/B switch, OFF: measured slower, profiles/r05_ab_log.txt)
+    if (leaves_ready) {
+        // The walk itself without a memory access: the staged tree has at most 64 nodes, so lane i holds node i -- split
+        // dimension, children, split value, and the leaf's result for this query -- and queue slot i; a node is read with
+        // v_readlane at a scalar index, a queue entry written with v_writelane.  Same visiting order, same comparisons, the
+        // queue in the same list order as oracle/paint_oracle.c stale_kd_query: equal results -- and 60.8 us a step against 57.5
+        // on the LDS copies: the walk's LDS round trips are covered by the SIMD's other waves, while every lane read / write here
+        // is an instruction (two per double, plus the moves of compare results to scalar registers), and the step is bound by
+        // instruction issue.
+        const int li = lane < P.n_kd_nodes ? lane : 0;
+        const i32x4 ndv = lds_node[li];
+        const double spv = lds_split[li];
+        const double lminv = __longlong_as_double((long long)lmin[li]);
+        const int lvert = (int)(uint32_t)lfirst[li];
+        double q_mind = INFINITY, q_s0 = 0, q_s1 = 0, q_s2 = 0;
+        int q_node = 0;
+        auto put_d = [&](double &reg, double val, int slot) {       // reg[slot] = val (val, slot wave-uniform)
+            const int lo = writelane_i(rfl(__double2loint(val)), slot, __double2loint(reg));
+            const int hi = writelane_i(rfl(__double2hiint(val)), slot, __double2hiint(reg));
+            reg = __hiloint2double(hi, lo);
+        };
+        for (int guard = 0; guard < 4 * KD_LDS_NODES; ++guard) {
+            node = rfl(node);
+            const int nd0 = __builtin_amdgcn_readlane(ndv.x, node);
+            if (nd0 < 0) {                                          // leaf: its smallest distance, the first point reaching it
+                const double dmin = bcast_d(lminv, node);
+                if (rfl(dmin < dub)) {
+                    dub = dmin;
+                    best = __builtin_amdgcn_readlane(lvert, node);
+                }
+                if (n_heap == 0) break;
+                const double key = lane < n_heap ? q_mind : INFINITY;
+                const double kmin = wave_min_d(key);
+                const int m = rfl(__builtin_ctzll(ballot64(key == kmin)));
+                mind = bcast_d(q_mind, m);
+                side0 = bcast_d(q_s0, m);
+                side1 = bcast_d(q_s1, m);
+                side2 = bcast_d(q_s2, m);
+                node = __builtin_amdgcn_readlane(q_node, m);
+                --n_heap;
+                if (m != n_heap) {                                  // the last entry fills the hole
+                    put_d(q_mind, bcast_d(q_mind, n_heap), m);
+                    put_d(q_s0, bcast_d(q_s0, n_heap), m);
+                    put_d(q_s1, bcast_d(q_s1, n_heap), m);
+                    put_d(q_s2, bcast_d(q_s2, n_heap), m);
+                    q_node = writelane_i(__builtin_amdgcn_readlane(q_node, n_heap), m, q_node);
+                }
+            } else {
+                if (rfl(mind > dub)) break;
+                const int nd1 = __builtin_amdgcn_readlane(ndv.y, node), nd2 = __builtin_amdgcn_readlane(ndv.z, node);
+                const double sp = bcast_d(spv, node);
+                const double xs = sel3(pt[0], pt[1], pt[2], nd0), old = sel3(side0, side1, side2, nd0);
+                const bool low = rfl(xs < sp);
+                const int near = low ? nd1 : nd2, far = low ? nd2 : nd1;
+                const double tmp = sp - xs, nw = tmp * tmp;
+                const double far_mind = mind + (nw - old);
+                if (rfl(far_mind <= dub) && n_heap < KD_HEAP) {
+                    put_d(q_mind, far_mind, n_heap);
+                    put_d(q_s0, nd0 == 0 ? nw : side0, n_heap);
+                    put_d(q_s1, nd0 == 1 ? nw : side1, n_heap);
+                    put_d(q_s2, nd0 == 2 ? nw : side2, n_heap);
+                    q_node = writelane_i(far, n_heap, q_node);
+                    ++n_heap;
+                }
+                node = near;
+            }
+        }
+        return best;
+    }
+#endif
     for (int guard = 0; guard < 4 * 4096; ++guard) {                // every path ends far earlier; a bound all the same
         const i32x4 nd = staged ? lds_node[node] : ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), node);
         const int nd0 = rfl(nd.x), nd1 = rfl(nd.y), nd2 = rfl(nd.z);
