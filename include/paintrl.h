@@ -190,6 +190,11 @@ int prl_batch_observe(PrlBatch *batch, double *obs, void *stream);
 /* Replaces get_job_status / get_texture_image style read-back (bpw:727-738): coverage bits in
  * device sample order, u64[N][mask_stride]. */
 int prl_batch_get_mask(PrlBatch *batch, uint64_t *painted, void *stream);
+/* The previous shot's affected set (Part._last_painted_pixels, bpw:483, 575-576: what OVERLAP_PENALTY's pixel counter is
+ * measured against) as bits in device sample order, u64[N][mask_stride], device.  nonzero_words (device, or NULL):
+ * u64[N][*nonzero_stride], the library's own index of that row -- bit w & 63 of word w >> 6 is set for every word w of the row
+ * that may be non-zero (a superset; kernels read and clear only those) -- for tests; nonzero_stride: host int, or NULL. */
+int prl_batch_get_last_mask(PrlBatch *batch, uint64_t *last, uint64_t *nonzero_words, int32_t *nonzero_stride, void *stream);
 /* COLOR_MODE 'HSI' only: the thickness byte of every sample, u8[N][64 * mask_stride] in device sample order
  * (what bpw texels[get_texel(i, j)] holds for the front samples). */
 int prl_batch_get_thickness(PrlBatch *batch, uint8_t *thick, void *stream);

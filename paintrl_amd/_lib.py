@@ -85,6 +85,7 @@ SYMBOLS = {
     'prl_rollout_fragment': (C.c_int, [_vp, C.POINTER(PrlPolicyWeights), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, C.c_uint64, _vp]),
     'prl_batch_get_mask': (C.c_int, [_vp, _vp, _vp]),
+    'prl_batch_get_last_mask': (C.c_int, [_vp, _vp, _vp, _ip, _vp]),
     'prl_batch_get_state': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_thickness': (C.c_int, [_vp, _vp, _vp]),
     'prl_batch_get_returns': (C.c_int, [_vp, _vp, _vp]),

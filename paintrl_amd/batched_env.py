@@ -202,6 +202,18 @@ class BatchedPaintEnv(object):
             _lib.check(self.lib.prl_batch_get_mask(self._batch, self._ptr(out), self._stream()), 'prl_batch_get_mask')
         return out
 
+    def last_shot_words(self):
+        """(last, nonzero): the previous shot's affected set as int64 (N, mask_stride) words in device sample order
+        (Part._last_painted_pixels, bpw:483) and the library's index of its non-zero words, int64 (N, nz_stride)."""
+        torch = _torch()
+        out = torch.zeros((self.n_envs, self.mask_stride), dtype=torch.int64, device=self.device)
+        nz = torch.zeros((self.n_envs, max(4, (self.mask_stride + 63) // 64)), dtype=torch.int64, device=self.device)
+        stride = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.prl_batch_get_last_mask(self._batch, self._ptr(out), self._ptr(nz), C.byref(stride), self._stream()),
+                       'prl_batch_get_last_mask')
+        return out, nz.reshape(-1)[:self.n_envs * stride.value].reshape(self.n_envs, stride.value)
+
     def painted_bits(self, env=0):
         """bool[P] coverage of one env in canonical sample order (PartTables.sample_pix order)."""
         words = self.painted_words()[env].cpu().numpy().view(np.uint64)

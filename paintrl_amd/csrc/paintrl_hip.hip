@@ -1093,6 +1093,18 @@ int prl_batch_get_mask(PrlBatch *b, uint64_t *painted, void *stream) {
     return PRL_OK;
 }
 
+int prl_batch_get_last_mask(PrlBatch *b, uint64_t *last, uint64_t *nonzero_words, int32_t *nonzero_stride, void *stream) {
+    if (!b || !last) return fail(PRL_E_INVALID, "null argument");
+    const size_t n = (size_t)b->n_envs * b->mask_stride;
+    hipLaunchKernelGGL(copy_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), b->last, last, n);
+    HIP_TRY(hipGetLastError());
+    if (nonzero_words)
+        HIP_TRY(hipMemcpyAsync(nonzero_words, b->last_nz, sizeof(uint64_t) * (size_t)b->n_envs * b->nz_stride, hipMemcpyDeviceToDevice,
+                               static_cast<hipStream_t>(stream)));
+    if (nonzero_stride) *nonzero_stride = b->nz_stride;
+    return PRL_OK;
+}
+
 int prl_batch_get_thickness(PrlBatch *b, uint8_t *thick, void *stream) {
     if (!b || !thick) return fail(PRL_E_INVALID, "null argument");
     if (!b->thick) return fail(PRL_E_INVALID, "prl_batch_get_thickness: the batch was not created with COLOR_MODE 'HSI'");

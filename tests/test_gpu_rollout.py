@@ -214,3 +214,88 @@ def test_ppo_improves_the_return():
     last_ret, last_len = hist[-1][0], hist[-1][1]
     assert first_ret < 6.0 and first_len < 40, hist[0]
     assert last_ret > 6.0 * first_ret and last_ret > 25.0 and last_len > 150, (hist[0], hist[-1])
+
+
+@pytest.mark.parametrize('part,tex', [('door_test', 240), ('square', 240), ('door_rr_big', 320)])
+def test_kernel_families_interleaved_keep_the_last_shot_rows(part, tex):
+    """Every kernel that steps a batch writes the last-shot rows and the index of their non-zero words (StepArgs::last_nz) in
+    its own way -- tracked word by word (step, act_step), whole rows marked 'all non-zero' (persistent fragments), in place in
+    HBM (large parts) -- and every other one must be able to continue from it.  One batch goes through them interleaved --
+    policy fragment (one persistent launch), given-action fragment, act_step launches, plain steps, a masked reset -- while a
+    twin takes the same actions launch by launch (prl_policy_act + prl_batch_step); after every phase the painted rows, the RAW
+    last-shot rows and the states are equal, and the index is a superset of the rows' non-zero words.  OVERLAP_PENALTY is on:
+    the rewards depend on the last-shot rows."""
+    import torch
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    from paintrl_amd.device_tables import DeviceTables
+    from paintrl_amd.rollout import MLPPolicy, RolloutWorker
+    tables = synthetic_tables(part, tex_size=(tex, tex))
+    sp = start_points_for(tables, 'all')
+    n, T = 70, 9
+    kw = dict(auto_reset=True, seed=33, overlap_penalty=True, max_possible_point=int(0.95 * tables.sample_pos.shape[0]))
+    env_a = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
+    env_b = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
+    start = np.random.RandomState(4).randint(0, len(sp), size=n)
+    env_a.reset(start_idx=start)
+    env_b.reset(start_idx=start)
+
+    def check(phase):
+        torch.cuda.synchronize()
+        assert torch.equal(env_a.painted_words(), env_b.painted_words()), phase
+        la, nza = env_a.last_shot_words()
+        lb, nzb = env_b.last_shot_words()
+        assert torch.equal(la, lb), 'last-shot rows after ' + phase
+        for last, nz in ((la, nza), (lb, nzb)):
+            words = (last.cpu().numpy() != 0)
+            bits = np.unpackbits(nz.cpu().numpy().view(np.uint8), axis=1, bitorder='little')[:, :words.shape[1]].astype(bool)
+            assert not (words & ~bits).any(), 'a non-zero word the index does not name, after ' + phase
+        sa, sb = env_a.state(), env_b.state()
+        for k in sa:
+            if k != 'facet_hint':
+                assert np.array_equal(sa[k], sb[k]), (phase, k)
+
+    torch.manual_seed(8)
+    policy = MLPPolicy(env_a.obs_dim, 4).to(env_a.device)
+    gen = torch.Generator(device=env_a.device)
+    gen.manual_seed(10)
+    # 1. the policy-driven fragment as one persistent launch / launch by launch
+    wa, wb = RolloutWorker(env_a, policy, fragment=T, seed=5, persistent=True), RolloutWorker(env_b, policy, fragment=T, seed=5)
+    ba, bb = wa.collect()[0], wb.collect()[0]
+    assert torch.equal(ba['actions'], bb['actions']) and torch.equal(ba['rewards'], bb['rewards'])
+    check('the policy fragment')
+    # 2. a given-action fragment (one persistent launch) / steps
+    buf = _fragment_buffers(env_a, T)
+    buf['action'].copy_(torch.randint(0, 4, (T, n), generator=gen, device=env_a.device, dtype=torch.int32))
+    buf['obs'][0].copy_(env_a.obs)
+    env_a.rollout_fragment(T, buf['obs'], buf['final_obs'], buf['reward'], buf['done'], buf['info'], buf['action'])
+    for t in range(T):
+        _, r, _, _ = env_b.step(buf['action'][t])
+        assert torch.equal(buf['reward'][t], r), t
+    check('the given-action fragment')
+    # 3. act_step launches / two launches per step (fresh sampling streams on both sides)
+    # (a new worker resets its env -- the library's own start draws, the same on both sides: one more writer of the rows)
+    wa2, wb2 = RolloutWorker(env_a, policy, fragment=T, seed=6, act_step=True), RolloutWorker(env_b, policy, fragment=T, seed=6)
+    check('the workers\' reset')
+    ba, bb = wa2.collect()[0], wb2.collect()[0]
+    assert torch.equal(ba['actions'], bb['actions']) and torch.equal(ba['rewards'], bb['rewards'])
+    check('the act_step launches')
+    # 4. plain steps, a masked reset, plain steps
+    for t in range(4):
+        a = torch.randint(0, 4, (n,), generator=gen, device=env_a.device, dtype=torch.int32)
+        ra, rb = env_a.step(a)[1].clone(), env_b.step(a)[1].clone()
+        assert torch.equal(ra, rb)
+    check('plain steps')
+    mask = (np.arange(n) % 3 == 0)
+    nxt = np.random.RandomState(5).randint(0, len(sp), size=n)
+    assert torch.equal(env_a.reset(mask=mask, start_idx=nxt), env_b.reset(mask=mask, start_idx=nxt))
+    check('a masked reset')
+    # 5. ... and back into a persistent fragment
+    buf['action'].copy_(torch.randint(0, 4, (T, n), generator=gen, device=env_a.device, dtype=torch.int32))
+    buf['obs'][0].copy_(env_a.obs)
+    env_a.rollout_fragment(T, buf['obs'], buf['final_obs'], buf['reward'], buf['done'], buf['info'], buf['action'])
+    for t in range(T):
+        _, r, _, _ = env_b.step(buf['action'][t])
+        assert torch.equal(buf['reward'][t], r), t
+    check('the second given-action fragment')
+    env_a.close()
+    env_b.close()
