@@ -541,104 +541,147 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
         tot_l += above ? (vg | (vl << 16) | (ve << 48)) : ((vl << 32) | ((vg + ve) << 48));
         und_l += above ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
     };
-    for (int k = 0; k < n_slots; ++k) {
-        const int w = lane + 64 * k;
-        const bool inw = w < P.n_words;
-        const int wc = inw ? w : 0;
-        const uint32_t info = ldg(P.word_info, wc);
-        const f32x2 xb = ldg(xbox, wc);
-        const uint64_t pw = inw ? painted[wc] : 0;
-        const int nv = inw ? (int)(info >> 16) : 0, row = (int)(info & 0xffffu);
-        const bool xg = xb.x > x1_hi, xl = xb.y < x1_lo, yg = (row > cy2) & x2ok, yl = row < cy2;
-        const bool whole = (xg | xl) & (yg | yl);
-        const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
-        const uint64_t c = whole ? (uint64_t)nv : 0, pc = whole ? (uint64_t)__popcll(pw) : 0;
-        tot_l += c << (16 * idx);
-        und_l += (c - pc) << (16 * idx);
-        const bool vline = !whole & (nv > 0) & (yg | yl);
-        const uint64_t vm = ballot64(vline);
-        if (vm) {
-            const int np = __popcll(vm);
-            if (n_list + np > 64) {                                   // (more rows than a part has: kept for generality)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                resolve(n_list);
-                __builtin_amdgcn_wave_barrier();
-                n_list = 0;
+    // (three slots a trip: their nine loads are issued together, one round trip)
+    constexpr int G1 = 3;
+    for (int k0 = 0; k0 < n_slots; k0 += G1) {
+        uint32_t info[G1];
+        f32x2 xb[G1];
+        uint64_t pw[G1];
+        bool inw[G1];
+#pragma unroll
+        for (int g = 0; g < G1; ++g) {
+            const int w = lane + 64 * (k0 + g);
+            inw[g] = w < P.n_words;
+            const int wc = inw[g] ? w : 0;
+            info[g] = ldg(P.word_info, wc);
+            xb[g] = ldg(xbox, wc);
+            pw[g] = painted[wc];
+        }
+#pragma unroll
+        for (int g = 0; g < G1; ++g) {
+            const int w = lane + 64 * (k0 + g);
+            const int nv = inw[g] ? (int)(info[g] >> 16) : 0, row = (int)(info[g] & 0xffffu);
+            const bool xg = xb[g].x > x1_hi, xl = xb[g].y < x1_lo, yg = (row > cy2) & x2ok, yl = row < cy2;
+            const bool whole = (xg | xl) & (yg | yl);
+            const int idx = (xg & yg) ? 0 : ((xl & yg) ? 1 : ((xl & yl) ? 2 : 3));
+            const uint64_t c = whole ? (uint64_t)nv : 0, pc = (whole & inw[g]) ? (uint64_t)__popcll(pw[g]) : 0;
+            tot_l += c << (16 * idx);
+            und_l += (c - pc) << (16 * idx);
+            const bool vline = !whole & (nv > 0) & (yg | yl);
+            const uint64_t vm = ballot64(vline);
+            if (vm) {
+                const int np = __popcll(vm);
+                if (n_list + np > 64) {                               // (more rows than a part has: kept for generality)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    resolve(n_list);
+                    __builtin_amdgcn_wave_barrier();
+                    n_list = 0;
+                }
+                if (vline)
+                    list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0))] = w | (yg ? 1 << 30 : 0);
+                n_list += np;
             }
-            if (vline)
-                list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0))] = w | (yg ? 1 << 30 : 0);
-            n_list += np;
         }
     }
+#if defined(PRL_OBS_CUT) && PRL_OBS_CUT >= 2           // (timing builds, wrong results)
+    n_list = 0;
+#endif
     if (n_list) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the lanes that found the words wrote the list, lanes 0.. read it
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         resolve(n_list);
     }
-    // pass 3: the tool's own row of cells
+    // pass 3: the tool's own row of cells.  One word per lane first -- its float interval, valid and painted words in ONE round
+    // trip for the whole row (65 words at 70 654 samples) -- which leaves a single load per word for the loop below: its float
+    // a2 coordinates, eight words a trip.  (Word by word with the interval, valid and painted words read where they were
+    // needed the loop was a chain of ~70 dependent round trips: 28 of the step's 95 us.)
+#if defined(PRL_OBS_CUT) && PRL_OBS_CUT >= 1
+    if (false)
+#endif
     if (cy2 >= 0 && cy2 < P.sg_ny) {
         const int ws0 = P.sg_start[cy2 * P.sg_nx] >> 6, ws1 = (P.sg_start[(cy2 + 1) * P.sg_nx] + 63) >> 6;
         const float y_lo = f32_at_or_below(x2), y_hi = f32_at_or_above(x2);
         gfloat_p yf32 = P.samp_a2_f32;
-        uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane; widened every 64 words
+        uint32_t tot_s = 0, und_s = 0;                 // 4 x 8-bit counters per lane; widened before they can overflow
         int since = 0;
-        for (int w0 = ws0; w0 < ws1; w0 += 4) {
-            uint64_t vs[4], pws[4];
-            float yf[4];
-            bool side[4], right[4];
+        auto widen = [&]() {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int w = w0 + q < ws1 ? w0 + q : ws1 - 1;
-                const f32x2 xb = reinterpret_cast<const f32x2 CAS *>((uint64_t)P.word_x32)[w];      // (wave-uniform: a scalar load)
-                right[q] = xb.x > x1_hi;
-                side[q] = right[q] | (xb.y < x1_lo);
-                yf[q] = ldg(yf32, (w << 6) + lane);
-                vs[q] = w0 + q < ws1 ? P.word_valid[w] : 0;
-                pws[q] = uni_u64(painted[w]);                        // (every lane the same word: one request)
+                tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
+                und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
             }
-            bool amb = false;
+            tot_s = und_s = 0;
+            since = 0;
+        };
+        for (int c0 = ws0; c0 < ws1; c0 += 64) {
+            const int wi = c0 + lane;
+            const bool inr = wi < ws1;
+            const int wc = inr ? wi : c0;
+            const f32x2 xb = ldg(xbox, wc);
+            const uint64_t v_i = inr ? ldg(P.word_valid, wc) : 0, p_i = painted[wc];
+            const bool right_i = xb.x > x1_hi, side_i = right_i | (xb.y < x1_lo);
+            const uint64_t have = ballot64(v_i != 0), rightm = ballot64(right_i);
+            uint64_t ym = ballot64(side_i) & have, bm = have & ~ym;
+            constexpr int G3 = 8;
+            while (ym) {                                              // wholly left or right of the tool: the a2 coordinate decides
+                int L[G3];
+                float yf[G3];
+                bool has[G3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) amb |= side[q] & (yf[q] >= y_lo) & (yf[q] <= y_hi) & __builtin_amdgcn_inverse_ballot_w64(vs[q]);
-            const bool redo = ballot64(amb) != 0;
+                for (int q = 0; q < G3; ++q) {
+                    has[q] = ym != 0;
+                    L[q] = has[q] ? __builtin_ctzll(ym) : 0;
+                    ym &= ym - 1;                                     // (0 stays 0)
+                    yf[q] = ldg(yf32, ((c0 + L[q]) << 6) + lane);
+                }
+                uint64_t vs[G3];
+                bool amb = false;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int w = w0 + q < ws1 ? w0 + q : ws1 - 1;
-                const bool cnt0 = __builtin_amdgcn_inverse_ballot_w64(vs[q]);
-                uint32_t sh;
-                bool cnt = cnt0;
-                if (side[q]) {                                        // wave-uniform: left or right of the tool as a whole
+                for (int q = 0; q < G3; ++q) {
+                    vs[q] = has[q] ? bcast_u64(v_i, L[q]) : 0;
+                    amb |= (yf[q] >= y_lo) & (yf[q] <= y_hi) & __builtin_amdgcn_inverse_ballot_w64(vs[q]);
+                }
+                const bool redo = ballot64(amb) != 0;
+#pragma unroll
+                for (int q = 0; q < G3; ++q) {
                     bool gy = yf[q] > y_hi, ly = yf[q] < y_lo;
                     if (redo) {                                       // (rare: a sample within a float's spacing of the line)
-                        const double yd = ldg(sy, (w << 6) + lane);
+                        const double yd = ldg(sy, ((c0 + L[q]) << 6) + lane);
                         gy = yd > x2;
                         ly = yd < x2;
                     }
-                    const uint32_t up = right[q] ? 0u : 8u, down = right[q] ? 24u : 16u;
-                    sh = gy ? up : (ly ? down : 24u);
-                } else {                                              // straddles both lines: both coordinates, float64
-                    const double xs = ldg(sx, (w << 6) + lane), ys = ldg(sy, (w << 6) + lane);
-                    cnt = cnt0 & !((xs == x1) & (ys == x2));          // bpw:1032: the tool's own sample is skipped
-                    const bool gy = ys > x2, lx = xs < x1;
-                    sh = ((xs > x1) & gy) ? 0u : ((lx & gy) ? 8u : ((lx & (ys < x2)) ? 16u : 24u));
+                    const uint64_t pw = bcast_u64(p_i, L[q]);
+                    const bool right = (rightm >> L[q]) & 1;          // wave-uniform
+                    // bpw:1034-1043:  (>, >) -> 0, (<, >) -> 1, (<, <) -> 2, else 3
+                    const uint32_t up = right ? 0u : 8u, down = right ? 24u : 16u;
+                    const uint32_t sh = gy ? up : (ly ? down : 24u);
+                    const uint32_t one = __builtin_amdgcn_inverse_ballot_w64(vs[q]) ? (1u << sh) : 0u;
+                    tot_s += one;
+                    und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
                 }
+                since += G3;
+                if (since > 255 - G3) widen();
+            }
+            while (bm) {                                              // straddles both lines (one or two words): both coordinates, float64
+                const int Lb = __builtin_ctzll(bm);
+                bm &= bm - 1;
+                const int w = c0 + Lb;
+                const double xs = ldg(sx, (w << 6) + lane), ys = ldg(sy, (w << 6) + lane);
+                const uint64_t vw = bcast_u64(v_i, Lb), pw = bcast_u64(p_i, Lb);
+                const bool cnt = __builtin_amdgcn_inverse_ballot_w64(vw) & !((xs == x1) & (ys == x2));      // bpw:1032: the tool's own sample is skipped
+                const bool gy = ys > x2, lx = xs < x1;
+                const uint32_t sh = ((xs > x1) & gy) ? 0u : ((lx & gy) ? 8u : ((lx & (ys < x2)) ? 16u : 24u));
                 const uint32_t one = cnt ? (1u << sh) : 0u;
                 tot_s += one;
-                und_s += __builtin_amdgcn_inverse_ballot_w64(pws[q]) ? 0u : one;
-            }
-            since += 4;
-            if (since >= 252 || w0 + 4 >= ws1) {                      // the 8-bit fields hold 255: widen into the 16-bit ones
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    tot_l += (uint64_t)((tot_s >> (8 * q)) & 0xffu) << (16 * q);
-                    und_l += (uint64_t)((und_s >> (8 * q)) & 0xffu) << (16 * q);
-                }
-                tot_s = und_s = 0;
-                since = 0;
+                und_s += __builtin_amdgcn_inverse_ballot_w64(pw) ? 0u : one;
+                since += 1;
+                if (since > 255 - G3) widen();
             }
         }
+        widen();
     }
 }
 
