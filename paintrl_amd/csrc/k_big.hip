@@ -56,8 +56,11 @@ __device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, in
 
 // One launch = one batched step of a large part, COLOR_MODE 'RGB': one wavefront per env, WAVES envs per workgroup, four
 // waves a SIMD -- the small parts' step_kernel with the masks left in HBM.
+#ifndef PRL_BIG_OCC
+#define PRL_BIG_OCC 4                  // waves a SIMD the large parts' step is compiled for (A/B: 3 = 168 registers)
+#endif
 template <bool GENSEC, bool KD, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void step_kernel_big(StepArgs) {
+__global__ __launch_bounds__(64 * WAVES, PRL_BIG_OCC) void step_kernel_big(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));

@@ -353,7 +353,11 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
                     // (GP words a trip with their records and mask words requested together: 2 spilled ten vector registers, 4 fifty-seven --
                     // 18 k samples 43.3 -> 48.4 us, 70 k 84.2 -> 81.7: one at a time)
                     while (m) {
+#ifdef PRL_BIG_GP
+                        constexpr int GP = PRL_BIG_GP;
+#else
                         constexpr int GP = 1;
+#endif
                         int wq[GP];
                         bool hq[GP];
                         f32x4 pfq[GP];

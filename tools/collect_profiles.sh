@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/; tools/summarise_profiles.py (run in the build container afterwards) turns it into profiles/<tag>_*.
 # Counter passes carry --pmc only (no --kernel-trace / --stats with them); the program after `--` is python3 itself.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -24,7 +24,12 @@ $B --policy random-fragment --no-cpu-baseline > "$OUT/bench_random_fragment.json
 $B --streams 2 --no-cpu-baseline > "$OUT/bench_streams2.json" 2>> "$OUT/bench.err"
 $B --paint-method normal --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/bench_normal.json" 2>> "$OUT/bench.err"
 echo "== the reference's sheet: four mask words per lane (fine sheet), and with the stale kd-tree (coarse sheet)"
-for p in square test; do python3 "$ROOT/tools/bench_part.py" $p --json 2>/dev/null | tail -1 > "$OUT/bench_part_$p.json"; done
+for p in square test; do $B --part $p --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_part_$p.json" 2>> "$OUT/bench.err"; done
+echo "== large parts (Part_Dict rge:106-117: door_rr / door_rf / door_rr_big classes; step_kernel_big, mask rows in HBM)"
+for spec in door_rr:328 door_rf:448 door_rr_big:652; do
+  $B --part door_rr_big --tex ${spec##*:} --steps 300 --warmup 60 --no-cpu-baseline > "$OUT/bench_part_${spec%%:*}.json" 2>> "$OUT/bench.err"
+done
+$B --part door_rr_big --tex 652 --policy random-fragment --steps 300 --warmup 100 --no-cpu-baseline > "$OUT/bench_part_door_rr_big_random_fragment.json" 2>> "$OUT/bench.err"
 echo "== the RCCL path on one rank (PAINTRL_FORCE_DIST=1)"
 PAINTRL_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29613 $B --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/bench_rccl_world1.json" 2>> "$OUT/bench.err"
 echo "== batch-size sweep (one wave per CU ... four per SIMD: the step's latency chain against its throughput)"
@@ -41,6 +46,8 @@ echo "== kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- $B --no-cpu-baseline > "$OUT/trace.log" 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_grid" --output-format csv -- $B --obs-mode grid --no-cpu-baseline > "$OUT/trace_grid.log" 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_normal" --output-format csv -- $B --paint-method normal --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/trace_normal.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_big" --output-format csv -- $B --part door_rr_big --tex 652 --steps 200 --warmup 40 --no-cpu-baseline > "$OUT/trace_big.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace_kd" --output-format csv -- $B --part test --steps 400 --warmup 100 --no-cpu-baseline > "$OUT/trace_kd.log" 2>&1
 echo "== SQ / TA counters"
 G1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH"
 G2="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH"

@@ -33,7 +33,7 @@ def counters(d, kernel='step_kernel'):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
     src = os.path.join(REPO, 'gpurun_out', tag)
     dst = os.path.join(REPO, 'profiles')
     # bench lines
@@ -43,7 +43,8 @@ def main():
             with open(os.path.join(dst, '%s_%s' % (tag, os.path.basename(f))), 'w') as out:
                 out.write(lines[-1] + '\n')
     # kernel trace stats
-    for name, sub in (('kernel_stats', 'trace'), ('kernel_stats_grid', 'trace_grid'), ('kernel_stats_normal', 'trace_normal')):
+    for name, sub in (('kernel_stats', 'trace'), ('kernel_stats_grid', 'trace_grid'), ('kernel_stats_normal', 'trace_normal'),
+                      ('kernel_stats_big', 'trace_big'), ('kernel_stats_kd', 'trace_kd')):
         hits = glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True)
         hits.sort(key=os.path.getmtime)                 # (gpurun merges new files next to older ones: newest wins)
         if hits:
