@@ -116,7 +116,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
+#ifdef PRL_ENV_PERM                        // (diagnostic build, tools/tail_experiment.py)
+    const int slot_ = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (slot_ >= a.n_envs) return;
+    const int env = rfl(g_env_perm ? g_env_perm[slot_] : slot_);
+#else
     const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
+#endif
     if (env >= a.n_envs) return;
     // (round 3 parked the last-shot masks of the four-word kernels in LDS rows -- prl_paint.hpp RowWords, WaveLds::lastrow --
     // against 63 spilled vector registers on the reference's own sheet.  The registers were the observation's: four slots'

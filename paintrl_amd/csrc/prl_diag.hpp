@@ -4,6 +4,7 @@
 // kernels carry no instrumentation.  Diagnostic builds (tools/, tests/test_gpu_forced_paths.py) may define:
 //   PRL_PHASE_TIMING=<k>       s_memtime deltas of phase k summed over all waves (tools/phase_timing.py)
 //   PRL_WAVE_TRACE             per env and launch: start / end time and path counters of its wave (tools/wave_trace.py)
+//   PRL_ENV_PERM               wave slot -> env through a host-set permutation (tools/tail_experiment.py)
 //   PRL_CUT=<1|2|4|5|6>       instruction-count builds: no observation / nor painting / nor hook point / nor ray / no
 //                              shots at all (wrong results;
 //                              counter differences between them give each phase's instructions, tools/pmc_cuts.sh)
@@ -74,6 +75,12 @@ __device__ unsigned long long g_wave_trace16[PRL_TRACE_ENVS];      // four 16-bi
 #define TRACE_END(env, dn) \
     do {                   \
     } while (0)
+#endif
+
+#ifdef PRL_ENV_PERM
+// diagnostic build only (tools/tail_experiment.py): wave slot -> env through a permutation the host sets per launch, to measure
+// what a launch gains when the envs of a SIMD are chosen by their expected cost
+__device__ const int *g_env_perm;
 #endif
 
 #ifdef PRL_FRAG_TIMING

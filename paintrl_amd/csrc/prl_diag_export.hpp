@@ -29,6 +29,13 @@ int prl_debug_frag_ticks(unsigned long long *out) {
 }
 #endif
 
+#ifdef PRL_ENV_PERM
+// diagnostic build only: the permutation (device int[n_envs], or null = identity) the next step launches map their wave slots through
+int prl_debug_set_env_perm(const int *perm_dev) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_env_perm), &perm_dev, sizeof perm_dev) == hipSuccess ? PRL_OK : PRL_E_HIP;
+}
+#endif
+
 #ifdef PRL_WAVE_TRACE
 // diagnostic build only: the last launch's per-env trace rows (start, end, path counters, done)
 int prl_debug_wave_trace(unsigned long long *out, int n_envs) {
