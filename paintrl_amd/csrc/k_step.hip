@@ -116,6 +116,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
+#ifdef PRL_GRID_LDS                        // (A/B switch: the part's cell-start tables in the workgroup's LDS)
+    __shared__ int s_grid[2][GRID_LDS];
+    bool grids_staged = false;
+    if (!a.env_part) {                     // a batch of one part: every env of the workgroup reads the same two tables
+        PartRef P0 = *(const PartDev CAS *)a.parts;
+        const int n_vg = P0.vg_nx * P0.vg_ny + 1, n_sg = P0.sg_nx * P0.sg_ny + 1;
+        if (n_vg <= GRID_LDS && n_sg <= GRID_LDS) {
+            for (int i = threadIdx.x; i < n_vg; i += 64 * WAVES) s_grid[0][i] = ldg(P0.vg_start, i);
+            for (int i = threadIdx.x; i < n_sg; i += 64 * WAVES) s_grid[1][i] = ldg(P0.sg_start, i);
+            grids_staged = true;
+            __syncthreads();               // (before any wave of the workgroup leaves: the last workgroup may hold waves without an env)
+        }
+    }
+#endif
 #ifdef PRL_ENV_PERM                        // (diagnostic build, tools/tail_experiment.py)
     const int slot_ = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
     if (slot_ >= a.n_envs) return;
@@ -128,7 +142,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // against 63 spilled vector registers on the reference's own sheet.  The registers were the observation's: four slots'
     // pivot probes at once, 64 of them (prl_observe.hpp section4_accumulate); taken two slots at a time no KW = 4 kernel
     // spills any more and the rows are not needed.)
-    const WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES, PRL_TILE_ON, PRL_GATHER_ON>();
+    WaveLds wl = wave_lds<GENSEC, KD, 0, WAVES, PRL_TILE_ON, PRL_GATHER_ON>();
+#ifdef PRL_GRID_LDS
+    if (grids_staged) {
+        wl.vg_lds = s_grid[0];
+        wl.sg_lds = s_grid[1];
+    }
+#endif
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;

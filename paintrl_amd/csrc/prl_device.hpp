@@ -248,7 +248,11 @@ struct WaveLds {
     FacetTile *tile;    // the ray's facet tile, or nullptr (kernels that do not stage one: the ray then reads global memory)
     f64x2 *gather;      // [GATHER_CHUNKS]: where a few lanes' records are fetched by ALL lanes (record_gather below), or nullptr
     int kd_staged;      // kd_heap has KD_ROW doubles: small trees are walked from their copy behind the queue (kd_stage); 0: KD_HEAP * 5
+    // the part's two cell-start tables (PartDev::vg_start, sg_start) copied into the workgroup's LDS where the kernel stages
+    // them (step_kernel: batches of one part whose grids have at most GRID_LDS entries), or nullptr: read from global memory
+    const int *vg_lds = nullptr, *sg_lds = nullptr;
 };
+constexpr int GRID_LDS = 512;
 template <bool GENSEC, bool KD = false, int LASTROW_KW = 0, int WAVES = MAX_WAVES_PER_WG, bool TILE = false, bool GATHER = false>
 __device__ __forceinline__ WaveLds wave_lds() {
     __shared__ int s_cand[WAVES][64];

@@ -148,7 +148,7 @@ struct HbmWords {
 // of the bounding block against all five centres gives each shot exactly its own ball query.
 template <typename Words>
 __device__ void paint_shots_union(PartRef P, double radius, const double *cen_lds, int lane, const Words &words,
-                                  int &succeeded, int &pixel_counter) {
+                                  int &succeeded, int &pixel_counter, const int *sg_lds = nullptr) {
     const double r2 = radius * radius;
     // the float64 centres are only needed for the cell ranges and by the rare float64 branch, which reads them
     // from LDS again: fifteen doubles held across the word loop would be thirty vector registers
@@ -194,7 +194,8 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     // TRIP rows per trip: lanes 0 .. 2 TRIP - 1 fetch the range bounds
     const int rcy = r0 + (lane >> 1);
     const bool ok = lane < 2 * TRIP && rcy <= row_hi && cx0 <= cx1;
-    const int bound = ok ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
+    const int bidx = ok ? rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0) : 0;
+    const int bound = ok ? (sg_lds ? sg_lds[bidx] : ldg(P.sg_start, bidx)) : 0;      // (the table's LDS copy where the kernel has one)
     int rb[TRIP], re[TRIP];
 #pragma unroll
     for (int r = 0; r < TRIP; ++r) {

@@ -124,7 +124,7 @@ __device__ __forceinline__ void ring_block_scan(PartRef P, int bound, const doub
 // scanned (its rows are contiguous index ranges, flattened into one candidate list); every vertex
 // outside the block is at least k cells away in the principal plane, so the result is exact once the
 // best distance is within k * 0.99 * cell.  After ring 3 the whole table is scanned.
-__device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
+__device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane, const int *vg_lds = nullptr) {
     const double h1 = sel3(pt[0], pt[1], pt[2], P.a1), h2 = sel3(pt[0], pt[1], pt[2], P.a2);
     const int icx = cell_coord(h1, P.vg_o1, P.vg_inv, P.vg_nx), icy = cell_coord(h2, P.vg_o2, P.vg_inv, P.vg_ny);
     double best_d = INFINITY, dmin = INFINITY;
@@ -135,7 +135,8 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane) {
         const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
         const int rcy = icy - ring + (lane >> 1);
         const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
-        const int bound = okr ? ldg(P.vg_start, rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
+        const int bidx = okr ? rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0) : 0;
+        const int bound = okr ? (vg_lds ? vg_lds[bidx] : ldg(P.vg_start, bidx)) : 0;       // (the table's LDS copy where the kernel has one)
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;
@@ -514,8 +515,8 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     FacetTile *tile = wl.tile;
     f64x2 *gather = wl.gather;
     int vidx;
-    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap, wl.kd_staged != 0) : nearest_vertex_wave(P, pt, lane);
-    else vidx = nearest_vertex_wave(P, pt, lane);
+    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap, wl.kd_staged != 0) : nearest_vertex_wave(P, pt, lane, wl.vg_lds);
+    else vidx = nearest_vertex_wave(P, pt, lane, wl.vg_lds);
     if (tile && pf.facet >= 0) tile_fill(P, tile, pf.facet, pf.ids, lane);
     STAMP(PH_VERTEX);
     if (vidx < 0) return false;

@@ -393,7 +393,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
             uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
 #if !defined(PRL_CUT) || PRL_CUT < 2
             paint_shots_union(P, C.paint_radius, cen, lane, RegWords<KW>{painted, last, new_last, lane}, succeeded,
-                              pixel_counter);
+                              pixel_counter, wl.sg_lds);
 #endif
 #pragma unroll
             for (int k = 0; k < KW; ++k) last[k] = new_last[k];
