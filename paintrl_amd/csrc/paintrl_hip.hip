@@ -183,6 +183,21 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
     if (d.n_obs_cells > 0) {
         UP(cell_mask, t->obs_cell_mask, (size_t)d.n_obs_cells * d.n_words);
         UP(cell_count, t->obs_cell_count, d.n_obs_cells);
+        // which cells a word's samples lie in (derived): nearly every word lies in ONE cell of the grid observation, whose count
+        // is then the popcount of its painted word -- no mask read; the words on a cell boundary name their two to four cells
+        std::vector<int32_t> wc((size_t)d.n_words);
+        for (int w = 0; w < d.n_words; ++w) {
+            uint32_t packed = 0xffffffffu;
+            int n = 0;
+            for (int c = 0; c < d.n_obs_cells && n <= 4; ++c)
+                if (t->obs_cell_mask[(size_t)c * d.n_words + w] != 0) {
+                    if (n < 4 && c < 255) packed = (packed & ~(0xffu << (8 * n))) | ((uint32_t)c << (8 * n));
+                    else n = 4;                                   // a fifth cell, or an index the byte cannot hold
+                    ++n;
+                }
+            wc[(size_t)w] = (int32_t)(n > 4 ? 0xfffffffeu : packed);
+        }
+        UP(word_cells, wc.data(), wc.size());
     }
     d.n_vertices = t->n_vertices;
     if (d.n_vertices <= 0) return fail(PRL_E_INVALID, "part has no same-side vertices");

@@ -62,6 +62,8 @@ struct PartDev {
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
     gfloat_p samp_a2_f32;         // [n_samples_pad]: the a2 coordinate rounded to the nearest float (derived in part_fill)
     // large parts' observation (prl_observe.hpp section4_big; derived in part_fill):
+    gint_p word_cells;            // [n_words]: the (at most four) grid-observation cells the word's valid samples lie in, one byte each,
+                                  // 0xff = none; 0xfffffffe: more than four (or a cell index beyond 254): every cell's mask is tried
     gint_p word_info;             // [n_words]: the word's cell row (low 16 bits) | its number of valid samples << 16
     gfloat_p word_x32;            // [n_words][2]: float interval holding the a1 coordinates of its valid samples (rounded outward)
     // fine sample grid for the cone-beam painter's nearest-sample queries, one query per lane (prl_cone.hpp; derived
