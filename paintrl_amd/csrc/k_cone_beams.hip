@@ -125,7 +125,16 @@ __global__ __launch_bounds__(64 * WAVES, 4) void cone_path_kernel(StepArgs) {
     shots_begin<KD>(P, S, delta1, delta2, X, lane, wl);
     double *shots = a.cone_shots + (size_t)env * PAINT_PER_ACTION * 8;
     PROF_BEGIN();
+#ifndef PRL_NO_PATH_PRIO                   // (A/B switch; issue priority by progress as in step_env: 30.7 -> 29.9 us)
+    PRIO_YOUNG_DECL();
+#endif
     for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
+#ifndef PRL_NO_PATH_PRIO
+        // the wave that is behind is served first (prl_step.hpp): 3 for the first shots, falling to 0 with progress
+        if (shot <= 1) PRIO_BY_PROGRESS(3);
+        else if (shot <= 3) PRIO_YOUNG_OLD(3, 2, shot);
+        else PRIO_YOUNG_OLD(2, 1, shot);
+#endif
         double center[3], quat[4];
         sub_shot<KD>(P, lane, S, X, wl, center, quat PROF_PASS);
         // lanes 0..7 write the record: pos, quat, {facet hint, 0}
