@@ -261,8 +261,13 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
     {   // this kernel writes the last-shot rows whole, step by step: say so once (prl_step.hpp last_row_untracked)
         const StepArgs CAS &a0 = opaque(g0)->f.s;
         const int env_ = (int)blockIdx.x * POLICY_WAVES + wave0;
+#ifndef PRL_POLICY_TRACKED
         if constexpr (KW != 0)
             if (env_ < a0.n_envs) last_row_untracked(a0, env_, (int)(threadIdx.x & 63));
+#else
+        (void)a0;
+        (void)env_;
+#endif
     }
     for (int t = 0;; ++t) {
         const PolicyFragmentArgs CAS &g = *opaque(g0);
@@ -307,10 +312,20 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
             EnvState S;
             load_state_motion(state_rec, S);
+#ifndef PRL_POLICY_TRACKED                           // (default: whole mask rows read and written every step)
             const auto masks = [&] {
                 if constexpr (KW == 0) return hbm_masks(a, env, P.n_words, lane);      // (large parts: rows worked on in place)
                 else return global_masks(a, env, P.n_words, lane);
             }();
+#else
+            // (A/B switch, OFF: changed words only, the last-shot row's non-zero words only -- GlobalMasksT<true>, as the per-step
+            // kernels: twelve more vector registers, 19 spilled instead of 5: 22.0 k steps/s against 23.4 k)
+            const auto masks = [&] {
+                if constexpr (KW == 0) return hbm_masks(a, env, P.n_words, lane);      // (large parts: rows worked on in place)
+                else return global_masks<true>(a, env, P.n_words, lane);
+            }();
+            if constexpr (KW != 0) masks.prefetch();
+#endif
             double delta1, delta2, new_angle;
             decode_discrete_action(C, act, delta1, delta2, new_angle);
             const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
