@@ -497,9 +497,8 @@ def main():
     episodes = sum(int(e.state()['episode'].sum()) for e in subs) - args.envs
     # which device every rank ran on (a SCALE record can be checked against it)
     rank_devices = [int(local_rank)]
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        rank_devices = [None] * dist.get_world_size()
-        dist.all_gather_object(rank_devices, int(local_rank))
+    if dist.is_initialized() and dist.get_world_size() > 1:          # (the returns' own all_gather path: RCCL or gloo)
+        rank_devices = [int(v) for v in pdist.gather_returns(torch.tensor([float(local_rank)], dtype=torch.float64, device=device)).tolist()]
     occupancy = None
     if args.paint_method == 'fast' and args.policy in ('random', 'mlp', 'mlp-torch'):
         occupancy = env.step_occupancy()                 # of one prl_batch_step launch
