@@ -71,14 +71,19 @@ __global__ __launch_bounds__(64 * WAVES, PRL_BIG_OCC) void step_kernel_big(StepA
     CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
+    TRACE_BEGIN();
     load_state_motion(state_rec, S);
     const HbmMasks masks = hbm_masks(a, env, P.n_words, lane);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    PROF_BEGIN();                                    // (stamped builds time step_kernel; this one only has to compile)
+    PROF_BEGIN();                                    // (trace builds: tools/wave_trace.py with --diag-unit k_big)
     const int dn = step_env<0, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                       new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
+    STAMP(PH_STORE);
+    PROF_END();
+    PROF_STORE(env);
+    TRACE_END(env, dn);
 }
 
 // COLOR_MODE 'HSI' on a large part: four LDS copies of the rows per env (painted, last, the shot's set, the union of valid sets)

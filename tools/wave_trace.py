@@ -31,15 +31,19 @@ def main():
     _lib._lib = None
     lib = _lib.load()
     lib.prl_debug_wave_trace.argtypes = [C.c_void_p, C.c_int]
-    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh('door_test'), tex_size=(240, 240))
-    dt = DeviceTables(tables)
+    part = os.environ.get('PRL_PART', 'door_test')           # (PRL_PART=door_rr_big PRL_TEX=652 with a --diag-unit k_big build)
+    tex = int(os.environ.get('PRL_TEX', '0')) or synth_parts.TEXTURES[part][0][0]
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(part), tex_size=(tex, tex), name=part)
+    other = part != 'door_test' or tex != 240
+    dt = DeviceTables(tables, start_points=part_tables.start_points(tables, 'all') if other else None)
     n = int(os.environ.get('PRL_ENVS', '4096'))
     steps = int(os.environ.get('PRL_TRACE_STEPS', '40'))
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1234)
     acts = torch.randint(0, 4, (200 + steps, n), generator=gen, device='cuda', dtype=torch.int32)
     method = os.environ.get('PRL_PAINT_METHOD', 'fast')
-    env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, paint_method=method)
+    env = BatchedPaintEnv(dt, n, auto_reset=True, seed=5678, paint_method=method,
+                          max_possible_point=int(0.95 * tables.sample_pos.shape[0]) if other else 9148)
     env.reset()
     warm = 200 if method == 'fast' else 20
     for s in range(warm):
