@@ -351,6 +351,30 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
                     }
                     const bool reach = inr & near & !((bb.x > reach_hi1) | (bb.y < reach_lo1) | (bb.z > reach_hi2) | (bb.w < reach_lo2));
                     uint64_t m = ballot64(reach);
+#ifdef PRL_BIG_PREFETCH                              // (A/B switch: the next word's loads one word ahead; see profiles/r05_ab_log.txt)
+                    if (m) {
+                        int w_cur = wb + __builtin_ctzll(m);
+                        m &= m - 1;
+                        f32x4 pf = ldg(s4, (w_cur << 6) + lane);
+                        uint64_t pw_c, lw_c;
+                        words.get(w_cur, pw_c, lw_c);
+                        for (;;) {
+                            const bool more = m != 0;
+                            const int w_nxt = more ? wb + __builtin_ctzll(m) : w_cur;
+                            m &= m - 1;                                   // (0 stays 0)
+                            const f32x4 pn = ldg(s4, (w_nxt << 6) + lane);       // (the last trip reads its own word again: harmless)
+                            uint64_t pw_n, lw_n;
+                            words.get(w_nxt, pw_n, lw_n);
+                            do_word(w_cur, pf, rb[r], re[r], pw_c, lw_c);
+                            if (!more) break;
+                            w_cur = w_nxt;
+                            pf = pn;
+                            pw_c = pw_n;
+                            lw_c = lw_n;
+                        }
+                    }
+                }
+#else
                     // (GP words a trip with their records and mask words requested together: 2 spilled ten vector registers, 4 fifty-seven --
                     // 18 k samples 43.3 -> 48.4 us, 70 k 84.2 -> 81.7: one at a time)
                     while (m) {
@@ -376,6 +400,7 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
                             if (hq[q]) do_word(wq[q], pfq[q], rb[r], re[r], pwq[q], lwq[q]);
                     }
                 }
+#endif
                 done_w = wlast > done_w ? wlast : done_w;
             } else {
                 for (int w = wfirst; w <= wlast; ++w) {
