@@ -286,3 +286,42 @@ def test_reference_sized_part_with_the_stale_tree_fits_the_lds(kw, n, steps):
     assert np.array_equal(env.parts[0].mask_to_canonical(words), np.stack([orc.painted_bits(e) for e in range(n)]))
     assert np.array_equal(env.observe().cpu().numpy(), orc.observe())
     env.close()
+
+
+def test_fused_rollout_on_a_large_part_with_the_stale_tree():
+    """The fused rollout kernels of large parts (k_rollout.hip compiled with -DPRL_KW=0: mask rows in HBM) on a part that also
+    carries the stale vertex kd-tree (34 000 samples): the given-action fragment as ONE persistent launch equals the steps launch
+    by launch, row by row, painted rows, last-shot rows and states at the end; OVERLAP_PENALTY on."""
+    import torch
+    tables = synthetic_tables('test', tex_size=(370, 370))
+    assert tables.sample_pos.shape[0] > 16384 and len(tables.kd_split_dim) > 0
+    sp = start_points_for(tables, 'all')
+    n, T = 40, 14
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    mk = lambda: _env(tables, n, sp, auto_reset=True, seed=3, overlap_penalty=True, max_possible_point=mpp)     # noqa: E731
+    env_a, env_b = mk(), mk()
+    start = np.random.RandomState(2).randint(0, len(sp), size=n)
+    o0 = env_a.reset(start_idx=start).clone()
+    env_b.reset(start_idx=start)
+    dev, od = env_a.device, env_a.obs_dim
+    f64 = dict(dtype=torch.float64, device=dev)
+    obs, fin = torch.zeros((T + 1, n, od), **f64), torch.zeros((T, n, od), **f64)
+    rew, info = torch.zeros((T, n), **f64), torch.zeros((T, n, 2), **f64)
+    done = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12)
+    act = torch.randint(0, 4, (T, n), generator=gen, device=dev, dtype=torch.int32)
+    obs[0].copy_(o0)
+    env_a.rollout_fragment(T, obs, fin, rew, done, info, act)
+    torch.cuda.synchronize()
+    for t in range(T):
+        o, r, d, i = env_b.step(act[t])
+        assert torch.equal(obs[t + 1], o) and torch.equal(rew[t], r) and torch.equal(info[t], i) and torch.equal(done[t].bool(), d), 'row %d' % t
+    assert torch.equal(env_a.painted_words(), env_b.painted_words())
+    assert torch.equal(env_a.last_shot_words()[0], env_b.last_shot_words()[0])
+    sa, sb = env_a.state(), env_b.state()
+    for k in sa:
+        if k != 'facet_hint':
+            assert np.array_equal(sa[k], sb[k]), k
+    env_a.close()
+    env_b.close()
