@@ -277,6 +277,7 @@ def main():
                          "group's slowest wave then only delays that group); default 1 = one launch per step")
     ap.add_argument('--graph', action='store_true', help='with --policy mlp: capture policy + env step in one HIP graph')
     ap.add_argument('--paint-method', default='fast', choices=['fast', 'normal'])
+    ap.add_argument('--color-mode', default='RGB', choices=['RGB', 'HSI'], help="COLOR_MODE (rge:156): 'HSI' = thickness bytes (bpw:384-434)")
     ap.add_argument('--part', default='door_test',
                     help="synthetic part (paintrl_amd.synth_parts.PARTS): 'door_test' = the BASELINE door panel (default), 'square' "
                          "the fine sheet, 'test' the coarse sheet with the reference's stale kd-tree, 'door_rr_big' the door on a "
@@ -316,7 +317,7 @@ def main():
     dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, start_mode))
     overlap = args.obs_mode == 'grid'
     common = dict(device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
-                  paint_method=args.paint_method)
+                  paint_method=args.paint_method, color_mode=args.color_mode)
     if args.mixed:
         if args.streams > 1:
             raise SystemExit('--streams is not combined with --mixed')
@@ -519,7 +520,7 @@ def main():
         tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         # the committed PMC measurement is for the default workload (section / grid) only
         if os.path.isfile(tpath) and args.envs == ENVS_PER_GPU and not args.mixed and args.actions == 'random' \
-                and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast' and not other_part:
+                and len(subs) == 1 and args.policy == 'random' and args.paint_method == 'fast' and not other_part and args.color_mode == 'RGB':
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get('bytes_per_launch_%s' % args.obs_mode)
@@ -548,7 +549,8 @@ def main():
                                       "synthetic part '%s' on a %d x %d texture (START_POINT_MODE all)" % (args.part, tex, tex),
                                       ' + sheet (mixed, START_POINT_MODE all)' if args.mixed else '', args.obs_mode,
                                       ' + OVERLAP_PENALTY' if overlap else '', args.envs, act_desc)
-                                   + (", PAINT_METHOD='normal'" if args.paint_method == 'normal' else ''),
+                                   + (", PAINT_METHOD='normal'" if args.paint_method == 'normal' else '')
+                                   + (", COLOR_MODE='HSI'" if args.color_mode == 'HSI' else ''),
                        'envs_per_gpu': args.envs, 'env_steps_per_s': value * args.envs,
                        'part': args.part, 'texture': tex, 'samples': int(dt.n_samples), 'mask_words': int(env.mask_stride),
                        'stale_kd_nodes': len(getattr(tables, 'kd_split_dim', ())), 'collision_triangles': int(dt.n_collision),
@@ -582,7 +584,7 @@ def main():
                          'avg_kernel_us_sampled': sampled_us, 'sampled_launches': int(launches),
                          'second_bound': valu_issue_bound(avg_kernel_s * 1e6 if avg_kernel_s else None, args.obs_mode)
                          if (args.envs == ENVS_PER_GPU and not args.mixed and args.policy == 'random' and args.actions == 'random'
-                             and args.paint_method == 'fast' and len(subs) == 1 and not other_part) else
+                             and args.paint_method == 'fast' and len(subs) == 1 and not other_part and args.color_mode == 'RGB') else
                          (cone_second_bound(1e3 * ms_per_step) if (args.paint_method == 'normal' and args.envs == ENVS_PER_GPU
                                                                     and not args.mixed and len(subs) == 1) else None)},
         }

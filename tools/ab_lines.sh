@@ -8,4 +8,4 @@ for cfg in "" "--obs-mode grid" "--mixed" "--policy fragment" "--policy random-f
     for lib in "$@"; do echo "$(basename $lib) [$cfg] $(line $lib $cfg)"; done
   done
 done
-for p in square test; do for lib in "$@"; do echo "$(basename $lib) part_$p $(PAINTRL_LIB=$PWD/$lib python tools/bench_part.py $p --json 2>/dev/null | tail -1)"; done; done
+for p in square test; do for lib in "$@"; do echo "$(basename $lib) part_$p $(PAINTRL_LIB=$PWD/$lib python bench.py --part $p --steps 600 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200)"; done; done
