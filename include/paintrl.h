@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PRL_ABI_VERSION 2
+#define PRL_ABI_VERSION 3
 
 enum { PRL_OK = 0, PRL_E_INVALID = -1, PRL_E_HIP = -2, PRL_E_UNSUPPORTED = -3, PRL_E_NOMEM = -4 };
 enum { PRL_OBS_SECTION = 0, PRL_OBS_GRID = 1, PRL_OBS_SIMPLE = 2, PRL_OBS_DISCRETE = 3 };   /* rge:166-173 */

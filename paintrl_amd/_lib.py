@@ -93,7 +93,7 @@ SYMBOLS = {
     'prl_batch_timing_enable': (C.c_int, [_vp, C.c_int]),
     'prl_batch_timing_read': (C.c_int, [_vp, _dp, C.POINTER(C.c_int64)]),
 }
-ABI_VERSION = 2
+ABI_VERSION = 3          # 3: + prl_batch_step_occupancy, prl_batch_get_last_mask (round 5)
 _lib = None
 
 

@@ -46,7 +46,7 @@ inline DynLdsTable &dyn_lds_table() {
 inline size_t prl_static_lds(const void *kernel) {
     DynLdsTable &t = dyn_lds_table();
     std::lock_guard<std::mutex> lock(t.mu);
-    return t.entry(kernel, 0).static_lds;
+    return t.entry(kernel, 32 * 1024).static_lds;
 }
 
 // Makes sure `kernel` may be launched with `lds` bytes of dynamic LDS on the calling thread's current device.

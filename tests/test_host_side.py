@@ -95,7 +95,7 @@ def test_capi_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.prl_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.prl_abi_version() == _lib.ABI_VERSION == 3
     cfg = config.make_config(obs_mode='grid', obs_grad=4)
     assert lib.prl_obs_dim(cfg) == 16
     assert lib.prl_obs_dim(config.make_config(obs_mode='discrete')) == 5

@@ -107,7 +107,7 @@ def main():
               '(p100 - mean of the life: %.1f) | light envs %.1f %% | light waves on the launch\'s last SIMD: %s | waves w, w + 4 of a '
               'workgroup on one SIMD: %.0f %%' % (name, 1e3 * np.mean(ms), b2b, life.mean(), np.percentile(life, 99), life.max(), np.mean(spans),
                                                np.mean([l.max() - l.mean() for l in lives]), 100 * np.mean(light_frac),
-                                               dict(zip(*np.unique(last_light, return_counts=True))), 100 * np.mean(pair_same)))
+                                               {int(k): int(v) for k, v in zip(*np.unique(last_light, return_counts=True))}, 100 * np.mean(pair_same)))
 
 
 if __name__ == '__main__':
