@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void observe_kernel(StepArgs a) {
 
 // ---------------------------------------------------------------- step kernel (rge:349-368)
 // One launch = one batched step: one wavefront per env, WAVES envs per workgroup (prl_step.hpp holds the step).
-template <int KW, bool GENSEC, bool HSI = false, bool KD = false, int WAVES = STEP_WAVES_NARROW>
+template <int KW, bool GENSEC, bool HSI = false, bool KD = false, int WAVES = STEP_WAVES_NARROW, bool GRID = false>
 __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     // the one by-value argument, read in place (constant address space) wherever a field is needed
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     if constexpr (GENSEC) last_row_untracked(a, env, lane);      // (the atan2-sector kernels write the rows whole)
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
-    const int dn = step_env<KW, GENSEC, true, HSI, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,
+    const int dn = step_env<KW, GENSEC, true, HSI, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,
                                                       StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
@@ -178,6 +178,12 @@ typedef void (*StepKernelFn)(StepArgs);
 template <int WAVES>
 StepKernelFn pick_step(const PrlStepSel &sel) {
     constexpr int KW = PRL_KW;
+    if (sel.grid && !sel.gensec) {                 // OBS_MODE 'grid': the grid-only builds (atan2 sectors are a section / discrete matter)
+        if (sel.kd && sel.hsi) return step_kernel<KW, false, true, true, WAVES, true>;
+        if (sel.kd) return step_kernel<KW, false, false, true, WAVES, true>;
+        if (sel.hsi) return step_kernel<KW, false, true, false, WAVES, true>;
+        return step_kernel<KW, false, false, false, WAVES, true>;
+    }
     if (sel.kd && sel.hsi && sel.gensec) return step_kernel<KW, true, true, true, WAVES>;
     if (sel.kd && sel.hsi) return step_kernel<KW, false, true, true, WAVES>;
     if (sel.kd && sel.gensec) return step_kernel<KW, true, false, true, WAVES>;

@@ -801,6 +801,7 @@ PrlStepSel step_sel(const PrlBatch *b) {
     sel.hsi = b->cfg.color_mode == PRL_COLOR_HSI ? 1 : 0;
     sel.kd = b->kd ? 1 : 0;
     sel.wide = b->n_envs <= b->resident_envs ? 1 : 0;
+    sel.grid = b->cfg.obs_mode == PRL_OBS_GRID ? 1 : 0;
     return sel;
 }
 

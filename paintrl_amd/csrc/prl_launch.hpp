@@ -17,6 +17,7 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
     int hsi;                         // COLOR_MODE 'HSI'
     int kd;                          // some part carries the reference's stale vertex kd-tree
     int wide;                        // eight envs per workgroup (the whole launch is resident at once)
+    int grid;                        // OBS_MODE 'grid': the per-step kernel's grid-only build (the others carry every mode but grid)
 };
 
 #define PRL_K_PROTOS(KW)                                                                                               \

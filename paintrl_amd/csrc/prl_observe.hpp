@@ -432,20 +432,24 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
 
 // GENSEC selects the atan2-sector variant at compile time so that the default kernel carries none of
 // its registers or code.  Masks in registers (parts with at most 16 384 samples).
-template <int KW, bool GENSEC>
+// OBSM: which observation modes the instantiation carries -- -1: all of them, chosen at run time (rollout kernels, cone finish,
+// reset / observe); 0: every mode but 'grid'; 1: 'grid' only.  The per-step kernel is built once for each (round 5): with both
+// in one kernel the grid code's registers cost the section path 0.4 us (two spilled vector registers at the 128 ceiling),
+// profiles/r05_ab_log.txt.
+template <int KW, bool GENSEC, int OBSM = -1>
 __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
                                  const uint64_t painted[KW_MAX], int lane, double *out, int *cnt_lds) {
     double x1, x2, np0, np1;
     normalized_pose(P, C, pose, x1, x2, np0, np1);
-    const int mode = C.obs_mode;
-    if (mode == PRL_OBS_SIMPLE) {
+    const int mode = OBSM == 1 ? PRL_OBS_GRID : C.obs_mode;
+    if (OBSM != 1 && mode == PRL_OBS_SIMPLE) {
         if (lane == 0) {
             out[0] = np0;
             out[1] = np1;
         }
         return;
     }
-    if (mode == PRL_OBS_GRID) {                    // bpw:1126-1139: 1 - painted/num per cell
+    if (OBSM != 0 && mode == PRL_OBS_GRID) {       // bpw:1126-1139: 1 - painted/num per cell
         // 16 cells per pass: four packed accumulators, four DPP sums, then lane j finishes cell j (one division
         // per lane, one coalesced store)
         const int cells = P.n_obs_cells;
@@ -470,7 +474,9 @@ __device__ void observation_wave(PartRef P, CfgRef C, const double pose[3],
         }
         return;
     }
-    if constexpr (GENSEC) {                        // section / discrete with atan2 sectors (OBS_GRAD != 4)
+    if constexpr (OBSM == 1) {
+        return;                                    // (a grid-only instantiation has nothing below)
+    } else if constexpr (GENSEC) {                 // section / discrete with atan2 sectors (OBS_GRAD != 4)
         section_general_wave<KW>(P, C.obs_grad, x1, x2, painted, static_cast<const uint64_t *>(nullptr), lane, cnt_lds, out);
         if (lane == 0) section_pose_tail(mode, C.obs_grad, np0, np1, out);
         return;

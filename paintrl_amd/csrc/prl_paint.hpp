@@ -194,8 +194,13 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
     // TRIP rows per trip: lanes 0 .. 2 TRIP - 1 fetch the range bounds
     const int rcy = r0 + (lane >> 1);
     const bool ok = lane < 2 * TRIP && rcy <= row_hi && cx0 <= cx1;
+#ifdef PRL_GRID_LDS                                  // (A/B switch, k_step.hip: the table's LDS copy where the kernel has one)
     const int bidx = ok ? rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0) : 0;
-    const int bound = ok ? (sg_lds ? sg_lds[bidx] : ldg(P.sg_start, bidx)) : 0;      // (the table's LDS copy where the kernel has one)
+    const int bound = ok ? (sg_lds ? sg_lds[bidx] : ldg(P.sg_start, bidx)) : 0;
+#else
+    (void)sg_lds;
+    const int bound = ok ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
+#endif
     int rb[TRIP], re[TRIP];
 #pragma unroll
     for (int r = 0; r < TRIP; ++r) {

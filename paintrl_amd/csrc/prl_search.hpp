@@ -135,8 +135,13 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane, cons
         const int cx0 = icx - ring < 0 ? 0 : icx - ring, cx1 = icx + ring > P.vg_nx - 1 ? P.vg_nx - 1 : icx + ring;
         const int rcy = icy - ring + (lane >> 1);
         const bool okr = lane < 2 * nrows && rcy >= 0 && rcy < P.vg_ny && cx0 <= cx1;
+#ifdef PRL_GRID_LDS                                  // (A/B switch, k_step.hip: the table's LDS copy where the kernel has one)
         const int bidx = okr ? rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0) : 0;
-        const int bound = okr ? (vg_lds ? vg_lds[bidx] : ldg(P.vg_start, bidx)) : 0;       // (the table's LDS copy where the kernel has one)
+        const int bound = okr ? (vg_lds ? vg_lds[bidx] : ldg(P.vg_start, bidx)) : 0;
+#else
+        (void)vg_lds;
+        const int bound = okr ? ldg(P.vg_start, rcy * P.vg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
+#endif
         best_d = INFINITY;
         best_rank = 0x7fffffff;
         best_idx = -1;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void shots_end(PartRef P, EnvState &S, const ShotCtx 
 // termination (rge:321-340, 289-304), observation (rge:306-319), episode statistics, in-kernel auto-reset
 // (rge:370-387), masks back through `masks`.  `succeeded_f` = newly painted samples of the five shots (HSI: the float
 // sum of deposited fractions), `pixel_counter` = size of the union of the shots' valid sets (rob:425).  Returns done.
-template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, typename MaskIO, typename RowIO>
+template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, int OBSM = -1, typename MaskIO, typename RowIO>
 __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                            const double *state_rec, const MaskIO &masks, uint64_t painted[KW_MAX],
                                            uint64_t last[KW_MAX], double succeeded_f, int pixel_counter, int counter_before,
@@ -228,7 +228,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
 #endif
     if (term_row) {
         if constexpr (BIG) observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, term_row, wl.cnt, wl.cand);
-        else observation_wave<KW, GENSEC>(P, C, S.pose, painted, lane, term_row, wl.cnt);
+        else observation_wave<KW, GENSEC, OBSM>(P, C, S.pose, painted, lane, term_row, wl.cnt);
     }
     if (lane == 0) {
         a.reward()[env] = actual;
@@ -290,7 +290,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
 // copy all of it into registers at kernel entry.
 // HSI = COLOR_MODE 'HSI' (bpw:384-434): thickness bytes in a.thick, float "succeed counter" (prl_paint.hpp).
 // KD: parts of the batch may carry the reference's stale vertex kd-tree (prl_search.hpp nearest_vertex_kd).
-template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, typename MaskIO, typename RowIO>
+template <int KW, bool GENSEC, bool LATE_ACC, bool HSI, bool KD, int OBSM = -1, typename MaskIO, typename RowIO>
 __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int env, int lane, EnvState &S,
                                         const double *state_rec, const MaskIO &masks, double d1, double d2,
                                         double new_angle, const RowIO &a, const WaveLds &wl PROF_ARG) {
@@ -401,7 +401,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
         succeeded_f = (double)succeeded;
     }
     STAMP(PH_BALL);
-    return finish_step<KW, GENSEC, LATE_ACC, HSI>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
+    return finish_step<KW, GENSEC, LATE_ACC, HSI, OBSM>(P, C, part_id, env, lane, S, state_rec, masks, painted, last, succeeded_f,
                                                   pixel_counter, counter_before, new_angle, X.facet_hint, a, wl,
                                                   rows ? wl.lastrow + 64 * KW : nullptr PROF_PASS);
 }

@@ -24,7 +24,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tools'))
 from paintrl_amd import build as hb  # noqa: E402
 
-KERNEL = '_ZN12_GLOBAL__N_111step_kernelILi3ELb0ELb0ELb0ELi8E'       # step_kernel<3, false, false, false, 8>
+KERNEL = '_ZN12_GLOBAL__N_111step_kernelILi3ELb0ELb0ELb0ELi8ELb0E'   # step_kernel<3, false, false, false, 8, false>
 CLOCK_GHZ = 2.4
 N_SIMD = 1024
 
