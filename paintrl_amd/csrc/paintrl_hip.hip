@@ -1171,6 +1171,9 @@ static bool fused_rollout(const PrlBatch *b) {
     return c.color_mode == PRL_COLOR_RGB && c.paint_method == PRL_PAINT_FAST && !general_section(c);
 }
 
+// which build of a fused rollout kernel a batch takes (k_rollout.hip): bit 0 the stale kd-tree, bit 1 OBS_MODE 'grid'
+static int rollout_flags(const PrlBatch *b) { return (b->kd ? 1 : 0) | (b->cfg.obs_mode == PRL_OBS_GRID ? 2 : 0); }
+
 static int check_policy(const PrlBatch *b, const PrlPolicyWeights *w, const char *who) {
     const PrlConfig &c = b->cfg;
     if (!w->w1 || !w->b1 || !w->w2 || !w->b2 || !w->w3 || !w->b3) return fail(PRL_E_INVALID, "%s: null weights", who);
@@ -1210,7 +1213,7 @@ int prl_batch_act_step(PrlBatch *b, const PrlPolicyWeights *w, const double *obs
     f.rng_count = rng_count;
     f.rng_seed = rng_seed;
     const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
-    if (int e = PRL_KW_SWITCH(b->kw, act_step)(&f, lds, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_batch_act_step");
+    if (int e = PRL_KW_SWITCH(b->kw, act_step)(&f, lds, rollout_flags(b), stream)) return launch_failed(e, "prl_batch_act_step");
     return PRL_OK;
 }
 
@@ -1268,7 +1271,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
             g.rng_count = rng_count;
             g.rng_seed = rng_seed;
             const size_t lds = sizeof(float) * (size_t)policy_lds_layout(*w).floats;
-            if (int e = PRL_KW_SWITCH(b->kw, rollout_policy)(&g, lds, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_rollout_fragment");
+            if (int e = PRL_KW_SWITCH(b->kw, rollout_policy)(&g, lds, rollout_flags(b), stream)) return launch_failed(e, "prl_rollout_fragment");
             return PRL_OK;
         }
     }
@@ -1284,7 +1287,7 @@ int prl_rollout_fragment(PrlBatch *b, const PrlPolicyWeights *w, int n_steps, do
     f.action = action;
     const size_t lds = b->kw > KW_MAX ? 0 : (size_t)POLICY_WAVES * 2 * b->mask_stride * sizeof(uint64_t);
     if (lds > 120 * 1024) return fail(PRL_E_UNSUPPORTED, "prl_rollout_fragment: %zu bytes of LDS per workgroup", lds);
-    if (int e = PRL_KW_SWITCH(b->kw, rollout_fragment)(&f, b->kd ? 1 : 0, stream)) return launch_failed(e, "prl_rollout_fragment");
+    if (int e = PRL_KW_SWITCH(b->kw, rollout_fragment)(&f, rollout_flags(b), stream)) return launch_failed(e, "prl_rollout_fragment");
     return PRL_OK;
 }
 

@@ -28,9 +28,9 @@ struct PrlStepSel {                  // which instantiation of the step kernel a
     PRL_HIDDEN int prl_k##KW##_reset_obs(const void *part_dev, const void *cfg_dev, double *out, int n_start,          \
                                          int n_words, int gensec);                                                     \
     PRL_HIDDEN int prl_k##KW##_cone(const void *step_args, const PrlStepSel *sel, void *stream);                       \
-    PRL_HIDDEN int prl_k##KW##_act_step(const void *act_step_args, size_t policy_lds, int kd, void *stream);           \
-    PRL_HIDDEN int prl_k##KW##_rollout_policy(const void *policy_fragment_args, size_t policy_lds, int kd, void *stream); \
-    PRL_HIDDEN int prl_k##KW##_rollout_fragment(const void *fragment_args, int kd, void *stream);
+    PRL_HIDDEN int prl_k##KW##_act_step(const void *act_step_args, size_t policy_lds, int flags, void *stream);           \
+    PRL_HIDDEN int prl_k##KW##_rollout_policy(const void *policy_fragment_args, size_t policy_lds, int flags, void *stream); \
+    PRL_HIDDEN int prl_k##KW##_rollout_fragment(const void *fragment_args, int flags, void *stream);
 
 // PAINT_METHOD 'normal': the tool path and the beams of a step (k_cone_beams.hip); prl_k<KW>_cone finishes it
 PRL_HIDDEN int prl_kc_path(const void *step_args, int kd, int wide, void *stream);
