@@ -59,7 +59,7 @@ __device__ __forceinline__ BigMasks big_masks(const StepArgs CAS &a, int env, in
 #ifndef PRL_BIG_OCC
 #define PRL_BIG_OCC 4                  // waves a SIMD the large parts' step is compiled for (A/B: 3 = 168 registers)
 #endif
-template <bool GENSEC, bool KD, int WAVES>
+template <bool GENSEC, bool KD, int WAVES, bool GRID = false>
 __global__ __launch_bounds__(64 * WAVES, PRL_BIG_OCC) void step_kernel_big(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64 * WAVES, PRL_BIG_OCC) void step_kernel_big(StepA
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     PROF_BEGIN();                                    // (trace builds: tools/wave_trace.py with --diag-unit k_big)
-    const int dn = step_env<0, GENSEC, true, false, KD>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
-                                                      new_angle, StepRows{&a}, wl PROF_PASS);
+    const int dn = step_env<0, GENSEC, true, false, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+                                                                    new_angle, StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
     STAMP(PH_STORE);
     PROF_END();
@@ -317,6 +317,7 @@ typedef void (*BigStepFn)(StepArgs);
 template <int WAVES>
 BigStepFn pick_big_step(const PrlStepSel &sel) {           // COLOR_MODE 'RGB': rows in HBM
     const bool gs = sel.gensec != 0;
+    if (sel.grid && !gs) return sel.kd ? step_kernel_big<false, true, WAVES, true> : step_kernel_big<false, false, WAVES, true>;      // (per observation family)
     return sel.kd ? (gs ? step_kernel_big<true, true, WAVES> : step_kernel_big<false, true, WAVES>)
                   : (gs ? step_kernel_big<true, false, WAVES> : step_kernel_big<false, false, WAVES>);
 }

@@ -715,13 +715,13 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
 // (`const uint64_t *`) or the env's row in HBM (`uint64_t GAS *`: coalesced 8-byte loads, 8.9 KB per env-step at 71 000
 // samples) -- walked 64 words per lane slot; counts can exceed 16 bits, so the per-lane 16-bit fields (at most 64 x 25 per
 // lane) are split into 32-bit halves before the wave sums.
-template <bool GENSEC, typename PW>
+template <bool GENSEC, int OBSM = -1, typename PW>
 __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW painted, int lane,
                                 double *out, int *cnt_lds, int *list_lds /* this wave's 64-int row (WaveLds::cand) */) {
     double x1, x2, np0, np1;
     normalized_pose(P, C, pose, x1, x2, np0, np1);
-    const int mode = C.obs_mode;
-    if (mode == PRL_OBS_SIMPLE) {
+    const int mode = OBSM == 1 ? PRL_OBS_GRID : C.obs_mode;       // (OBSM: observation_wave)
+    if (OBSM != 1 && mode == PRL_OBS_SIMPLE) {
         if (lane == 0) {
             out[0] = np0;
             out[1] = np1;
@@ -729,7 +729,7 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW pa
         return;
     }
     const int n_slots = (P.n_words + 63) >> 6;
-    if (mode == PRL_OBS_GRID) {
+    if (OBSM != 0 && mode == PRL_OBS_GRID) {
         const int cells = P.n_obs_cells;
         for (int c0 = 0; c0 < cells; c0 += 16) {
             uint64_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};       // 2 x 32-bit per u64: fields 0,1 and 2,3 of acc
@@ -764,7 +764,9 @@ __device__ void observation_big(PartRef P, CfgRef C, const double pose[3], PW pa
         }
         return;
     }
-    if constexpr (GENSEC) {
+    if constexpr (OBSM == 1) {
+        return;
+    } else if constexpr (GENSEC) {
         const uint64_t none[KW_MAX] = {0, 0, 0, 0};
         section_general_wave<1>(P, C.obs_grad, x1, x2, none, painted, lane, cnt_lds, out);
         if (lane == 0) section_pose_tail(mode, C.obs_grad, np0, np1, out);

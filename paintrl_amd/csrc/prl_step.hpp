@@ -227,7 +227,7 @@ __device__ __forceinline__ int finish_step(PartRef P, CfgRef C, int part_id, int
     term_row = nullptr;
 #endif
     if (term_row) {
-        if constexpr (BIG) observation_big<GENSEC>(P, C, S.pose, masks.painted, lane, term_row, wl.cnt, wl.cand);
+        if constexpr (BIG) observation_big<GENSEC, OBSM>(P, C, S.pose, masks.painted, lane, term_row, wl.cnt, wl.cand);
         else observation_wave<KW, GENSEC, OBSM>(P, C, S.pose, painted, lane, term_row, wl.cnt);
     }
     if (lane == 0) {
