@@ -221,7 +221,7 @@ def test_soak_many_steps_equals_oracle(part, starts, seed):
 
 
 @pytest.mark.skipif(not __import__('os').environ.get('PAINTRL_SOAK_STEPS'), reason='soak run: set PAINTRL_SOAK_STEPS (e.g. 400)')
-@pytest.mark.parametrize('case', ['grid_overlap_turning', 'mixed', 'cone_beams'])
+@pytest.mark.parametrize('case', ['grid_overlap_turning', 'mixed', 'cone_beams', 'large_part'])
 def test_soak_other_configurations_equal_oracle(case):
     """The soak run for BASELINE configs 3 (grid + penalties), 5 (mixed door / sheet) and the cone-beam painter (a twentieth
     of the steps: its oracle is the slow one)."""
@@ -230,7 +230,15 @@ def test_soak_other_configurations_equal_oracle(case):
     steps = int(os.environ['PAINTRL_SOAK_STEPS'])
     n = 4096
     door = synthetic_tables('door_test')
-    if case == 'mixed':
+    if case == 'large_part':                       # 38 224 samples (mask rows in HBM), OVERLAP_PENALTY on, a fifth of the steps
+        big = synthetic_tables('door_rr_big', tex_size=(480, 480))
+        sp = start_points_for(big, 'all')
+        mpp = int(0.95 * big.sample_pos.shape[0])
+        steps = max(20, steps // 5)
+        env = BatchedPaintEnv(_dt(big, sp), n, auto_reset=True, overlap_penalty=True, max_possible_point=mpp)
+        orc = oracle.Oracle(big, n, start_points=sp, threads=16, overlap_penalty=True, max_possible_point=mpp)
+        n_start = np.full(n, len(sp))
+    elif case == 'mixed':
         sheet = synthetic_tables('square')
         sp_d, sp_s = start_points_for(door, 'all'), start_points_for(sheet, 'all')
         ids = (np.arange(n) % 2).astype(np.int32)
