@@ -245,6 +245,20 @@ class PaintGymEnv(spaces.Env):
             self._batch.close()
             self._batch = None
 
+    @classmethod
+    def make_batched(cls, n_envs, device=None, auto_reset=False, seed=0, **env_config):
+        """The BatchedPaintEnv of ``n_envs`` environments that PaintGymEnv(**env_config) would be ONE of: same part, class
+        attributes (OBS_MODE, ACTION_MODE ...), EXTRA_CONFIG and Robot.PAINT_METHOD; the part's tables are built once.
+        ``env_config`` is what paint_ppo.py:84-123 hands to ``env_creator`` (use with_robot=False)."""
+        from .batched_env import BatchedPaintEnv
+        one = cls(device=device, **env_config)
+        try:
+            kw = dict(one._batch.cfg_kwargs)
+            kw.update(auto_reset=bool(auto_reset), seed=int(seed))
+            return BatchedPaintEnv(one._batch.parts, int(n_envs), device=one._batch.device, **kw)
+        finally:
+            one.close()
+
     def seed(self, seed=None):
         return spaces.np_random(seed)[1]
 

@@ -198,3 +198,35 @@ def test_texture_image_equals_the_reference(urdf_root, tag, name, color_mode):
     img = env.get_texture_image()
     assert img.dtype == np.uint8 and np.array_equal(img, want[name])
     env.close()
+
+
+def test_rllib_vector_env_adaptor_equals_the_single_env_wrapper(urdf_root):
+    """paintrl_amd.rllib_env.PaintVectorEnv (RLlib's VectorEnv method names and return conventions; `ray` itself is not
+    installed here, the class then derives from object) around PaintGymEnv.make_batched: every sub-environment behaves as the
+    one-env PaintGymEnv does -- same observations, rewards, dones and info dicts on the same actions from the same start."""
+    from paintrl_amd import PaintGymEnv
+    from paintrl_amd.rllib_env import PaintVectorEnv
+    PaintGymEnv.change_action_mode(1, 'discrete', 4)
+    PaintGymEnv.change_obs_mode('section', 4)
+    cfg = dict(urdf_root=urdf_root, with_robot=False, renders=False, rollout=True)     # rollout=True: the fixed first start point
+    venv = PaintVectorEnv.from_env_config(cfg, num_envs=5)
+    assert venv.num_envs == 5 and venv.action_space.n == 4 and venv.observation_space.shape == (6,)
+    one = PaintGymEnv(**cfg)
+    o1 = one.reset()
+    obs = venv.vector_reset()
+    # (the library draws the vector env's start points itself: put sub-env 0 on the single env's start)
+    row = venv.env.reset_at(0, start_idx=0).cpu().numpy()
+    assert np.array_equal(row, o1)
+    rng = np.random.RandomState(0)
+    for k in range(12):
+        a = rng.randint(0, 4, size=5)
+        obs, rew, done, info = venv.vector_step(a)
+        o, r, d, i = one.step(int(a[0]))
+        assert np.array_equal(obs[0], o) and rew[0] == r and done[0] == d and info[0] == i, k
+        assert isinstance(rew[1], float) and isinstance(done[1], bool) and set(info[1]) == {'reward', 'penalty'}
+        if d:
+            break
+    assert venv.get_sub_environments() == []
+    assert venv.reset_at(3).shape == (venv.env.obs_dim,)
+    venv.close()
+    one.close()
