@@ -135,7 +135,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void step_kernel(StepArgs) {
     if (slot_ >= a.n_envs) return;
     const int env = rfl(g_env_perm ? g_env_perm[slot_] : slot_);
 #else
-    const int env = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    const int slot = rfl(blockIdx.x * WAVES + (threadIdx.x >> 6));
+    if (slot >= a.n_envs) return;
+    const int env = a.slot_env ? rfl(a.slot_env[slot]) : slot;      // (mixed batches: StepArgs::slot_env)
 #endif
     if (env >= a.n_envs) return;
     // (round 3 parked the last-shot masks of the four-word kernels in LDS rows -- prl_paint.hpp RowWords, WaveLds::lastrow --

@@ -93,6 +93,7 @@ struct PrlBatch {
     PartDev *parts_dev = nullptr;
     CfgDev *cfg_dev = nullptr;
     int *env_part_dev = nullptr;
+    int *slot_env_dev = nullptr;          // StepArgs::slot_env (batches of several parts)
     uint64_t *painted = nullptr, *last = nullptr;
     uint64_t *last_nz = nullptr;          // StepArgs::last_nz
     int nz_stride = 0;                    // words of it per env: KW_MAX (register-resident masks), (mask_stride + 63) / 64 (large parts)
@@ -766,6 +767,7 @@ StepArgs base_args(PrlBatch *b) {
     a.parts = b->parts_dev;
     a.cfg = b->cfg_dev;
     a.env_part = b->env_part_dev;
+    a.slot_env = b->slot_env_dev;
     a.n_envs = b->n_envs;
     a.mask_stride = b->mask_stride;
     a.painted = b->painted;
@@ -926,6 +928,30 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
     if (e == hipSuccess && env_part_id) {
         e = hipMalloc(reinterpret_cast<void **>(&b->env_part_dev), sizeof(int) * n_envs);
         if (e == hipSuccess) e = hipMemcpy(b->env_part_dev, env_part_id, sizeof(int) * n_envs, hipMemcpyHostToDevice);
+#ifndef PRL_NO_XCD_PARTS                             // (A/B switch)
+        if (e == hipSuccess && n_parts > 1) {
+            // XCD-aware placement of a mixed batch.  Workgroup b of a launch runs on XCD b % 8, and every XCD has its own 4 MB L2:
+            // with the envs of all parts spread evenly over the workgroups each L2 has to hold every part's tables (door + sheet:
+            // 5 MB) and the waves' dependent look-ups miss.  The wave slots of the workgroups of one XCD are therefore handed
+            // consecutive envs of the batch SORTED BY PART: an XCD then works on one part (two at a seam).  Results do not depend
+            // on which wave steps an env.
+            constexpr int N_XCD = 8;
+            const int waves = n_envs <= b->resident_envs ? STEP_WAVES_WIDE : STEP_WAVES_NARROW;      // (step_sel: the launch shape of this batch)
+            const int n_wg = (n_envs + waves - 1) / waves;
+            std::vector<int> sorted((size_t)n_envs), slot_env((size_t)n_envs, 0);
+            for (int i = 0; i < n_envs; ++i) sorted[(size_t)i] = i;
+            std::stable_sort(sorted.begin(), sorted.end(), [&](int x, int y) { return env_part_id[x] < env_part_id[y]; });
+            size_t next = 0;
+            for (int x = 0; x < N_XCD; ++x)
+                for (int wg = x; wg < n_wg; wg += N_XCD)
+                    for (int w = 0; w < waves; ++w) {
+                        const int slot = wg * waves + w;
+                        if (slot < n_envs) slot_env[(size_t)slot] = sorted[next++];
+                    }
+            e = hipMalloc(reinterpret_cast<void **>(&b->slot_env_dev), sizeof(int) * n_envs);
+            if (e == hipSuccess) e = hipMemcpy(b->slot_env_dev, slot_env.data(), sizeof(int) * n_envs, hipMemcpyHostToDevice);
+        }
+#endif
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->painted), mask_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->last), mask_bytes);
@@ -987,6 +1013,7 @@ void prl_batch_destroy(PrlBatch *b) {
     (void)hipFree(b->parts_dev);
     (void)hipFree(b->cfg_dev);
     (void)hipFree(b->env_part_dev);
+    (void)hipFree(b->slot_env_dev);
     (void)hipFree(b->painted);
     (void)hipFree(b->last);
     (void)hipFree(b->last_nz);

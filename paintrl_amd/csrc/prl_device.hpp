@@ -160,6 +160,8 @@ struct StepArgs {
     const PartDev *parts;
     const CfgDev *cfg;
     const int *env_part;          // device, or nullptr
+    const int *slot_env;          // device, or nullptr: step_kernel's wave slot -> env (mixed batches: every XCD's workgroups get the
+                                  // envs of as few parts as possible, so that its L2 holds one part's tables; paintrl_hip.hip)
     int n_envs, mask_stride;
     uint64_t *painted, *last;
     uint64_t *last_nz;            // [n_envs][nz_stride]: bit w & 63 of word w >> 6 = word w of the env's last-shot row is not zero (every
