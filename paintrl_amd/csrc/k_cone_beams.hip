@@ -423,7 +423,24 @@ __global__ __launch_bounds__(64 * FAR_WAVES, PRL_FAR_OCC) void cone_far_kernel(S
 #if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
     const unsigned long long far_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef PRL_FAR_LOCAL_QUEUE
+    // [A/B switch] The chunks of 16 points handed out dynamically INSIDE a workgroup: workgroup g owns the contiguous chunk range
+    // [total g / G, total (g + 1) / G) and its four waves draw from it through an LDS counter -- a wave that drew a long search
+    // (a point far from every sample: ten rounds down the pyramid instead of five) does not also get a second one by its index.
+    __shared__ int s_next;
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    const int c_lo = (int)((long long)lists.total * blockIdx.x / gridDim.x), c_hi = (int)((long long)lists.total * (blockIdx.x + 1) / gridDim.x);
+    (void)wave;
+    (void)n_waves;
+    for (;;) {
+        int k_ = 0;
+        if (lane == 0) k_ = atomicAdd(&s_next, 1);
+        const int chunk = c_lo + rfl(k_);
+        if (chunk >= c_hi) break;
+#else
     for (int chunk = wave; chunk < lists.total; chunk += n_waves) {
+#endif
         CONE_TIME_BEGIN();
         int sub, j, count;
         lists.find(chunk, sub, j, count);
@@ -577,7 +594,20 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
     hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
+#ifdef PRL_FAR_LOCAL_QUEUE
+    {   // as many workgroups as the chip holds at once (PRL_FAR_OCC waves a SIMD): each works its own slice of the chunks off
+        static int resident_wgs = 0;
+        if (!resident_wgs) {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            resident_wgs = cus * 4 * PRL_FAR_OCC / FAR_WAVES;
+        }
+        hipLaunchKernelGGL(cone_far_kernel, dim3(resident_wgs), dim3(64 * FAR_WAVES), 0, s, a);
+    }
+#else
     hipLaunchKernelGGL(cone_far_kernel, dim3(FAR_WGS * 4 / FAR_WAVES), dim3(64 * FAR_WAVES), 0, s, a);
+#endif
     return (int)hipGetLastError();
 }
 
