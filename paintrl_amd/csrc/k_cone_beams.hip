@@ -404,6 +404,12 @@ __global__ __launch_bounds__(64 * BEAM_WAVES, PRL_BEAM_OCC) void cone_beams_kern
 //                     has its wave at once.
 // (Side by side on two streams they took as long as the longer one plus ~25 us of fork and join; the rays' own far points
 // searched inside the rest kernel made that the longer one.)
+template <bool PUSH>
+__device__ __forceinline__ void cone_rest_work(const StepArgs CAS &a, int first, int stride, int lane, int *fr, const WaveLds &wl);
+
+#if defined(PRL_CONE_TAIL_MERGED) && !defined(PRL_FAR_OCC)
+#define PRL_FAR_OCC 4                 // (the rays' wave-wide search needs the registers; the far search runs as fast at four waves a SIMD)
+#endif
 #ifndef PRL_FAR_OCC
 #define PRL_FAR_OCC 6                 // (80 registers: at 8 waves a SIMD the search spills; 45 -> 40 us)
 #endif
@@ -418,6 +424,12 @@ __global__ __launch_bounds__(64 * FAR_WAVES, PRL_FAR_OCC) void cone_far_kernel(S
     int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
     const int wave = rfl(blockIdx.x * FAR_WAVES + (threadIdx.x >> 6)), n_waves = 4 * FAR_WGS;
     const int far_cap = a.cone_work[2];
+#ifdef PRL_CONE_TAIL_MERGED
+    // [A/B switch] the rest kernel's work inside this launch (no separate launch): leftover rays and trips go to the waves from
+    // the TOP of the grid down -- the launch's second generation of waves, which have one far chunk each -- and a ray's hit
+    // point that needs the far search gets it at once (nothing is pushed: the far counters are final when this kernel starts)
+    cone_rest_work<false>(a, n_waves - 1 - wave, n_waves, lane, fr, wave_lds<false, false, 0, FAR_WAVES>());
+#endif
     SubLists lists;
     lists.load(far_counters(a), far_cap, BFS_N, lane);
 #if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 4
@@ -479,15 +491,15 @@ __global__ __launch_bounds__(64 * FAR_WAVES, PRL_FAR_OCC) void cone_far_kernel(S
     }
 }
 
-__global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
-    __shared__ int s_bfs[4 * BFS_LDS_INTS];
-    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = threadIdx.x & 63;
-    int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
-    const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * REST_WGS;
-    const WaveLds wl = wave_lds<false, false>();
+// The leftover work of the beams kernel for the waves [0, n_waves): whole trips of the trip list through the general code, single
+// leftover rays through the wave-wide closest-hit search.  PUSH: a ray's hit point that one ring of the fine grid does not
+// settle joins the far list (the rest kernel, which runs BEFORE the far kernel); otherwise it is searched here at once (the
+// merged tail kernel: the far list is being emptied by other waves of the same launch).  This wave takes items first, first +
+// stride, ... of both lists.
+template <bool PUSH>
+__device__ __forceinline__ void cone_rest_work(const StepArgs CAS &a, int first, int stride, int lane, int *fr, const WaveLds &wl) {
     const int n_work = rfl(a.cone_work[0]);
-    for (int i = wave; i < n_work; i += n_waves) {
+    for (int i = first; i < n_work; i += stride) {
         const int item = rfl(a.cone_work[4 + i]);
         int env, shot, b0;
         if (!beam_item(a, item, env, shot, b0)) continue;
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
     SubLists lists;
     lists.load(ray_counters(a), ray_sub_cap(a), 1, lane);
     const int *rays = ray_list(a);
-    for (int i = wave; i < lists.total; i += n_waves) {
+    for (int i = first; i < lists.total; i += stride) {
         int sub, j, count;
         lists.find(i, sub, j, count);
         const int entry = rfl(rays[2 * ((size_t)sub * ray_sub_cap(a) + j)]), walk_facet = rfl(rays[2 * ((size_t)sub * ray_sub_cap(a) + j) + 1]);
@@ -526,38 +538,45 @@ __global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
         bool pushed = false;
         if (!beam_outside_outline_wave(P, pos, dst, lane)) {
             double tw, hw[3];
-#if defined(PRL_CONE_TRACE) && PRL_CONE_TRACE == 3
-            const unsigned long long ray_t0_ = __builtin_amdgcn_s_memrealtime();
-            const int hit_ = ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand);
-            CONE_HIST(3, 63 - __builtin_clzll((__builtin_amdgcn_s_memrealtime() - ray_t0_) | 1));
-            if (hit_ >= 0) {
-#else
             if (ray_closest_wave(P, pos, dst, lane, tw, hw, hint, wl.cand) >= 0) {
-#endif
-                float hint;
-                sidx = nearest_sample_lane_f32(P, hw, true, hint);      // (every lane the same query)
+                float hintf;
+                sidx = nearest_sample_lane_f32(P, hw, true, hintf);      // (every lane the same query)
                 if (sidx == -2) {
-                    // a hit point far from every sample: one more entry of the far list (the far kernel runs after this one)
-                    const int sub = blockIdx.x & (WORK_LISTS - 1), far_cap = a.cone_work[2];
-                    int slot = 0;
-                    if (lane == 0) slot = atomicAdd(far_counters(a) + 16 * sub, 1);
-                    slot = rfl(slot);
-                    if (slot < far_cap) {
-                        if (lane == 0) {
-                            f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * ((size_t)sub * far_cap + slot);
-                            e[0] = f64x2{hw[0], hw[1]};
-                            e[1] = f64x2{hw[2], __hiloint2double(__float_as_int(hint), (int)(((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm))};
+                    bool search_here = !PUSH;
+                    if constexpr (PUSH) {
+                        // a hit point far from every sample: one more entry of the far list (the far kernel runs after this one)
+                        const int fsub = blockIdx.x & (WORK_LISTS - 1), far_cap = a.cone_work[2];
+                        int slot = 0;
+                        if (lane == 0) slot = atomicAdd(far_counters(a) + 16 * fsub, 1);
+                        slot = rfl(slot);
+                        if (slot < far_cap) {
+                            if (lane == 0) {
+                                f64x2 *e = reinterpret_cast<f64x2 *>(a.cone_far) + 2 * ((size_t)fsub * far_cap + slot);
+                                e[0] = f64x2{hw[0], hw[1]};
+                                e[1] = f64x2{hw[2], __hiloint2double(__float_as_int(hintf), (int)(((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm))};
+                            }
+                            pushed = true;
+                        } else {
+                            search_here = true;                          // (the sub-list is full)
                         }
-                        pushed = true;
-                    } else {                                             // (the sub-list is full: searched here)
-                        sidx = nearest_sample_groups(P, hw, lane < BFS_G, hint, lane, fr);
                     }
+                    if (search_here) sidx = nearest_sample_groups(P, hw, lane < BFS_G, hintf, lane, fr);
                 }
             }
         }
         if (lane == 0 && !pushed) a.cone_hits[((size_t)env * PAINT_PER_ACTION + shot) * a.cone_nb + bm] = sidx;
         CONE_TIME_END(1);
     }
+}
+
+__global__ __launch_bounds__(256, 4) void cone_rest_kernel(StepArgs) {
+    __shared__ int s_bfs[4 * BFS_LDS_INTS];
+    const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    int *fr = s_bfs + (threadIdx.x >> 6) * BFS_LDS_INTS;
+    const int wave = rfl(blockIdx.x * 4 + (threadIdx.x >> 6)), n_waves = 4 * REST_WGS;
+    const WaveLds wl = wave_lds<false, false>();
+    cone_rest_work<true>(a, wave, n_waves, lane, fr, wl);
 }
 
 }  // namespace
@@ -593,7 +612,9 @@ PRL_HIDDEN int prl_kc_beams(const void *step_args, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long items = (long long)a.n_envs * PAINT_PER_ACTION * (a.cone_nb >> 6);
     hipLaunchKernelGGL(cone_beams_kernel, dim3((unsigned)((items + BEAM_WAVES - 1) / BEAM_WAVES)), dim3(64 * BEAM_WAVES), 0, s, a);
+#ifndef PRL_CONE_TAIL_MERGED
     hipLaunchKernelGGL(cone_rest_kernel, dim3(REST_WGS), dim3(256), 0, s, a);
+#endif
 #ifdef PRL_FAR_LOCAL_QUEUE
     {   // as many workgroups as the chip holds at once (PRL_FAR_OCC waves a SIMD): each works its own slice of the chunks off
         static int resident_wgs = 0;
