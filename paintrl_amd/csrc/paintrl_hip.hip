@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdarg>
+#include <limits>
 #include <map>
 #include <new>
 #include <vector>
@@ -268,6 +269,74 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
             }
             UP(kd_rec, kr.data(), kr.size());
             d.n_kd_points = t->n_kd_points;
+        }
+        {   // the same tree for the lane-parallel query (prl_search.hpp nearest_vertex_kd_lanes): one lane per node, the leaves'
+            // points in rows of sixteen.  Children follow their parents (checked above), so one pass in index order sees a
+            // node's parent first; anything that is not a tree of small leaves keeps the general walk.
+            const int n = d.n_kd_nodes;
+            bool ok = n <= 64;
+            std::vector<int> parent((size_t)n, 0), depth((size_t)n, 0), lesser((size_t)n, 0), ordinal((size_t)n, -1), seen((size_t)n, 0);
+            int n_leaves = 0, deepest = 0;
+            seen[0] = 1;
+            for (int i = 0; ok && i < n; ++i) {
+                const int32_t *nd = t->kd_node + 4 * (size_t)i;
+                if (!seen[(size_t)i]) ok = false;
+                else if (nd[0] < 0) {
+                    int live = 0;                                    // (rows parked at (10, 10, 10) are never the nearest: left out --
+                    for (int pt = nd[1]; pt < nd[2]; ++pt) live += t->kd_points[pt] >= 0;     // scipy keeps them all in ONE leaf)
+                    ok = live <= 16;
+                    ordinal[(size_t)i] = n_leaves++;
+                } else
+                    for (int k = 1; k <= 2 && ok; ++k) {
+                        const int c = nd[k];
+                        if (seen[(size_t)c]) ok = false;
+                        seen[(size_t)c] = 1;
+                        parent[(size_t)c] = i;
+                        depth[(size_t)c] = depth[(size_t)i] + 1;
+                        lesser[(size_t)c] = k == 1;
+                        deepest = std::max(deepest, depth[(size_t)c]);
+                    }
+            }
+            ok = ok && n_leaves <= 32 && d.n_vertices < (1 << 28);
+            if (ok) {
+                std::vector<int32_t> kl((size_t)n * 4, 0);
+                // (padding: points at +inf with vertex 0 -- their distance is +inf, never below the best; whole trips of 64 slots)
+                const size_t slots16 = ((size_t)n_leaves * 16 + 63) / 64 * 64;
+                std::vector<double> k16(slots16 * 4, std::numeric_limits<double>::infinity());
+                for (size_t q = 0; q < slots16; ++q) k16[q * 4 + 3] = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const int32_t *nd = t->kd_node + 4 * (size_t)i;
+                    const bool leaf = nd[0] < 0;
+                    const int pa = parent[(size_t)i], psd = i ? t->kd_node[4 * (size_t)pa] : 0;
+                    kl[4 * (size_t)i] = (leaf ? 3 : nd[0]) | (psd << 2) | (lesser[(size_t)i] << 4) | (depth[(size_t)i] << 5) | (pa << 11) |
+                                        ((leaf ? 0 : nd[1]) << 17) | ((leaf ? 0 : nd[2]) << 23);
+                    kl[4 * (size_t)i + 1] = ordinal[(size_t)i];
+                    const double psp = i ? t->kd_split[pa] : 0.0;
+                    std::memcpy(&kl[4 * (size_t)i + 2], &psp, sizeof psp);
+                    if (leaf) {
+                        int j = 0;
+                        for (int pt = nd[1]; pt < nd[2]; ++pt) {     // the live points in tree order, then padding
+                            const int v = t->kd_points[pt];
+                            if (v < 0) continue;
+                            double *r = &k16[((size_t)ordinal[(size_t)i] * 16 + (size_t)j++) * 4];
+                            for (int k = 0; k < 3; ++k) r[k] = t->vertex_xyz[k][v];
+                            const int32_t pair[2] = {v, i};
+                            std::memcpy(r + 3, pair, sizeof pair);
+                        }
+                    }
+                }
+                std::vector<uint64_t> anc((size_t)n, 0);
+                for (int i = 1; i < n; ++i) {
+                    const int dim = t->kd_node[4 * (size_t)parent[(size_t)i]];
+                    for (int c = parent[(size_t)i]; c != 0; c = parent[(size_t)c])
+                        if (t->kd_node[4 * (size_t)parent[(size_t)c]] == dim) anc[(size_t)i] |= 1ull << c;
+                }
+                UP(kd_anc, anc.data(), anc.size());
+                UP(kd_lane, kl.data(), kl.size());
+                UP(kd_rec16, k16.data(), k16.size());
+                d.n_kd_leaves = n_leaves;
+                d.kd_depth = deepest;
+            }
         }
         for (int k = 0; k < 6; ++k) d.kd_box[k] = t->kd_box[k];
     }

@@ -110,6 +110,16 @@ struct PartDev {
     gint_p kd_points;
     gdouble_p kd_rec;             // [n_kd_points][4]: x y z | {i32 vertex or -1, i32 the leaf's node} of the leaves' points in tree order (derived in part_fill)
     int n_kd_points;
+    // the tree for the lane-parallel query (nearest_vertex_kd_lanes; derived in part_fill when it has <= 64 nodes, <= 32 leaves of
+    // <= 16 points): node n's static word for lane n {split dim or 3 | parent's dim << 2 | lesser child << 4 | depth << 5 |
+    // parent << 11 | lesser << 17 | greater << 23, the leaf's ordinal or -1, the parent's split value}; the leaves' points as
+    // x y z | vertex in rows of 16 (leaf ordinal * 16, padded with vertex -1)
+    gint_p kd_lane;
+    gu64_p kd_anc;                // [n] the nodes on the way from the root to node n's parent (root excluded) that were reached across a plane of
+                                  // the same dimension as node n was: the deepest of them that the query reached as the FAR child set the old side distance
+    gdouble_p kd_rec16;
+    int n_kd_leaves;              // 0: no such tables
+    int kd_depth;
     double kd_box[6];
     int n_triangles;
     gdouble_p tri_rec;            // [n_triangles][TRI_REC]: the 16 doubles of the host table + derived tail (part_fill)

@@ -155,7 +155,10 @@ __device__ __forceinline__ void pair_sub_shot(PartRef P, int lane, PairCtx &X, c
             for (int hh = 0; hh < 2; ++hh) {
                 if (!((want >> (32 * hh)) & 1)) continue;
                 const double p_u[3] = {bcast_d(hit[0], 32 * hh), bcast_d(hit[1], 32 * hh), bcast_d(hit[2], 32 * hh)};
-                const int v = nearest_vertex_kd(P, p_u, lane, wl.kd_heap, wl.kd_staged != 0);
+#if defined(PRL_WAVE_TRACE) || defined(PRL_PHASE_TIMING)
+                Prof prof = {};                                      // (the query's own stamps are the step kernel's; unused here)
+#endif
+                const int v = nearest_vertex_kd(P, p_u, lane, wl.kd_heap, wl.kd_staged != 0 PROF_PASS);
                 if (upper == (hh == 1)) vidx = v;
             }
             vdone = true;

@@ -181,11 +181,23 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane, cons
 // The tree of a coarse part is tiny (the reference's sheet: 33 nodes) and every query walks it node by node, two dependent
 // global round trips a level.  kd_stage copies trees of up to KD_LDS_NODES nodes into this wave's LDS once per step (behind
 // the queue in `heap`); the walk then reads its nodes from there.
+__device__ __forceinline__ bool kd_lanes_on(PartRef P) {
+#if defined(PRL_KD_SCAN_LEAVES) || defined(PRL_KD_LDS_WALK)      // (parity / A-B switches: the general walk for every tree)
+    return false;
+#else
+    return P.n_kd_leaves > 0;
+#endif
+}
 __device__ __forceinline__ void kd_stage(PartRef P, double *heap, int lane) {
     if (P.n_kd_nodes > 0 && P.n_kd_nodes <= KD_LDS_NODES) {
         if (lane < P.n_kd_nodes) {
-            reinterpret_cast<i32x4 *>(heap + KD_HEAP * 5)[lane] = ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), lane);
-            heap[KD_HEAP * 5 + 2 * KD_LDS_NODES + lane] = ldg(P.kd_split, lane);
+            if (kd_lanes_on(P)) {                                   // (the lane-parallel query reads its own tables, and nothing else)
+                reinterpret_cast<i32x4 *>(heap + KD_HEAP * 5)[lane] = ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_lane), lane);
+                reinterpret_cast<uint64_t *>(heap)[lane] = ldg(P.kd_anc, lane);       // (where the general walk keeps its queue)
+            } else {
+                reinterpret_cast<i32x4 *>(heap + KD_HEAP * 5)[lane] = ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), lane);
+                heap[KD_HEAP * 5 + 2 * KD_LDS_NODES + lane] = ldg(P.kd_split, lane);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -201,7 +213,7 @@ __device__ __forceinline__ void kd_stage(PartRef P, double *heap, int lane) {
 // distances are >= +0: they order like unsigned integers), the first point reaching it a second one on (point << 32 | vertex).
 // The walk then reads a leaf's result from LDS: same visiting order, same strict comparisons, same answer.
 // lmin[node], lfirst[node]: this wave's rows behind the staged tree (KD_ROW).
-__device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], int lane, unsigned long long *lmin, unsigned long long *lfirst) {
+__device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], int lane, unsigned long long *lmin, unsigned long long *lfirst PROF_ARG) {
     if (lane < P.n_kd_nodes) {
         lmin[lane] = 0x7ff0000000000000ull;          // +inf
         lfirst[lane] = ~0ull;
@@ -226,6 +238,7 @@ __device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], i
         const unsigned long long bits = measure(p0 + lane, v, leaf);
         if (v >= 0) atomicMin(&lmin[leaf], bits);
     }
+    STAMP(9);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -237,11 +250,168 @@ __device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    STAMP(10);
 }
 
-__device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap, bool has_copy) {
+// Round 5, second step: the whole query one lane per NODE.  What the walk above does node by node -- read the node, the
+// bound of its far child, push, pop the nearest queued cell with a wave-wide minimum, each a dependent LDS round trip behind a
+// fence: 2.6 us a query on the coarse sheet, 13 of the step's 45 us -- depends on the query only through values every node can
+// compute for itself:
+//   * whether the walk, arriving at its parent, would go to this node FIRST (x[dim] < split) and the squared distance to the
+//     parent's plane if not (query.cxx: the far child's side distance);
+//   * its lower bound: the parent's, plus (new side - old side) if it is the far child -- the additions in the order of the
+//     path from the root, one tree level per trip, the parent's four values read across lanes;
+//   * a leaf's answer: its points are a row of 16 lanes (PartDev::kd_rec16), smallest distance by row rotations on the bit
+//     patterns, first point reaching it from the ballot.
+// The walk that remains is scalar: the node's children and flags from one v_readlane, `bound <= best` / `bound > best` /
+// `leaf's distance < best` as three ballots renewed when the best distance changes, the queue a 64-bit mask of nodes plus each
+// queued lane's position in scipy's list (equal bounds pop in list order; the last entry fills the hole).  Same visiting order,
+// same strict comparisons as oracle/paint_oracle.c stale_kd_query.  `node_tab`: the wave's copy of PartDev::kd_lane (kd_stage).
+__device__ int nearest_vertex_kd_lanes(PartRef P, const double pt[3], int lane, const i32x4 *node_tab, const uint64_t *anc_tab PROF_ARG) {
+    const int n_nodes = P.n_kd_nodes;
+    const bool isn = lane < n_nodes;
+    // the leaves' points: all loads in flight before anything else
+    const f64x2 GAS *r16 = reinterpret_cast<const f64x2 GAS *>(P.kd_rec16);
+    const int n_slots = 16 * P.n_kd_leaves;                       // (the table itself: whole trips of 64)
+    const i32x4 st = node_tab[isn ? lane : 0];
+    const int pk = st.x, ordinal = isn ? st.y : -1;
+    const int sd = pk & 3, psd = (pk >> 2) & 3, depth = (pk >> 5) & 63, parent = (pk >> 11) & 63, lesser = (pk >> 17) & 63,
+              greater = (pk >> 23) & 63;
+    const bool is_lesser = (pk >> 4) & 1;
+    const double psp = __hiloint2double(st.w, st.z);
+    // the edge into this node
+    const double xp = sel3(pt[0], pt[1], pt[2], psd);
+    const bool i_far = isn && lane != 0 && ((xp < psp) != is_lesser);
+    const double tmp = psp - xp, nw = tmp * tmp;
+    // the root's bound and side distances (every lane)
+    double s0, s1, s2;
+    {
+        const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
+                     a2 = pt[2] - P.kd_box[5], b2 = P.kd_box[2] - pt[2];
+        s0 = a0 > b0 ? a0 : b0;
+        s1 = a1 > b1 ? a1 : b1;
+        s2 = a2 > b2 ? a2 : b2;
+        s0 = s0 > 0 ? s0 : 0;
+        s1 = s1 > 0 ? s1 : 0;
+        s2 = s2 > 0 ? s2 : 0;
+        s0 = s0 * s0;
+        s1 = s1 * s1;
+        s2 = s2 * s2;
+    }
+    const uint64_t farmask = ballot64(i_far);
+    // the far child's bound is its parent's + (new side distance - old): the old one is the deepest far step across a plane of
+    // the same dimension on the way down (children follow their parents: the highest node index), or the root's
+    const uint64_t set_by = anc_tab[isn ? lane : 0] & farmask;
+    const double nw_set = __shfl(nw, 63 - __clzll((long long)(set_by | 1)));
+    const double delta = nw - (set_by ? nw_set : sel3(s0, s1, s2, psd));
+    double mind = (s0 + s1) + s2;
+    for (int d = 1; d <= P.kd_depth; ++d) {                         // level by level: the additions in the order of the path
+        const double pm = __shfl(mind, parent);
+        if (depth == d) mind = i_far ? pm + delta : pm;
+    }
+    const bool lesser_far = (farmask >> lesser) & 1;
+    // (a leaf's `near` field: the lane its answer ends up in, below)
+    const int walk = sd == 3 ? (0x10000 | (16 * (ordinal & 3) + (ordinal >> 2))) : ((lesser_far ? greater : lesser) | ((lesser_far ? lesser : greater) << 8));
+    if (!isn) mind = __longlong_as_double(0x7ff8000000000000ll);   // (no node: every comparison below is false)
+    // the bound as a pair of unsigned words that order like the doubles (-0 -> +0 first; a negative bound -- rounding of
+    // old + (new - old) -- orders below the positive ones): the nearest queued cell is two 32-bit minima, not a float64 one
+    const double mz = mind + 0.0;
+    const uint32_t mneg = (uint32_t)(__double2hiint(mz) >> 31);
+    const uint32_t khi = (uint32_t)__double2hiint(mz) ^ (mneg | 0x80000000u), klo = (uint32_t)__double2loint(mz) ^ mneg;
+    // the leaves: row r of trip t is the leaf of ordinal 4 t + r; its answer goes to lane 16 r + t
+    uint32_t lmin_hi = 0x7ff00000u, lmin_lo = 0;
+    int lvert = -1;
+    for (int t = 0; 64 * t < n_slots; ++t) {
+        // (the table is padded to whole trips with points at +inf: their distance is +inf, or NaN for a NaN query -- above
+        // every real one either way -- so nothing here asks whether a slot is real)
+        const f64x2 a = ldg(r16, 2 * (64 * t + lane)), b = ldg(r16, 2 * (64 * t + lane) + 1);
+        const double d0 = a.x - pt[0], d1 = a.y - pt[1], d2 = b.x - pt[2];
+        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;            // (a sum of squares: never -0)
+        const uint32_t hi = (uint32_t)__double2hiint(dd), lo = (uint32_t)__double2loint(dd);
+        uint32_t mh = hi;                                           // (>= +0 or NaN: ordered like their bit patterns)
+        mh = dpp_umin<0x121, 0xf>(mh);                              // row_ror 1, 2, 4, 8: every lane of the row has the row's minimum
+        mh = dpp_umin<0x122, 0xf>(mh);
+        mh = dpp_umin<0x124, 0xf>(mh);
+        mh = dpp_umin<0x128, 0xf>(mh);
+        uint32_t ml = hi == mh ? lo : 0xffffffffu;
+        ml = dpp_umin<0x121, 0xf>(ml);
+        ml = dpp_umin<0x122, 0xf>(ml);
+        ml = dpp_umin<0x124, 0xf>(ml);
+        ml = dpp_umin<0x128, 0xf>(ml);
+        // the first point (tree order = lane order) reaching it: a third minimum, over lane-in-row << 28 | vertex
+        uint32_t mv = (hi == mh) & (lo == ml) ? ((uint32_t)(lane & 15) << 28) | (uint32_t)__double2loint(b.y) : 0xffffffffu;
+        mv = dpp_umin<0x121, 0xf>(mv);
+        mv = dpp_umin<0x122, 0xf>(mv);
+        mv = dpp_umin<0x124, 0xf>(mv);
+        mv = dpp_umin<0x128, 0xf>(mv);
+        if ((lane & 15) == t) {
+            lmin_hi = mh;
+            lmin_lo = ml;
+            lvert = (int)(mv & 0x0fffffffu);
+        }
+    }
+    const double lminv = __hiloint2double((int)lmin_hi, (int)lmin_lo);
+    STAMP(9);
+    double dub = INFINITY;
+    int best = -1, node = 0, n_heap = 0, pos = -1;
+    uint64_t queued = 0;
+    uint64_t le = ballot64(mind <= dub), gt = 0, lt = ballot64(lminv < dub);
+    const uint64_t leaves = ballot64(isn & (sd == 3));
+    for (int guard = 0; guard < 4 * KD_LDS_NODES; ++guard) {         // (a node is queued at most once; a bound all the same)
+        node = rfl(node);
+        const int w = __builtin_amdgcn_readlane(walk, node);
+        if (w & 0x10000) {                                          // leaf
+            const int ll = w & 63;
+            if ((lt >> ll) & 1) {
+                dub = bcast_d(lminv, ll);
+                best = __builtin_amdgcn_readlane(lvert, ll);
+                le = ballot64(mind <= dub);
+                gt = ballot64(mind > dub);
+                lt = ballot64(lminv < dub);
+            }
+            // nothing queued, or only cells (no leaf) that all lie beyond the best: whichever is nearest ends the query
+            if ((queued & (leaves | ~gt)) == 0) break;
+            int m = (int)__builtin_ctzll(queued);
+            if (queued & (queued - 1)) {                            // more than one queued: the nearest
+                const bool mine = (queued >> lane) & 1;
+                const uint32_t mh = wave_min_u32(mine ? khi : 0xffffffffu);
+                const bool top = mine & (khi == mh);
+                uint64_t tie = ballot64(top);
+                if (tie & (tie - 1)) {                              // (the bounds' high words equal: rare)
+                    const uint32_t ml = wave_min_u32(top ? klo : 0xffffffffu);
+                    tie = ballot64(top & (klo == ml));
+                }
+                m = (int)__builtin_ctzll(tie);
+                if (tie & (tie - 1)) {                              // equal bounds: the first in the list
+                    const bool tied = (tie >> lane) & 1;
+                    const int pmin = wave_min_i(tied ? pos : 0x7fffffff);
+                    m = (int)__builtin_ctzll(ballot64(tied & (pos == pmin)));
+                }
+            }
+            m = rfl(m);
+            const int pos_m = __builtin_amdgcn_readlane(pos, m);
+            queued &= ~(1ull << m);
+            --n_heap;
+            pos = pos == n_heap ? pos_m : pos;                      // the last entry fills the hole
+            node = m;
+        } else {
+            if ((gt >> node) & 1) break;
+            const int far = (w >> 8) & 0xff;
+            if (((le >> far) & 1) && n_heap < KD_HEAP) {
+                queued |= 1ull << far;
+                pos = lane == far ? n_heap : pos;
+                ++n_heap;
+            }
+            node = w & 0xff;
+        }
+    }
+    return best;
+}
+
+__device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double *heap, bool has_copy PROF_ARG) {
     const bool staged = has_copy && P.n_kd_nodes <= KD_LDS_NODES;           // (kd_stage ran in shots_begin)
     const i32x4 *lds_node = reinterpret_cast<const i32x4 *>(heap + KD_HEAP * 5);
+    if (staged && kd_lanes_on(P)) return nearest_vertex_kd_lanes(P, pt, lane, lds_node, reinterpret_cast<const uint64_t *>(heap) PROF_PASS);
     const double *lds_split = heap + KD_HEAP * 5 + 2 * KD_LDS_NODES;
     unsigned long long *lmin = reinterpret_cast<unsigned long long *>(heap + KD_HEAP * 5 + 3 * KD_LDS_NODES);
     unsigned long long *lfirst = lmin + KD_LDS_NODES;
@@ -250,7 +420,7 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
 #else
     const bool leaves_ready = false;
 #endif
-    if (leaves_ready) kd_leaf_results(P, pt, lane, lmin, lfirst);
+    if (leaves_ready) kd_leaf_results(P, pt, lane, lmin, lfirst PROF_PASS);
     double side0, side1, side2;
     {
         const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
@@ -520,7 +690,7 @@ __device__ bool hook_point_wave(PartRef P, const double pt[3], int lane, double 
     FacetTile *tile = wl.tile;
     f64x2 *gather = wl.gather;
     int vidx;
-    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap, wl.kd_staged != 0) : nearest_vertex_wave(P, pt, lane, wl.vg_lds);
+    if constexpr (KD) vidx = P.n_kd_nodes > 0 ? nearest_vertex_kd(P, pt, lane, kd_heap, wl.kd_staged != 0 PROF_PASS) : nearest_vertex_wave(P, pt, lane, wl.vg_lds);
     else vidx = nearest_vertex_wave(P, pt, lane, wl.vg_lds);
     if (tile && pf.facet >= 0) tile_fill(P, tile, pf.facet, pf.ids, lane);
     STAMP(PH_VERTEX);

@@ -26,7 +26,7 @@ def main():
     from paintrl_amd import _lib, part_tables, synth_parts
     from paintrl_amd.batched_env import BatchedPaintEnv
     from paintrl_amd.device_tables import DeviceTables
-    hb.LIBRARY = os.path.join(REPO, 'tools', '_ab', 'trace.so')
+    hb.LIBRARY = os.path.join(REPO, 'tools', '_ab', os.environ.get('PRL_TRACE_LIB', 'trace') + '.so')   # (PRL_TRACE_LIB=trace4: --diag-unit k_step4)
     os.environ['PAINTRL_LAX_SYMBOLS'] = '1'
     _lib._lib = None
     lib = _lib.load()
@@ -104,7 +104,7 @@ def main():
                 print('   hits in [%d, %d): %.1f %% of the waves, life mean %.1f us, p99 %.1f' % (lo, hi, 100 * m.mean(), flat_life[m].mean(), np.percentile(flat_life[m], 99)))
     if rows_ph:
         ph = np.stack(rows_ph).astype(np.float64) * 0.01          # us, [steps, n, 16]
-        names = ['load', 'ray', 'vertex', 'bary', 'math', 'paint', 'apply', 'obs', 'store']
+        names = ['load', 'ray', 'vertex', 'bary', 'math', 'paint', 'apply', 'obs', 'store'] + ['extra%d' % k for k in range(9, 16) if ph[..., k].any()]
         tot = ph[..., :9].sum(-1)
         print('phase split of a wave life (us, mean over waves; the stamps cost a few lane moves each): ' +
               '  '.join('%s %.2f' % (nm, ph[..., k].mean()) for k, nm in enumerate(names)) + '  | sum %.1f of life %.1f' % (tot.mean(), life.mean()))
