@@ -288,12 +288,10 @@ __device__ int nearest_vertex_kd_lanes(PartRef P, const double pt[3], int lane, 
     {
         const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
                      a2 = pt[2] - P.kd_box[5], b2 = P.kd_box[2] - pt[2];
-        s0 = a0 > b0 ? a0 : b0;
-        s1 = a1 > b1 ? a1 : b1;
-        s2 = a2 > b2 ? a2 : b2;
-        s0 = s0 > 0 ? s0 : 0;
-        s1 = s1 > 0 ? s1 : 0;
-        s2 = s2 > 0 ? s2 : 0;
+        // (max(a, b, 0) as two v_max_f64: for a NaN query both differences are NaN and either form gives 0)
+        s0 = fmax(fmax(a0, b0), 0.0);
+        s1 = fmax(fmax(a1, b1), 0.0);
+        s2 = fmax(fmax(a2, b2), 0.0);
         s0 = s0 * s0;
         s1 = s1 * s1;
         s2 = s2 * s2;
@@ -324,6 +322,7 @@ __device__ int nearest_vertex_kd_lanes(PartRef P, const double pt[3], int lane, 
     for (int t = 0; 64 * t < n_slots; ++t) {
         // (the table is padded to whole trips with points at +inf: their distance is +inf, or NaN for a NaN query -- above
         // every real one either way -- so nothing here asks whether a slot is real)
+        // (the records of the next trips asked for ahead of their use: measured slower, the registers cost more than the wait)
         const f64x2 a = ldg(r16, 2 * (64 * t + lane)), b = ldg(r16, 2 * (64 * t + lane) + 1);
         const double d0 = a.x - pt[0], d1 = a.y - pt[1], d2 = b.x - pt[2];
         const double dd = (d0 * d0 + d1 * d1) + d2 * d2;            // (a sum of squares: never -0)
@@ -357,53 +356,53 @@ __device__ int nearest_vertex_kd_lanes(PartRef P, const double pt[3], int lane, 
     uint64_t queued = 0;
     uint64_t le = ballot64(mind <= dub), gt = 0, lt = ballot64(lminv < dub);
     const uint64_t leaves = ballot64(isn & (sd == 3));
-    for (int guard = 0; guard < 4 * KD_LDS_NODES; ++guard) {         // (a node is queued at most once; a bound all the same)
-        node = rfl(node);
-        const int w = __builtin_amdgcn_readlane(walk, node);
-        if (w & 0x10000) {                                          // leaf
-            const int ll = w & 63;
-            if ((lt >> ll) & 1) {
-                dub = bcast_d(lminv, ll);
-                best = __builtin_amdgcn_readlane(lvert, ll);
-                le = ballot64(mind <= dub);
-                gt = ballot64(mind > dub);
-                lt = ballot64(lminv < dub);
-            }
-            // nothing queued, or only cells (no leaf) that all lie beyond the best: whichever is nearest ends the query
-            if ((queued & (leaves | ~gt)) == 0) break;
-            int m = (int)__builtin_ctzll(queued);
-            if (queued & (queued - 1)) {                            // more than one queued: the nearest
-                const bool mine = (queued >> lane) & 1;
-                const uint32_t mh = wave_min_u32(mine ? khi : 0xffffffffu);
-                const bool top = mine & (khi == mh);
-                uint64_t tie = ballot64(top);
-                if (tie & (tie - 1)) {                              // (the bounds' high words equal: rare)
-                    const uint32_t ml = wave_min_u32(top ? klo : 0xffffffffu);
-                    tie = ballot64(top & (klo == ml));
-                }
-                m = (int)__builtin_ctzll(tie);
-                if (tie & (tie - 1)) {                              // equal bounds: the first in the list
-                    const bool tied = (tie >> lane) & 1;
-                    const int pmin = wave_min_i(tied ? pos : 0x7fffffff);
-                    m = (int)__builtin_ctzll(ballot64(tied & (pos == pmin)));
-                }
-            }
-            m = rfl(m);
-            const int pos_m = __builtin_amdgcn_readlane(pos, m);
-            queued &= ~(1ull << m);
-            --n_heap;
-            pos = pos == n_heap ? pos_m : pos;                      // the last entry fills the hole
-            node = m;
-        } else {
-            if ((gt >> node) & 1) break;
+    for (int pops = 0; pops <= KD_LDS_NODES; ++pops) {               // (a node is queued at most once; a bound all the same)
+        // down to a leaf, the far children queued (a child's index is above its parent's -- part_fill checks it: this ends)
+        int w = __builtin_amdgcn_readlane(walk, node);
+        while (!(w & 0x10000)) {
+            if ((gt >> node) & 1) return best;                      // this cell lies beyond the best: scipy's query ends here
             const int far = (w >> 8) & 0xff;
-            if (((le >> far) & 1) && n_heap < KD_HEAP) {
+            if ((le >> far) & 1) {
                 queued |= 1ull << far;
                 pos = lane == far ? n_heap : pos;
                 ++n_heap;
             }
             node = w & 0xff;
+            w = __builtin_amdgcn_readlane(walk, node);
         }
+        const int ll = w & 63;
+        if ((lt >> ll) & 1) {
+            dub = bcast_d(lminv, ll);
+            best = __builtin_amdgcn_readlane(lvert, ll);
+            le = ballot64(mind <= dub);
+            gt = ballot64(mind > dub);
+            lt = ballot64(lminv < dub);
+        }
+        // nothing queued, or only cells (no leaf) that all lie beyond the best: whichever is nearest ends the query
+        if ((queued & (leaves | ~gt)) == 0) break;
+        int m = (int)__builtin_ctzll(queued);
+        if (queued & (queued - 1)) {                                // more than one queued: the nearest
+            const bool mine = (queued >> lane) & 1;
+            const uint32_t mh = wave_min_u32(mine ? khi : 0xffffffffu);
+            const bool top = mine & (khi == mh);
+            uint64_t tie = ballot64(top);
+            if (tie & (tie - 1)) {                                  // (the bounds' high words equal: rare)
+                const uint32_t ml = wave_min_u32(top ? klo : 0xffffffffu);
+                tie = ballot64(top & (klo == ml));
+            }
+            m = (int)__builtin_ctzll(tie);
+            if (tie & (tie - 1)) {                                  // equal bounds: the first in the list
+                const bool tied = (tie >> lane) & 1;
+                const int pmin = wave_min_i(tied ? pos : 0x7fffffff);
+                m = (int)__builtin_ctzll(ballot64(tied & (pos == pmin)));
+            }
+        }
+        m = rfl(m);
+        const int pos_m = __builtin_amdgcn_readlane(pos, m);
+        queued &= ~(1ull << m);
+        --n_heap;
+        pos = pos == n_heap ? pos_m : pos;                          // the last entry fills the hole
+        node = m;
     }
     return best;
 }
