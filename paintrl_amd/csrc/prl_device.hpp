@@ -224,9 +224,7 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // this kernel's register budget, spills them (a scratch access is 64 separate cache lines on gfx950).
 constexpr int KD_HEAP = 64;         // queued cells of the stale kd-tree walk (5 doubles each)
 constexpr int KD_LDS_NODES = 64;    // trees of at most this many nodes are walked from a copy in LDS (kd_stage, prl_search.hpp)
-constexpr int KD_ROW = KD_HEAP * 5 + 5 * KD_LDS_NODES;      // doubles per wave: the queue | nodes as int4 | split values | per leaf: smallest
-                                                            // distance of the query, first point reaching it (kd_leaf_results)
-constexpr int KD_STAGE_POINTS = 512;                        // trees of at most this many points have their leaves' results staged per query
+constexpr int KD_ROW = KD_HEAP * 5 + 3 * KD_LDS_NODES;      // doubles per wave: the queue (lane-parallel query: kd_anc) | nodes as int4 (kd_lane) | split values
 
 // Convex collision sets: the records of ONE facet's vertex neighbourhood (the facet itself in lane 0, PartDev::col_nbr) staged
 // in this wave's LDS -- the "LDS-staged triangle tile" of the ray (prl_ray.hpp).  A sub-shot's ray ends on the facet the

@@ -182,7 +182,7 @@ __device__ int nearest_vertex_wave(PartRef P, const double pt[3], int lane, cons
 // global round trips a level.  kd_stage copies trees of up to KD_LDS_NODES nodes into this wave's LDS once per step (behind
 // the queue in `heap`); the walk then reads its nodes from there.
 __device__ __forceinline__ bool kd_lanes_on(PartRef P) {
-#if defined(PRL_KD_SCAN_LEAVES) || defined(PRL_KD_LDS_WALK)      // (parity / A-B switches: the general walk for every tree)
+#ifdef PRL_KD_GENERAL_WALK                          // (parity and A-B switch: the general walk for every tree)
     return false;
 #else
     return P.n_kd_leaves > 0;
@@ -205,55 +205,7 @@ __device__ __forceinline__ void kd_stage(PartRef P, double *heap, int lane) {
     }
 }
 
-// Round 5: every leaf's result for THIS query at once.  The walk visits two to six leaves, and each visit was a dependent
-// global round trip (the leaf's point records) and two wave-wide reductions (smallest distance, first lane reaching it) in
-// the middle of a serial chain -- 5 us a query on the coarse sheet (the reference's square.urdf class: 17-33 nodes, a few
-// hundred points).  The distance of the query to EVERY point of the tree is one round trip with all loads in flight
-// (ceil(points / 64) records a lane); each leaf's minimum is an LDS atomic minimum on the distance's bit pattern (squared
-// distances are >= +0: they order like unsigned integers), the first point reaching it a second one on (point << 32 | vertex).
-// The walk then reads a leaf's result from LDS: same visiting order, same strict comparisons, same answer.
-// lmin[node], lfirst[node]: this wave's rows behind the staged tree (KD_ROW).
-__device__ __forceinline__ void kd_leaf_results(PartRef P, const double pt[3], int lane, unsigned long long *lmin, unsigned long long *lfirst PROF_ARG) {
-    if (lane < P.n_kd_nodes) {
-        lmin[lane] = 0x7ff0000000000000ull;          // +inf
-        lfirst[lane] = ~0ull;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const f64x2 GAS *r = reinterpret_cast<const f64x2 GAS *>(P.kd_rec);
-    // (two passes over the records instead of one with the distances kept: eight trips' worth of them were 32 vector registers,
-    // and the second read comes from L1)
-    auto measure = [&](int p, int &v, int &leaf) -> unsigned long long {
-        const bool in = p < P.n_kd_points;
-        const f64x2 a = ldg(r, 2 * (in ? p : 0)), b = ldg(r, 2 * (in ? p : 0) + 1);
-        v = in ? __double2loint(b.y) : -1;                           // -1: a row parked at (10, 10, 10)
-        leaf = __double2hiint(b.y);
-        const double d0 = a.x - pt[0], d1 = a.y - pt[1], d2 = b.x - pt[2];
-        const double dd = (d0 * d0 + d1 * d1) + d2 * d2;
-        return (unsigned long long)__double_as_longlong(dd + 0.0);
-    };
-    for (int p0 = 0; p0 < P.n_kd_points; p0 += 64) {
-        int v, leaf;
-        const unsigned long long bits = measure(p0 + lane, v, leaf);
-        if (v >= 0) atomicMin(&lmin[leaf], bits);
-    }
-    STAMP(9);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int p0 = 0; p0 < P.n_kd_points; p0 += 64) {
-        int v, leaf;
-        const unsigned long long bits = measure(p0 + lane, v, leaf);
-        if (v >= 0 && bits == lmin[leaf]) atomicMin(&lfirst[leaf], ((unsigned long long)(uint32_t)(p0 + lane) << 32) | (uint32_t)v);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    STAMP(10);
-}
-
-// Round 5, second step: the whole query one lane per NODE.  What the walk above does node by node -- read the node, the
+// Round 5: the whole query one lane per NODE.  What the general walk below does node by node -- read the node, the
 // bound of its far child, push, pop the nearest queued cell with a wave-wide minimum, each a dependent LDS round trip behind a
 // fence: 2.6 us a query on the coarse sheet, 13 of the step's 45 us -- depends on the query only through values every node can
 // compute for itself:
@@ -412,14 +364,6 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
     const i32x4 *lds_node = reinterpret_cast<const i32x4 *>(heap + KD_HEAP * 5);
     if (staged && kd_lanes_on(P)) return nearest_vertex_kd_lanes(P, pt, lane, lds_node, reinterpret_cast<const uint64_t *>(heap) PROF_PASS);
     const double *lds_split = heap + KD_HEAP * 5 + 2 * KD_LDS_NODES;
-    unsigned long long *lmin = reinterpret_cast<unsigned long long *>(heap + KD_HEAP * 5 + 3 * KD_LDS_NODES);
-    unsigned long long *lfirst = lmin + KD_LDS_NODES;
-#ifndef PRL_KD_SCAN_LEAVES                           // (A/B and parity switch: the leaves scanned where the walk visits them)
-    const bool leaves_ready = staged && P.n_kd_points <= KD_STAGE_POINTS;
-#else
-    const bool leaves_ready = false;
-#endif
-    if (leaves_ready) kd_leaf_results(P, pt, lane, lmin, lfirst PROF_PASS);
     double side0, side1, side2;
     {
         const double a0 = pt[0] - P.kd_box[3], b0 = P.kd_box[0] - pt[0], a1 = pt[1] - P.kd_box[4], b1 = P.kd_box[1] - pt[1],
@@ -434,87 +378,10 @@ __device__ int nearest_vertex_kd(PartRef P, const double pt[3], int lane, double
     }
     double mind = (side0 + side1) + side2, dub = INFINITY;
     int node = 0, best = -1, n_heap = 0;
-#ifdef PRL_KD_WALK_REGS                              // (A/B switch, OFF: measured slower, profiles/r05_ab_log.txt)
-    if (leaves_ready) {
-        // The walk itself without a memory access: the staged tree has at most 64 nodes, so lane i holds node i -- split
-        // dimension, children, split value, and the leaf's result for this query -- and queue slot i; a node is read with
-        // v_readlane at a scalar index, a queue entry written with v_writelane.  Same visiting order, same comparisons, the
-        // queue in the same list order as oracle/paint_oracle.c stale_kd_query: equal results -- and 60.8 us a step against 57.5
-        // on the LDS copies: the walk's LDS round trips are covered by the SIMD's other waves, while every lane read / write here
-        // is an instruction (two per double, plus the moves of compare results to scalar registers), and the step is bound by
-        // instruction issue.
-        const int li = lane < P.n_kd_nodes ? lane : 0;
-        const i32x4 ndv = lds_node[li];
-        const double spv = lds_split[li];
-        const double lminv = __longlong_as_double((long long)lmin[li]);
-        const int lvert = (int)(uint32_t)lfirst[li];
-        double q_mind = INFINITY, q_s0 = 0, q_s1 = 0, q_s2 = 0;
-        int q_node = 0;
-        auto put_d = [&](double &reg, double val, int slot) {       // reg[slot] = val (val, slot wave-uniform)
-            const int lo = writelane_i(rfl(__double2loint(val)), slot, __double2loint(reg));
-            const int hi = writelane_i(rfl(__double2hiint(val)), slot, __double2hiint(reg));
-            reg = __hiloint2double(hi, lo);
-        };
-        for (int guard = 0; guard < 4 * KD_LDS_NODES; ++guard) {
-            node = rfl(node);
-            const int nd0 = __builtin_amdgcn_readlane(ndv.x, node);
-            if (nd0 < 0) {                                          // leaf: its smallest distance, the first point reaching it
-                const double dmin = bcast_d(lminv, node);
-                if (rfl(dmin < dub)) {
-                    dub = dmin;
-                    best = __builtin_amdgcn_readlane(lvert, node);
-                }
-                if (n_heap == 0) break;
-                const double key = lane < n_heap ? q_mind : INFINITY;
-                const double kmin = wave_min_d(key);
-                const int m = rfl(__builtin_ctzll(ballot64(key == kmin)));
-                mind = bcast_d(q_mind, m);
-                side0 = bcast_d(q_s0, m);
-                side1 = bcast_d(q_s1, m);
-                side2 = bcast_d(q_s2, m);
-                node = __builtin_amdgcn_readlane(q_node, m);
-                --n_heap;
-                if (m != n_heap) {                                  // the last entry fills the hole
-                    put_d(q_mind, bcast_d(q_mind, n_heap), m);
-                    put_d(q_s0, bcast_d(q_s0, n_heap), m);
-                    put_d(q_s1, bcast_d(q_s1, n_heap), m);
-                    put_d(q_s2, bcast_d(q_s2, n_heap), m);
-                    q_node = writelane_i(__builtin_amdgcn_readlane(q_node, n_heap), m, q_node);
-                }
-            } else {
-                if (rfl(mind > dub)) break;
-                const int nd1 = __builtin_amdgcn_readlane(ndv.y, node), nd2 = __builtin_amdgcn_readlane(ndv.z, node);
-                const double sp = bcast_d(spv, node);
-                const double xs = sel3(pt[0], pt[1], pt[2], nd0), old = sel3(side0, side1, side2, nd0);
-                const bool low = rfl(xs < sp);
-                const int near = low ? nd1 : nd2, far = low ? nd2 : nd1;
-                const double tmp = sp - xs, nw = tmp * tmp;
-                const double far_mind = mind + (nw - old);
-                if (rfl(far_mind <= dub) && n_heap < KD_HEAP) {
-                    put_d(q_mind, far_mind, n_heap);
-                    put_d(q_s0, nd0 == 0 ? nw : side0, n_heap);
-                    put_d(q_s1, nd0 == 1 ? nw : side1, n_heap);
-                    put_d(q_s2, nd0 == 2 ? nw : side2, n_heap);
-                    q_node = writelane_i(far, n_heap, q_node);
-                    ++n_heap;
-                }
-                node = near;
-            }
-        }
-        return best;
-    }
-#endif
     for (int guard = 0; guard < 4 * 4096; ++guard) {                // every path ends far earlier; a bound all the same
         const i32x4 nd = staged ? lds_node[node] : ldg(reinterpret_cast<const i32x4 GAS *>(P.kd_node), node);
         const int nd0 = rfl(nd.x), nd1 = rfl(nd.y), nd2 = rfl(nd.z);
         if (nd0 < 0) {                                              // leaf: points nd1 .. nd2 - 1
-            if (leaves_ready) {                                     // its smallest distance and the first point (tree order) reaching it
-                const double dmin = __longlong_as_double((long long)lmin[node]);
-                if (dmin < dub) {
-                    dub = dmin;
-                    best = rfl((int)(uint32_t)lfirst[node]);
-                }
-            } else
             for (int i0 = nd1; i0 < nd2; i0 += 64) {
                 const int i = i0 + lane;
                 int v = -1;                                         // -1: a row parked at (10, 10, 10)

@@ -5,8 +5,8 @@ disabled or stressed (whole-table scans instead of ring searches and the general
 convex-neighbourhood path, without the outline's miss certificate, with culling boxes rounded by nextafterf and the
 determinant's reciprocal as a plain division; the painter walking one sample-grid row per trip instead of four, with the uncertainty
 band of its float pre-filter widened 4096-fold so that the float64 confirmation runs constantly, every mask word loaded and
-written back instead of the tracked ones, the large parts' observation through the small parts' passes, the stale kd-tree's
-leaves scanned where the walk visits them).  The parity suites are run against
+written back instead of the tracked ones, the large parts' observation through the small parts' passes, the stale kd-tree
+walked node by node through its queue instead of one lane per node).  The parity suites are run against
 each variant in a fresh child process (PAINTRL_LIB selects the library before anything is loaded); the product
 build never defines these macros.
 """

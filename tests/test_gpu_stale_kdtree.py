@@ -47,6 +47,65 @@ def test_stale_tree_part_matches_oracle(kw):
     env.close()
 
 
+def test_queries_on_the_split_planes_and_vertex_coordinates():
+    """Tools parked so that the sub-shots' hit points lie EXACTLY on the stale tree's split planes (x[dim] < split is false
+    there: the greater child is the near one), on vertex coordinates and half-way between neighbouring vertices (equal
+    distances: the first point in tree order wins, equal bounds pop in list order), and well off the sheet's outline (long
+    walks, many queued cells): one step in each of the four directions, everything equal to the oracle.  The tree's
+    lane-parallel query (nearest_vertex_kd_lanes) computes bounds, near / far choices and every leaf's answer at once; this
+    is where its comparisons meet scipy's at equality."""
+    tables = synthetic_tables('test')
+    sd, sp_val = np.asarray(tables.kd_split_dim), np.asarray(tables.kd_split)
+    side = np.asarray(tables.vertex_is_side).astype(bool)
+    verts = np.asarray(tables.vertices, dtype=np.float64)[side]
+    a0 = [k for k in range(3) if k not in (tables.a1, tables.a2)][0]
+    lo, hi = verts.min(0), verts.max(0)
+    rng = np.random.RandomState(17)
+    poses = []
+    for node in np.nonzero(sd >= 0)[0]:                             # on each split plane, at random and at vertex coordinates
+        for k in range(6):
+            p = rng.uniform(lo, hi)
+            if k >= 3:
+                p = verts[rng.randint(len(verts))].copy()
+            p[sd[node]] = sp_val[node]
+            poses.append(p)
+    for k in range(40):                                             # on vertices, half-way between two, off the outline
+        v = verts[rng.randint(len(verts))]
+        w = verts[np.argsort(((verts - v) ** 2).sum(1))[1 + k % 3]]
+        poses.append(v.copy())
+        poses.append(0.5 * (v + w))
+        q = rng.uniform(lo, hi)
+        q[tables.a1 if k % 2 else tables.a2] += (hi - lo)[tables.a1 if k % 2 else tables.a2] * (0.3 if k % 4 < 2 else -0.3)
+        poses.append(q)
+    poses = np.repeat(np.asarray(poses), 4, axis=0)                 # every pose steps in all four directions
+    for p in poses:
+        p[a0] = verts[:, a0].max()
+    n = len(poses)
+    acts = np.arange(n) % 4
+    orn = [0.0, 0.0, 0.0]
+    orn[a0] = -1.0
+    sp = start_points_for(tables, 'all')
+    for kw in (dict(obs_mode='section'), dict(obs_mode='section', paint_method='normal')):
+        env = _env(tables, n, sp, max_possible_point=14000, **kw)
+        orc = oracle.Oracle(tables, n, start_points=sp, threads=8, max_possible_point=14000, **kw)
+        start = np.arange(n) % len(sp)
+        assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+        for i in range(n):
+            env.set_pose(i, poses[i], orn)
+            orc.set_pose(i, poses[i], orn)
+        for k in range(3):
+            a = (acts + k) % 4
+            o, r, d, _ = env.step(a)
+            oo, rr, dd, _ = orc.step(a)
+            assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+            assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(d.cpu().numpy(), dd), 'step %d' % k
+            st = env.state()
+            for e in range(n):
+                so = orc.state(e)
+                assert np.array_equal(st['pose'][e], so['pose']) and np.array_equal(st['quat'][e], so['quat']), (k, e)
+        env.close()
+
+
 def test_stale_tree_on_a_large_part_and_in_a_mixed_batch():
     """The same tree under the LDS-mask kernels (the reference's door_lf / door_rf carry both properties), next to a
     part without a tree in one batch."""
