@@ -2,7 +2,7 @@
 // front samples) do not fit four mask words per lane.  The ball painter's step (step_kernel_big) leaves the env's mask rows
 // where they are, in HBM / L2 (prl_step.hpp HbmMasks: the painter touches the words of its cell block in place, the
 // observation streams the painted row) -- no LDS for masks, sixteen waves a CU like the small parts' kernel.  COLOR_MODE
-// 'HSI' and the cone beams' finish kernel still work on LDS copies of the rows (BigMasks), sized at launch.  Everything else
+// the cone beams' finish kernel still works on LDS copies of the rows (BigMasks), sized at launch.  Everything else
 // is the same device code (prl_step.hpp with KW = 0).  See prl_launch.hpp for the translation-unit layout.
 #define PRL_UNIT_STEP 1                    // (prl_step.hpp step_env: the part's table pointers re-read per sub-shot)
 #include "prl_all.hpp"
@@ -86,21 +86,22 @@ __global__ __launch_bounds__(64 * WAVES, PRL_BIG_OCC) void step_kernel_big(StepA
     TRACE_END(env, dn);
 }
 
-// COLOR_MODE 'HSI' on a large part: four LDS copies of the rows per env (painted, last, the shot's set, the union of valid sets)
+// COLOR_MODE 'HSI' on a large part: the same with the thickness painter (paint_shots_hsi_words: the rows in HBM, every word of the
+// shots' cell block visited once) -- until round 5 four LDS copies of the rows per env, one wave a SIMD, 755 us a step at 70 654 samples
 template <bool GENSEC, bool KD>
-__global__ __launch_bounds__(256, 2) void step_kernel_big_hsi(StepArgs) {
+__global__ __launch_bounds__(256, 4) void step_kernel_big_hsi(StepArgs) {
     const StepArgs CAS &a = *(const StepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
     const int lane = threadIdx.x & 63;
     const int env = rfl(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (env >= a.n_envs) return;
-    const WaveLds wl = wave_lds<GENSEC, KD>();
+    const WaveLds wl = wave_lds<GENSEC, KD, 0, 4>();
     const int part_id = a.env_part ? a.env_part[env] : 0;
     PartRef P = *(const PartDev CAS *)(a.parts + part_id);
     CfgRef C = *(const CfgDev CAS *)a.cfg;
     double *state_rec = a.state + (size_t)env * PRL_STATE_DOUBLES;
     EnvState S;
     load_state_motion(state_rec, S);
-    const BigMasks masks = big_masks(a, env, P.n_words, lane, 4);
+    const HbmMasks masks = hbm_masks(a, env, P.n_words, lane);
     double delta1, delta2, new_angle;
     decode_action(C, a.actions, env, delta1, delta2, new_angle);
     PROF_BEGIN();
@@ -332,7 +333,10 @@ BigStepFn pick_big_step_hsi(const PrlStepSel &sel) {
 PRL_HIDDEN int KFN(step)(const void *step_args, const PrlStepSel *sel, void *stream) {
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sel->hsi) return launch_big(pick_big_step_hsi(*sel), a, 4, 0, s);
+    if (sel->hsi) {
+        hipLaunchKernelGGL(pick_big_step_hsi(*sel), dim3((a.n_envs + 3) / 4), dim3(256), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (sel->wide) hipLaunchKernelGGL(pick_big_step<STEP_WAVES_WIDE>(*sel), dim3((a.n_envs + STEP_WAVES_WIDE - 1) / STEP_WAVES_WIDE), dim3(64 * STEP_WAVES_WIDE), 0, s, a);
     else hipLaunchKernelGGL(pick_big_step<STEP_WAVES_NARROW>(*sel), dim3((a.n_envs + STEP_WAVES_NARROW - 1) / STEP_WAVES_NARROW), dim3(64 * STEP_WAVES_NARROW), 0, s, a);
     return (int)hipGetLastError();
@@ -343,15 +347,10 @@ PRL_HIDDEN int KFN(step_occupancy)(const void *step_args, const PrlStepSel *sel,
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
     int nb = 0;
     if (sel->hsi) {
-        const BigStepFn k = pick_big_step_hsi(*sel);
-        const int waves = big_waves(k, a, 4, 0);
-        if (waves < 1) return (int)hipErrorInvalidValue;
-        const size_t lds = (size_t)waves * 4 * a.mask_stride * sizeof(uint64_t);
-        if (const hipError_t e = big_grant_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), 64 * waves, lds);
-        out[0] = waves;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(pick_big_step_hsi(*sel)), 256, 0);
+        out[0] = 4;
         out[1] = nb;
-        out[2] = (int)lds;
+        out[2] = 0;
         return (int)e;
     }
     const int waves = sel->wide ? STEP_WAVES_WIDE : STEP_WAVES_NARROW;

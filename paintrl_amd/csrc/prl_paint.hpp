@@ -423,147 +423,159 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
 // uint8, 255 after reset; shot by shot every hit texel whose byte is not 0 loses
 //     quantity = int(25 (1 - (d / r)^2)) + 1,     d = distance to the shot centre, r = the shot's largest d,
 // in wrapping uint8 arithmetic, and contributes quantity / 255 to the shot's "succeed counter".  The status bit the
-// observation reads stays "byte == 255" (bpw:723-725).  The five shots run one after the other here -- r belongs
-// to a shot, and a byte may be hit by several -- two passes over a shot's 3 x 3 cell block each: the largest
-// distance, then the deposits.  `thick` is this env's row of bytes in HBM (device sample order); only the words a
-// shot touches are read and written.  The float sum is reduced in lane order: tests allow 1e-12 on rewards.
+// observation reads stays "byte == 255" (bpw:723-725).  `thick` is this env's row of bytes in HBM (device sample order); only
+// the words a shot touches are read and written.  The float sum is reduced in lane order: tests allow 1e-12 on rewards.
+//
+// Until round 5 the five shots ran one after the other, two passes over a shot's 3 x 3 cell block each (76 us a step on the
+// door, every word read up to ten times), and for parts beyond 16 384 samples on four LDS copies of the mask rows with row-wide
+// passes between the shots (one wave a SIMD: 755 us a step at 70 654 samples).  But a shot's largest distance depends on the
+// geometry alone, and everything else is local to a word once the five r's are known.  So: pass 0 finds the five r's, pass 1
+// visits each word of the shots' bounding cell block ONCE -- a sample's byte takes the five deposits in shot order in a
+// register, the status bit is the byte's last state, and as in paint_shots_union the valid sets only look one shot back:
+//     union = (b0 & ~last) | (b1 & ~b0) | ... ,  new last = b4.
+// A sample outside a shot's own 3 x 3 cell block is more than the radius away from its centre (paint_shots_union), so inside the
+// bounding block the distance alone decides -- oracle/paint_oracle.c ball_query.  Words the balls cannot reach are left out by the
+// word-box test of paint_shots_union's pre-pass; words not visited keep their bytes and painted bits and lose their last-shot
+// word (HbmMasks::paint_hsi clears what was set before and not visited now; register masks: the new last-shot words start at zero).
+// Words: RegWords (masks in registers) or HbmWords (rows in HBM).  62 us on the door, 155 us at 70 654 samples.
 template <int KW>
 __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
-                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter) {
+                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter);
+
+template <typename Words>
+__device__ void paint_shots_hsi_words(PartRef P, double radius, const double *cen_lds, int lane, const Words &words, uint8_t *thick,
+                                      double &succeeded, int &pixel_counter) {
     const double r2 = radius * radius;
-    uint64_t uni[KW_MAX] = {0, 0, 0, 0};
-    double succ_l = 0.0;
-    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-        const double c0 = cen_lds[3 * shot], c1 = cen_lds[3 * shot + 1], c2 = cen_lds[3 * shot + 2];
-        const int icx = rfl(cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx));
-        const int icy = rfl(cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny));
-        const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
-        uint64_t cur[KW_MAX] = {0, 0, 0, 0};
-        double dmax_l = -1.0;
-        for (int pass = 0; pass < 2; ++pass) {
-            const double rmax = pass ? sqrt(wave_max_d(dmax_l)) : 0.0;       // = max of the sqrt's: sqrt is monotone
-            if (pass && !(rmax >= 0.0)) break;                               // no sample hit: nothing to deposit
+    double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int begin = R.begin[r], end = begin + R.count[r];
-                if (R.count[r] <= 0) continue;
-                for (int w = begin >> 6; w <= ((end - 1) >> 6); ++w) {
-                    const int s = (w << 6) + lane;
-                    const double dx = c0 - ldg(P.samp[0], s), dy = c1 - ldg(P.samp[1], s), dz = c2 - ldg(P.samp[2], s);
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    const bool hit = s >= begin && s < end && dd <= r2;
-                    if (!pass) {
-                        if (hit) dmax_l = dd > dmax_l ? dd : dmax_l;
-                        continue;
-                    }
-                    const uint64_t b = ballot64(hit);
-                    if (b == 0) continue;
-                    uint8_t v = thick[s];
-                    if (hit) {
-                        const double q = sqrt(dd) / rmax;
-                        const int quantity = (int)(25 * (1 - q * q)) + 1;
-                        if (v != 0) {
-                            v = (uint8_t)(v - quantity);
-                            succ_l += quantity / 255.0;
-                            thick[s] = v;
-                        }
-                    }
-                    const uint64_t stat = ballot64(hit && v == 255);
-                    const int owner = w & 63, slot = w >> 6;
+    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+        const double c0 = cen_lds[3 * k], c1 = cen_lds[3 * k + 1], c2 = cen_lds[3 * k + 2];
+        const double h1 = sel3(c0, c1, c2, P.a1), h2 = sel3(c0, c1, c2, P.a2);
+        lo1 = fmin(lo1, h1);
+        hi1 = fmax(hi1, h1);
+        lo2 = fmin(lo2, h2);
+        hi2 = fmax(hi2, h2);
+    }
+    const bool none = !(lo1 <= hi1);                 // (NaN centres: they hit nothing)
+    const double reach_r = radius * (1.0 + 1.0e-9) + 1.0e-12;
+    const double reach_lo1 = lo1 - reach_r, reach_hi1 = hi1 + reach_r, reach_lo2 = lo2 - reach_r, reach_hi2 = hi2 + reach_r;
+    const int cx_lo = none ? -2 : cell_coord(lo1, P.sg_o1, P.sg_inv, P.sg_nx), cx_hi = none ? -2 : cell_coord(hi1, P.sg_o1, P.sg_inv, P.sg_nx);
+    const int cy_lo = none ? -2 : cell_coord(lo2, P.sg_o2, P.sg_inv, P.sg_ny), cy_hi = none ? -2 : cell_coord(hi2, P.sg_o2, P.sg_inv, P.sg_ny);
+    const int cx0 = cx_lo - 1 < 0 ? 0 : cx_lo - 1, cx1 = cx_hi + 1 > P.sg_nx - 1 ? P.sg_nx - 1 : cx_hi + 1;
+    const int row_lo = rfl(cy_lo - 1 < 0 ? 0 : cy_lo - 1), row_hi = rfl(cy_hi + 1 > P.sg_ny - 1 ? P.sg_ny - 1 : cy_hi + 1);
+    const f64x4 GAS *wb4 = reinterpret_cast<const f64x4 GAS *>(P.word_bbox);
+    // every word of the bounding block that a ball may reach, once, in ascending order: fn(word)
+    auto for_words = [&](auto &&fn) {
+        int done_w = -1;
+        for (int r0 = row_lo; r0 <= row_hi; r0 += 32) {
+            const int rcy = r0 + (lane >> 1);
+            const bool ok = rcy <= row_hi && cx0 <= cx1;
+            const int bound = ok ? ldg(P.sg_start, rcy * P.sg_nx + ((lane & 1) ? cx1 + 1 : cx0)) : 0;
+            const int n_rows = row_hi - r0 + 1 < 32 ? row_hi - r0 + 1 : 32;
+            for (int r = 0; r < n_rows; ++r) {
+                const int rb = __builtin_amdgcn_readlane(bound, 2 * r), re = __builtin_amdgcn_readlane(bound, 2 * r + 1);
+                if (re <= rb) continue;
+                const int wlast = (re - 1) >> 6, wfirst = (rb >> 6) > done_w ? (rb >> 6) : done_w + 1;
+                for (int wb = wfirst; wb <= wlast; wb += 64) {
+                    const int wi = wb + lane;
+                    const bool inr = wi <= wlast;
+                    const f64x4 bb = ldg(wb4, inr ? wi : wb);
+                    bool near = false;
 #pragma unroll
-                    for (int k = 0; k < KW; ++k)
-                        if (k == slot && lane == owner) {
-                            painted[k] = (painted[k] & ~b) | stat;
-                            cur[k] |= b;                 // (a word can be visited from two rows' ranges: disjoint lanes)
-                        }
+                    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+                        const double c0 = cen_lds[3 * k], c1 = cen_lds[3 * k + 1], c2 = cen_lds[3 * k + 2];
+                        const double h1 = sel3(c0, c1, c2, P.a1), h2 = sel3(c0, c1, c2, P.a2);
+                        const double ex = fmax(fmax(bb.x - h1, h1 - bb.y), 0.0), ey = fmax(fmax(bb.z - h2, h2 - bb.w), 0.0);
+                        near |= ex * ex + ey * ey <= reach_r * reach_r;
+                    }
+                    const bool reach = inr & near & !((bb.x > reach_hi1) | (bb.y < reach_lo1) | (bb.z > reach_hi2) | (bb.w < reach_lo2));
+                    uint64_t m = ballot64(reach);
+                    while (m) {
+                        const int w = wb + __builtin_ctzll(m);
+                        m &= m - 1;
+                        fn(w);
+                    }
                 }
+                done_w = wlast > done_w ? wlast : done_w;
             }
         }
+    };
+    // the five squared distances of this lane's sample of word w (the rows' alignment pads lie 1e15 away: device_tables.FAR)
+    auto distances = [&](int w, double dd[PAINT_PER_ACTION]) {
+        const int s = (w << 6) + lane;
+        const double x = ldg(P.samp[0], s), y = ldg(P.samp[1], s), z = ldg(P.samp[2], s);
 #pragma unroll
-        for (int k = 0; k < KW; ++k) {                   // bpw:575-576: valid = affected minus the previous shot's
-            uni[k] |= cur[k] & ~last[k];
-            last[k] = cur[k];
+        for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+            const double dx = cen_lds[3 * k] - x, dy = cen_lds[3 * k + 1] - y, dz = cen_lds[3 * k + 2] - z;
+            dd[k] = (dx * dx + dy * dy) + dz * dz;
         }
-    }
-    uint32_t pix_l = 0;
+    };
+    // pass 0: each shot's largest distance
+    double dmax_l[PAINT_PER_ACTION] = {-1.0, -1.0, -1.0, -1.0, -1.0};
+    for_words([&](int w) {
+        double dd[PAINT_PER_ACTION];
+        distances(w, dd);
 #pragma unroll
-    for (int k = 0; k < KW; ++k) pix_l += __popcll(uni[k]);
-    pixel_counter = (int)wave_sum_u64(pix_l);
+        for (int k = 0; k < PAINT_PER_ACTION; ++k) dmax_l[k] = (dd[k] <= r2) & (dd[k] > dmax_l[k]) ? dd[k] : dmax_l[k];
+    });
+    double rmax[PAINT_PER_ACTION];
+#pragma unroll
+    for (int k = 0; k < PAINT_PER_ACTION; ++k) rmax[k] = uni_d(sqrt(wave_max_d(dmax_l[k])));      // (no hit: NaN, and no deposit either)
+    // pass 1: the deposits, word by word
+    double succ_l = 0.0;
+    int pix = 0;
+    for_words([&](int w) {
+        double dd[PAINT_PER_ACTION];
+        distances(w, dd);
+        uint64_t b[PAINT_PER_ACTION], any = 0;
+#pragma unroll
+        for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+            b[k] = ballot64(dd[k] <= r2);
+            any |= b[k];
+        }
+        if (any == 0) return;                        // (its last-shot word, if set, is cleared with the words not visited)
+        uint64_t pw_old, lw_old;
+        words.get(w, pw_old, lw_old);
+        if constexpr (Words::HBM) {                  // (loaded by every lane from one address: wave-uniform, to scalar registers)
+            pw_old = uni_u64(pw_old);
+            lw_old = uni_u64(lw_old);
+        }
+        const int s = (w << 6) + lane;
+        const bool mine = (any >> lane) & 1;
+        const uint8_t v_old = mine ? thick[s] : (uint8_t)0;
+        uint8_t v = v_old;
+        uint64_t pw = pw_old, uw = 0, prev = lw_old;
+#pragma unroll
+        for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+            if (b[k]) {
+                const bool hit = (b[k] >> lane) & 1;
+                if (hit && v != 0) {
+                    const double q = sqrt(dd[k]) / rmax[k];
+                    const int quantity = (int)(25 * (1 - q * q)) + 1;
+                    v = (uint8_t)(v - quantity);
+                    succ_l += quantity / 255.0;
+                }
+                pw = (pw & ~b[k]) | ballot64(hit && v == 255);
+            }
+            uw |= b[k] & ~prev;
+            prev = b[k];
+        }
+        if (mine && v != v_old) thick[s] = v;
+        pix += (int)__popcll(uw);
+        words.put(w, pw, prev, pw_old, lw_old);
+    });
+    pixel_counter = pix;
     succeeded = wave_sum_d(succ_l);
 }
 
-// The same for a part with more than 16 384 samples: the masks live in LDS (`painted`, `last`, `cur`: zero on entry and the
-// last shot's affected set on exit, `uni`: scratch; n_words words each).  Word updates go through lane 0.
-__device__ void paint_shots_hsi_big(PartRef P, double radius, const double *cen_lds, int lane, uint64_t *painted, uint64_t *last,
-                                    uint64_t *cur, uint64_t *uni, int n_words, uint8_t *thick, double &succeeded,
-                                    int &pixel_counter) {
-    const double r2 = radius * radius;
-    double succ_l = 0.0;
-    for (int w = lane; w < n_words; w += 64) uni[w] = 0;
-    for (int shot = 0; shot < PAINT_PER_ACTION; ++shot) {
-        const double c0 = cen_lds[3 * shot], c1 = cen_lds[3 * shot + 1], c2 = cen_lds[3 * shot + 2];
-        const int icx = rfl(cell_coord(sel3(c0, c1, c2, P.a1), P.sg_o1, P.sg_inv, P.sg_nx));
-        const int icy = rfl(cell_coord(sel3(c0, c1, c2, P.a2), P.sg_o2, P.sg_inv, P.sg_ny));
-        const Rows3 R = grid_rows3(P.sg_start, P.sg_nx, P.sg_ny, icx, icy, lane);
-        double dmax_l = -1.0;
-        for (int pass = 0; pass < 2; ++pass) {
-            const double rmax = pass ? sqrt(wave_max_d(dmax_l)) : 0.0;
-            if (pass && !(rmax >= 0.0)) break;
+// masks in registers (parts of up to 16 384 samples)
+template <int KW>
+__device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
+                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter) {
+    uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
+    paint_shots_hsi_words(P, radius, cen_lds, lane, RegWords<KW>{painted, last, new_last, lane}, thick, succeeded, pixel_counter);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int begin = R.begin[r], end = begin + R.count[r];
-                if (R.count[r] <= 0) continue;
-                for (int w = begin >> 6; w <= ((end - 1) >> 6); ++w) {
-                    const int s = (w << 6) + lane;
-                    const double dx = c0 - ldg(P.samp[0], s), dy = c1 - ldg(P.samp[1], s), dz = c2 - ldg(P.samp[2], s);
-                    const double dd = (dx * dx + dy * dy) + dz * dz;
-                    const bool hit = s >= begin && s < end && dd <= r2;
-                    if (!pass) {
-                        if (hit) dmax_l = dd > dmax_l ? dd : dmax_l;
-                        continue;
-                    }
-                    const uint64_t b = ballot64(hit);
-                    if (b == 0) continue;
-                    uint8_t v = thick[s];
-                    if (hit) {
-                        const double q = sqrt(dd) / rmax;
-                        const int quantity = (int)(25 * (1 - q * q)) + 1;
-                        if (v != 0) {
-                            v = (uint8_t)(v - quantity);
-                            succ_l += quantity / 255.0;
-                            thick[s] = v;
-                        }
-                    }
-                    const uint64_t stat = ballot64(hit && v == 255);
-                    if (lane == 0) {
-                        painted[w] = (painted[w] & ~b) | stat;
-                        cur[w] |= b;                     // (a word can be visited from two rows' ranges: disjoint lanes)
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int w = lane; w < n_words; w += 64) {       // bpw:575-576: valid = affected minus the previous shot's
-            uni[w] |= cur[w] & ~last[w];
-            last[w] = cur[w];
-            cur[w] = 0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    uint32_t pix_l = 0;
-    for (int w = lane; w < n_words; w += 64) {
-        pix_l += __popcll(uni[w]);
-        cur[w] = last[w];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    pixel_counter = (int)wave_sum_u64(pix_l);
-    succeeded = wave_sum_d(succ_l);
+    for (int k = 0; k < KW; ++k) last[k] = new_last[k];
 }
 
 }  // namespace

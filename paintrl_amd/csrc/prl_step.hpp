@@ -373,8 +373,7 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     int succeeded = 0, pixel_counter = 0;
     double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
     if constexpr (HSI && BIG) {
-        paint_shots_hsi_big(P, C.paint_radius, cen, lane, masks.painted, masks.last, masks.new_last, masks.extra, masks.n_words,
-                            a.thick() + (size_t)env * 64 * a.mask_stride(), succeeded_f, pixel_counter);
+        masks.paint_hsi(P, C.paint_radius, cen, a.thick() + (size_t)env * 64 * a.mask_stride(), succeeded_f, pixel_counter);
     } else if constexpr (HSI) {
         paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
                             succeeded_f, pixel_counter);
@@ -510,13 +509,26 @@ struct HbmMasks {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    // COLOR_MODE 'HSI' (bpw:384-434) for the five shots, rows in place (paint_shots_hsi_words)
+    __device__ __forceinline__ void paint_hsi(PartRef P, double radius, const double *cen, uint8_t *thick, double &succeeded,
+                                              int &pixel_counter) const {
+        paint_shots_hsi_words(P, radius, cen, lane, HbmWords{painted, last, lane, &vis, &nzn}, thick, succeeded, pixel_counter);
+        zero_last(old_nz & ~vis);
+        if (lane < nz_words() && nzn != old_nz) nz[lane] = nzn;
+        old_nz = nzn;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     __device__ __forceinline__ void clear() const {               // reset: nothing painted, no last shot
         for (int w = lane; w < n_words; w += 64) painted[w] = 0;
         zero_last(old_nz);
         if (lane < nz_words() && old_nz != 0) nz[lane] = 0;
         old_nz = 0;
     }
-    __device__ __forceinline__ void all_painted(PartRef) const {}
+    // COLOR_MODE 'HSI' after a reset: every real sample reads painted (only the thickness kernel calls it)
+    __device__ __forceinline__ void all_painted(PartRef P) const {
+        for (int w = lane; w < n_words; w += 64) painted[w] = ldg(P.word_valid, w);
+    }
     template <int KW>
     __device__ __forceinline__ void store(const uint64_t *, const uint64_t *) const {}
 };
