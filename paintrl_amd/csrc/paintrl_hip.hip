@@ -1048,9 +1048,12 @@ int prl_batch_create(PrlPart *const *parts, int n_parts, const int32_t *env_part
         const size_t work_ints = 4 + items + 2 * (size_t)PRL_CONE_WORK_LISTS * prl_cone_ray_sub_cap((int)items) + 2 * 16 * PRL_CONE_WORK_LISTS;
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_work), sizeof(int) * work_ints);
         if (e == hipSuccess) e = hipMemset(b->cone_work, 0, sizeof(int) * work_ints);
-        // hit points handed to the far search: 128 per env and step over all sub-lists (a typical step has a dozen; a full
-        // sub-list sends the rest through the general code), a sub-list at least one trip's worth
-        const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * 128 / PRL_CONE_WORK_LISTS, 64), (size_t)1 << 18);
+        // hit points handed to the far search, per env and step over all sub-lists: a quarter of the step's beams, at least 128
+        // (the door: 33 of 520 beams on average; a 70 654-sample part casts 3 860 beams a step and hands over 132 -- with 128 a
+        // step the sub-lists were full every step and whole trips went through the general code: 3.2 ms a step, round 5), a
+        // sub-list at least one trip's worth
+        const size_t far_per_env = std::max<size_t>(128, (size_t)PAINT_PER_ACTION * b->cone_nb / 4);
+        const int far_cap = (int)std::min<size_t>(std::max<size_t>((size_t)n_envs * far_per_env / PRL_CONE_WORK_LISTS, 64), (size_t)1 << 18);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->cone_far), sizeof(double) * 4 * (size_t)far_cap * PRL_CONE_WORK_LISTS);
         if (e == hipSuccess) e = hipMemcpy(b->cone_work + 2, &far_cap, sizeof(int), hipMemcpyHostToDevice);
     }

@@ -31,7 +31,8 @@ def main():
     _lib._lib = None
     lib = _lib.load()
     lib.prl_debug_cone_stats.argtypes = [C.c_void_p]
-    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(os.environ.get('PRL_PART', 'door_test')), tex_size=(240, 240))
+    tex = int(os.environ.get('PRL_TEX', '240'))
+    tables = part_tables.build_part_tables(mesh=synth_parts.synthetic_mesh(os.environ.get('PRL_PART', 'door_test')), tex_size=(tex, tex))
     n = int(os.environ.get('PRL_ENVS', '4096'))
     steps = int(os.environ.get('PRL_TRACE_STEPS', '20'))
     gen = torch.Generator(device='cuda')
