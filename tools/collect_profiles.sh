@@ -30,6 +30,8 @@ for spec in door_rr:328 door_rf:448 door_rr_big:652; do
   $B --part door_rr_big --tex ${spec##*:} --steps 300 --warmup 60 --no-cpu-baseline > "$OUT/bench_part_${spec%%:*}.json" 2>> "$OUT/bench.err"
 done
 $B --part door_rr_big --tex 652 --policy random-fragment --steps 300 --warmup 100 --no-cpu-baseline > "$OUT/bench_part_door_rr_big_random_fragment.json" 2>> "$OUT/bench.err"
+echo "== cone beams on a large part (772 beams a shot at 70 654 samples: the beam table grows with the sample density)"
+$B --paint-method normal --part door_rr_big --tex 652 --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_normal_part_door_rr_big.json" 2>> "$OUT/bench.err"
 echo "== COLOR_MODE 'HSI' (thickness bytes, bpw:384-434): the door, under the cone beams, a 70 654-sample part"
 $B --color-mode HSI --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_hsi.json" 2>> "$OUT/bench.err"
 $B --color-mode HSI --paint-method normal --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/bench_hsi_normal.json" 2>> "$OUT/bench.err"
