@@ -216,6 +216,11 @@ __global__ __launch_bounds__(256, 2) void cone_finish_kernel_big(StepArgs, int l
             }
             if (beam_hits > 0) {
                 const double rmax = sqrt(wave_max_d(dmax_l));
+                if (P.n_beams > HSI_ROUNDS_FROM && P.n_beams <= 64 * 64) {                                   // (prl_paint.hpp: rounds over a hashed set, linear in the beams)
+                    uint64_t *hash = reinterpret_cast<uint64_t *>(reinterpret_cast<int *>(big_lds) + list_off + (size_t)(blockDim.x >> 6) * a.cone_nb) +
+                                     (size_t)wave * HSI_HASH_WORDS;
+                    hsi_list_deposits(P, list, P.n_beams, lane, c, rmax, thick, row, stat, hash, succ_l);
+                } else
                 for (int b0 = 0; b0 < P.n_beams; b0 += 64) {
                     const int sidx = list[b0 + lane];
                     int mult = 0;
@@ -377,7 +382,7 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
     const StepArgs &a = *static_cast<const StepArgs *>(step_args);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (sel->hsi) {
-        const size_t list_bytes = sizeof(int) * (size_t)a.cone_nb;                  // per wave, behind all the mask copies
+        const size_t list_bytes = sizeof(int) * (size_t)a.cone_nb + sizeof(uint64_t) * HSI_HASH_WORDS;      // per wave, behind all the mask copies: the hit lists, then the hashed sets
         void (*k)(StepArgs, int) = sel->gensec ? cone_finish_kernel_big<true, true> : cone_finish_kernel_big<false, true>;
         const int waves = big_waves(k, a, 5, list_bytes);
         const int list_off = (int)((size_t)waves * 5 * a.mask_stride * 2);          // in ints

@@ -91,7 +91,11 @@ __global__ __launch_bounds__(64 * WAVES) void cone_finish_kernel(StepArgs) {
             }
             if (beam_hits == 0) continue;
             const double rmax = sqrt(wave_max_d(dmax_l));                   // = max of the sqrt's: sqrt is monotone
-            for (int b0 = 0; b0 < P.n_beams; b0 += 64) {
+            if (P.n_beams > HSI_ROUNDS_FROM && P.n_beams <= 64 * 64) {
+                hsi_list_deposits(P, list, P.n_beams, lane, c, rmax, thick, row, stat,
+                                  reinterpret_cast<uint64_t *>(s_list + (size_t)WAVES * a.cone_nb) + (size_t)wave * HSI_HASH_WORDS, succ_l);
+            } else
+            for (int b0 = 0; b0 < P.n_beams; b0 += 64) {                     // (more than 4 096 beams a shot: the first entry counts the rest)
                 const int sidx = list[b0 + lane];
                 int mult = 0;
                 bool first = sidx >= 0;
@@ -183,7 +187,7 @@ PRL_HIDDEN int KFN(cone)(const void *step_args, const PrlStepSel *sel, void *str
     const dim3 grid((a.n_envs + 3) / 4), block(256);
     if (sel->hsi) {
         void (*k)(StepArgs) = sel->gensec ? cone_finish_kernel<PRL_KW, true, true, 4> : cone_finish_kernel<PRL_KW, false, true, 4>;
-        const size_t lds = sizeof(int) * 4 * (size_t)a.cone_nb;        // the four waves' hit lists
+        const size_t lds = sizeof(int) * 4 * (size_t)a.cone_nb + 4 * sizeof(uint64_t) * HSI_HASH_WORDS;      // the four waves' hit lists, then their hashed sets
         if (const hipError_t e = prl_grant_dyn_lds(reinterpret_cast<const void *>(k), lds)) return (int)e;      // (once per device)
         hipLaunchKernelGGL(k, grid, block, lds, s, a);
     } else if (sel->gensec) {

@@ -578,4 +578,73 @@ __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds,
     for (int k = 0; k < KW; ++k) last[k] = new_last[k];
 }
 
+// COLOR_MODE 'HSI' under the cone beams (bpw:419-434; oracle/paint_oracle.c apply_paint_hsi_list): the deposits of ONE shot's
+// hit list -- every ENTRY deposits on its sample, a sample under k beams receives k deposits of the same quantity, each unless
+// the byte is 0 at that moment.  `list`: the shot's hit list in LDS (n_beams entries, -1 = no hit), up to 64 trips of 64.
+// Until round 5 the first entry of a sample counted its multiplicity by reading the whole list: quadratic in the beams (a
+// 70 654-sample part casts 772 a shot: 22.8 ms a step).  Here in rounds: the pending entries race for a bit of a hashed set
+// (16 384 bits, cleared per round); a winner makes ONE deposit and retires, a loser -- an entry of the same sample, or of
+// another that hashes alike -- waits for the next round.  A sample gets at most one deposit a round and as many rounds as it
+// has entries: the same bytes.  Rounds = the largest multiplicity (+ the odd collision); used from HSI_ROUNDS_FROM beams a shot.  Then the status bits (byte == 255)
+// through each sample's first entry, found with the hit row's own atomicOr.  `row`, `stat`: the shot's hit / status rows in LDS.
+constexpr int HSI_HASH_WORDS = 256;
+constexpr int HSI_ROUNDS_FROM = 256;      // beams a shot from which the rounds pay (the door's 104: 253 us a step counting, 404 in rounds --
+                                          // few samples under many beams: ten rounds; 772 beams at 70 654 samples: 22.8 -> 6.6 ms)
+__device__ __forceinline__ void hsi_list_deposits(PartRef P, const int *list, int n_beams, int lane, const double c[3], double rmax,
+                                                  uint8_t *thick, uint64_t *row, uint64_t *stat, uint64_t *hash, double &succ_l) {
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    uint64_t pending = 0, rep = 0;
+    {
+        int t = 0;
+        for (int b0 = 0; b0 < n_beams; b0 += 64, ++t) {
+            const int sidx = list[b0 + lane];
+            if (sidx >= 0) {
+                pending |= 1ull << t;
+                const unsigned long long bit = 1ull << (sidx & 63);
+                const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long *>(&row[sidx >> 6]), bit);
+                if (!(old & bit)) rep |= 1ull << t;
+            }
+        }
+    }
+    while (ballot64(pending != 0) != 0) {
+        for (int i = lane; i < HSI_HASH_WORDS; i += 64) hash[i] = 0;
+        sync();
+        int t = 0;
+        for (int b0 = 0; b0 < n_beams; b0 += 64, ++t) {
+            const bool mine = (pending >> t) & 1;
+            if (ballot64(mine) == 0) continue;
+            const int sidx = list[b0 + lane];
+            if (mine) {
+                const uint32_t h = ((uint32_t)sidx * 2654435761u) >> 18;      // 14 bits
+                const unsigned long long bit = 1ull << (h & 63);
+                const unsigned long long old = atomicOr(reinterpret_cast<unsigned long long *>(&hash[h >> 6]), bit);
+                if (!(old & bit)) {
+                    pending &= ~(1ull << t);
+                    const double dx = c[0] - ldg(P.samp[0], sidx), dy = c[1] - ldg(P.samp[1], sidx), dz = c[2] - ldg(P.samp[2], sidx);
+                    const double dd = (dx * dx + dy * dy) + dz * dz;
+                    const double q = sqrt(dd) / rmax;
+                    const int quantity = (int)(25 * (1 - q * q)) + 1;
+                    const uint8_t v = thick[sidx];
+                    if (v != 0) {
+                        thick[sidx] = (uint8_t)(v - quantity);
+                        succ_l += quantity / 255.0;
+                    }
+                }
+            }
+        }
+        sync();                                      // (a sample's next deposit reads this one's byte: same wave, in order)
+    }
+    int t = 0;
+    for (int b0 = 0; b0 < n_beams; b0 += 64, ++t) {
+        if ((rep >> t) & 1) {
+            const int sidx = list[b0 + lane];
+            if (thick[sidx] == 255) atomicOr(reinterpret_cast<unsigned long long *>(&stat[sidx >> 6]), 1ull << (sidx & 63));
+        }
+    }
+}
+
 }  // namespace
