@@ -675,11 +675,55 @@ __device__ __forceinline__ int nearest_sample_bfs(PartRef P, const double pt[3],
     while (top > 0 && P.py_nx[top - 1] * P.py_ny[top - 1] <= 8) --top;
     const int top_nx = __builtin_amdgcn_readlane(lv_nx, top), top_n = top_nx * __builtin_amdgcn_readlane(lv_ny, top);
     int nf = want ? top_n : 0;
-    for (int i = m; want && i < top_n; i += BFS_G) cur[i] = (top << 24) | ((i / top_nx) << 12) | (i % top_nx);      // (node: level << 24 | cy << 12 | cx)
+    // [-DPRL_FAR_HINT_START, the far kernel: every entry carries a bound]  A sample within the bound lies within r = sqrt(bound) of
+    // the point in the principal plane, so in the 3 x 3 nodes around the point's own at the lowest level whose nodes are at least r
+    // wide: the walk of this group can start THERE (nine nodes, the ones outside the grid marked so that their children test as
+    // outside) instead of at the top -- two to four levels lower on the door, more on a large part's deeper pyramid.
+    int lg = top, scx = 0, scy = 0;
+#ifdef PRL_FAR_HINT_START
+    if constexpr (!SEED) {
+        if (want) {
+            const double rc = sqrt(bound) * P.fg_inv;                 // r in cells
+            const int k = (int)fmin(rc * 1.000001 + 1.001, 1.0e9);    // >= ceil(r in cells), a hair more
+            int l = k <= 1 ? 0 : 32 - __builtin_clz((unsigned)(k - 1));     // the lowest level whose nodes span k cells
+            l = l < 1 ? 1 : l;
+            if (l < top) {
+                int cx = cell_coord(sel3(pt[0], pt[1], pt[2], P.a1), P.fg_o1, P.fg_inv, P.fg_nx);
+                int cy = cell_coord(sel3(pt[0], pt[1], pt[2], P.a2), P.fg_o2, P.fg_inv, P.fg_ny);
+                cx = cx < 0 ? 0 : (cx > P.fg_nx - 1 ? P.fg_nx - 1 : cx);
+                cy = cy < 0 ? 0 : (cy > P.fg_ny - 1 ? P.fg_ny - 1 : cy);
+                lg = l;
+                scx = cx >> l;
+                scy = cy >> l;
+                nf = 0;
+            }
+        }
+    }
+    const int level_from = -wave_min_i(-(want ? lg : 1));
+#else
+    const int level_from = top;
+#endif
+    for (int i = m; want && lg == top && i < top_n; i += BFS_G) cur[i] = (top << 24) | ((i / top_nx) << 12) | (i % top_nx);      // (node: level << 24 | cy << 12 | cx)
     lds_wave_sync();
-    for (int level = top; level >= 1; --level) {                     // (wave-uniform)
+    for (int level = level_from; level >= 1; --level) {              // (wave-uniform)
         const int cl = level - 1, cnx = __builtin_amdgcn_readlane(lv_nx, cl), cny = __builtin_amdgcn_readlane(lv_ny, cl),
                   off = __builtin_amdgcn_readlane(lv_off, cl);
+#ifdef PRL_FAR_HINT_START
+        if constexpr (!SEED) {
+            if (ballot64(want && lg == level && lg != top) != 0) {   // the groups whose walk starts at this level
+                const int lnx = __builtin_amdgcn_readlane(lv_nx, level), lny = __builtin_amdgcn_readlane(lv_ny, level);
+                if (want && lg == level && lg != top) {
+                    for (int i = m; i < 9; i += BFS_G) {
+                        const int nx_ = scx + (i % 3) - 1, ny_ = scy + (i / 3) - 1;
+                        const bool ok = (nx_ >= 0) & (nx_ < lnx) & (ny_ >= 0) & (ny_ < lny);
+                        cur[i] = (level << 24) | ((ok ? ny_ : 0xfff) << 12) | (ok ? nx_ : 0xfff);
+                    }
+                    nf = 9;
+                }
+                lds_wave_sync();
+            }
+        }
+#endif
         int nn = 0;
         float tight = INFINITY;
         const int rounds = -wave_min_i(-((nf * 4 + BFS_G - 1) >> BFS_SHIFT));
