@@ -219,7 +219,8 @@ def test_cone_beams_full_size_8_steps_equals_oracle():
 SOAK_SLICE_STEPS = 300          # the slice of the soak that every `-m gpu` run takes (headline configuration only)
 
 
-@pytest.mark.parametrize('part,starts,seed', [('door_test', 'anchor', 11), ('door_test', 'all', 12), ('square', 'all', 13)])
+@pytest.mark.parametrize('part,starts,seed', [('door_test', 'anchor', 11), ('door_test', 'all', 12), ('square', 'all', 13),
+                                               ('test', 'all', 14)])         # ('test': the coarse sheet with the reference's stale kd-tree)
 def test_soak_many_steps_equals_oracle(part, starts, seed):
     """The headline batch over many steps -- dozens of episode ends per env, every row against the oracle.  The headline
     configuration (door, anchor starts: what bench.py runs) takes SOAK_SLICE_STEPS = 300 steps x 4 096 envs in every `-m gpu`
@@ -235,8 +236,9 @@ def test_soak_many_steps_equals_oracle(part, starts, seed):
     tables = synthetic_tables(part)
     sp = start_points_for(tables, starts)
     n = 4096
-    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True)
-    orc = oracle.Oracle(tables, n, start_points=sp, threads=16)
+    kw = dict(max_possible_point=14000) if part == 'test' else {}
+    env = BatchedPaintEnv(_dt(tables, sp), n, auto_reset=True, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16, **kw)
     ends, fullest = _run(env, orc, np.full(n, len(sp)), steps, seed, n)
     print('soak %s / %s: %d steps, %d episode ends (%.1f per env), fullest mask %.2f' % (part, starts, steps, ends, ends / n, fullest))
     if not asked:
@@ -245,7 +247,7 @@ def test_soak_many_steps_equals_oracle(part, starts, seed):
 
 
 @pytest.mark.skipif(not __import__('os').environ.get('PAINTRL_SOAK_STEPS'), reason='soak run: set PAINTRL_SOAK_STEPS (e.g. 400)')
-@pytest.mark.parametrize('case', ['grid_overlap_turning', 'mixed', 'cone_beams', 'large_part'])
+@pytest.mark.parametrize('case', ['grid_overlap_turning', 'mixed', 'cone_beams', 'large_part', 'thickness'])
 def test_soak_other_configurations_equal_oracle(case):
     """The soak run for BASELINE configs 3 (grid + penalties), 5 (mixed door / sheet) and the cone-beam painter (a twentieth
     of the steps: its oracle is the slow one)."""
@@ -275,12 +277,14 @@ def test_soak_other_configurations_equal_oracle(case):
     else:
         sp = start_points_for(door, 'anchor')
         kw = dict(obs_mode='grid', obs_grad=4, overlap_penalty=True, turning_penalty=True) if case == 'grid_overlap_turning' \
-            else dict(paint_method='normal')
+            else (dict(color_mode='HSI') if case == 'thickness' else dict(paint_method='normal'))
         if case == 'cone_beams':
             steps = max(8, steps // 20)
+        if case == 'thickness':                   # (COLOR_MODE 'HSI': every byte after every step; a quarter of the steps)
+            steps = max(20, steps // 4)
         env = BatchedPaintEnv(_dt(door, sp), n, auto_reset=True, **kw)
         orc = oracle.Oracle(door, n, start_points=sp, threads=16, **kw)
         n_start = np.full(n, len(sp))
-    ends, fullest = _run(env, orc, n_start, steps, 77, 1)
+    ends, fullest = _run(env, orc, n_start, steps, 77, 1, reward_atol=1e-12 if case == 'thickness' else 0.0)
     print('soak %s: %d steps, %d episode ends (%.1f per env), fullest mask %.2f' % (case, steps, ends, ends / n, fullest))
     env.close()
