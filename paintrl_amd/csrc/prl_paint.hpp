@@ -437,14 +437,14 @@ __device__ void paint_shots_union(PartRef P, double radius, const double *cen_ld
 // bounding block the distance alone decides -- oracle/paint_oracle.c ball_query.  Words the balls cannot reach are left out by the
 // word-box test of paint_shots_union's pre-pass; words not visited keep their bytes and painted bits and lose their last-shot
 // word (HbmMasks::paint_hsi clears what was set before and not visited now; register masks: the new last-shot words start at zero).
-// Words: RegWords (masks in registers) or HbmWords (rows in HBM).  62 us on the door, 155 us at 70 654 samples.
+// Words: RegWords (masks in registers) or HbmWords (rows in HBM).  61 us on the door, 140 us at 70 411 samples.
 template <int KW>
 __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
-                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter);
+                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter, double *scratch);
 
 template <typename Words>
 __device__ void paint_shots_hsi_words(PartRef P, double radius, const double *cen_lds, int lane, const Words &words, uint8_t *thick,
-                                      double &succeeded, int &pixel_counter) {
+                                      double &succeeded, int &pixel_counter, double *scratch) {      // scratch: 10 doubles of this wave's LDS
     const double r2 = radius * radius;
     double lo1 = INFINITY, hi1 = -INFINITY, lo2 = INFINITY, hi2 = -INFINITY;
 #pragma unroll
@@ -518,9 +518,18 @@ __device__ void paint_shots_hsi_words(PartRef P, double radius, const double *ce
 #pragma unroll
         for (int k = 0; k < PAINT_PER_ACTION; ++k) dmax_l[k] = (dd[k] <= r2) & (dd[k] > dmax_l[k]) ? dd[k] : dmax_l[k];
     });
-    double rmax[PAINT_PER_ACTION];
+    // (the five r's and 1 / r^2's wait in LDS: twenty scalar registers across the word loop were spilled to vector lanes)
 #pragma unroll
-    for (int k = 0; k < PAINT_PER_ACTION; ++k) rmax[k] = uni_d(sqrt(wave_max_d(dmax_l[k])));      // (no hit: NaN, and no deposit either)
+    for (int k = 0; k < PAINT_PER_ACTION; ++k) {
+        const double r = sqrt(wave_max_d(dmax_l[k]));             // (no hit: NaN, and no deposit either)
+        if (lane == 0) {
+            scratch[k] = r;
+            scratch[PAINT_PER_ACTION + k] = 1.0 / (r * r);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // pass 1: the deposits, word by word
     double succ_l = 0.0;
     int pix = 0;
@@ -549,9 +558,21 @@ __device__ void paint_shots_hsi_words(PartRef P, double radius, const double *ce
         for (int k = 0; k < PAINT_PER_ACTION; ++k) {
             if (b[k]) {
                 const bool hit = (b[k] >> lane) & 1;
+                // quantity = int(25 (1 - (d / r)^2)) + 1 with d = sqrt(dd): a square root and a division per hit.  25 (1 - dd / r^2)
+                // with the shot's 1 / r^2 is the same number to a few units in the last place (< 1e-13 absolute); its integer part
+                // can only differ where it lies within that of an integer -- those lanes (the farthest sample, a sample on the
+                // centre, a NaN) take the reference's own expression
+                const double t = 25 * (1 - dd[k] * scratch[PAINT_PER_ACTION + k]);
+                const double fr = t - floor(t);
+                int quantity = (int)t + 1;
+                const bool exact = hit && !((fr > 1.0e-9) & (fr < 1.0 - 1.0e-9));
+                if (ballot64(exact) != 0) {
+                    if (exact) {
+                        const double q = sqrt(dd[k]) / scratch[k];
+                        quantity = (int)(25 * (1 - q * q)) + 1;
+                    }
+                }
                 if (hit && v != 0) {
-                    const double q = sqrt(dd[k]) / rmax[k];
-                    const int quantity = (int)(25 * (1 - q * q)) + 1;
                     v = (uint8_t)(v - quantity);
                     succ_l += quantity / 255.0;
                 }
@@ -571,9 +592,9 @@ __device__ void paint_shots_hsi_words(PartRef P, double radius, const double *ce
 // masks in registers (parts of up to 16 384 samples)
 template <int KW>
 __device__ void paint_shots_hsi(PartRef P, double radius, const double *cen_lds, int lane, uint64_t painted[KW_MAX],
-                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter) {
+                                uint64_t last[KW_MAX], uint8_t *thick, double &succeeded, int &pixel_counter, double *scratch) {
     uint64_t new_last[KW_MAX] = {0, 0, 0, 0};
-    paint_shots_hsi_words(P, radius, cen_lds, lane, RegWords<KW>{painted, last, new_last, lane}, thick, succeeded, pixel_counter);
+    paint_shots_hsi_words(P, radius, cen_lds, lane, RegWords<KW>{painted, last, new_last, lane}, thick, succeeded, pixel_counter, scratch);
 #pragma unroll
     for (int k = 0; k < KW; ++k) last[k] = new_last[k];
 }

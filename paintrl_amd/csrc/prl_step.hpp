@@ -373,10 +373,11 @@ __device__ __forceinline__ int step_env(PartRef P, CfgRef C, int part_id, int en
     int succeeded = 0, pixel_counter = 0;
     double succeeded_f = 0.0;                      // HSI: the float sum of deposited fractions
     if constexpr (HSI && BIG) {
-        masks.paint_hsi(P, C.paint_radius, cen, a.thick() + (size_t)env * 64 * a.mask_stride(), succeeded_f, pixel_counter);
+        masks.paint_hsi(P, C.paint_radius, cen, a.thick() + (size_t)env * 64 * a.mask_stride(), succeeded_f, pixel_counter,
+                        reinterpret_cast<double *>(wl.cand));      // (the candidate list's LDS is free while the painter runs)
     } else if constexpr (HSI) {
         paint_shots_hsi<KW>(P, C.paint_radius, cen, lane, painted, last, a.thick() + (size_t)env * 64 * a.mask_stride(),
-                            succeeded_f, pixel_counter);
+                            succeeded_f, pixel_counter, reinterpret_cast<double *>(wl.cand));
     } else {
         if constexpr (BIG) {
             masks.paint(P, C.paint_radius, cen, succeeded, pixel_counter);      // (LDS copies: BigMasks, rows in HBM: HbmMasks)
@@ -511,8 +512,8 @@ struct HbmMasks {
     }
     // COLOR_MODE 'HSI' (bpw:384-434) for the five shots, rows in place (paint_shots_hsi_words)
     __device__ __forceinline__ void paint_hsi(PartRef P, double radius, const double *cen, uint8_t *thick, double &succeeded,
-                                              int &pixel_counter) const {
-        paint_shots_hsi_words(P, radius, cen, lane, HbmWords{painted, last, lane, &vis, &nzn}, thick, succeeded, pixel_counter);
+                                              int &pixel_counter, double *scratch) const {
+        paint_shots_hsi_words(P, radius, cen, lane, HbmWords{painted, last, lane, &vis, &nzn}, thick, succeeded, pixel_counter, scratch);
         zero_last(old_nz & ~vis);
         if (lane < nz_words() && nzn != old_nz) nz[lane] = nzn;
         old_nz = nzn;
