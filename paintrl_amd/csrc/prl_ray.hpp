@@ -253,8 +253,11 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
     const double d0 = e[0] - o[0], d1 = e[1] - o[1], d2 = e[2] - o[2];
     double best_t = INFINITY, best_det = 0, tmin = INFINITY;
     int best_r = 0x7fffffff, best_i = -1, win = -1;
+    // (the ray before this one missed: this one probably does too -- the general search then takes the whole segment at once)
+    bool after_a_miss = hint < 0;
 #ifdef PRL_FORCE_GENERAL_RAY                         // diagnostic build: never take the convex fast path
     hint = -1;
+    after_a_miss = false;                            // (... and both stages of the general search)
 #endif
 #ifndef PRL_FACET_TILE                               // A/B switch: the LDS tile lost to the scalar test + global rounds
     tile = nullptr;                                  // (profiles/r04_ab_log.txt: 42.0 against 40.2 us), so it is off
@@ -473,7 +476,12 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
         uint64_t any_chunk = 0;
         for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64)
             any_chunk |= ballot64(box_overlap(sb_all, ldg(chunk_boxes, 2 * (cbase + lane)), ldg(chunk_boxes, 2 * (cbase + lane) + 1)));
-        for (int stage = any_chunk ? 0 : 2; stage < 2; ++stage) {
+        // Two stages -- the near part of the segment first: a tool on the part hits at t ~ 0.1 -- unless the previous ray missed
+        // (no facet hint): a tool within millimetres of the rim, tilted so that the outline does not certify its rays, casts five
+        // that pass over the rim and hit nothing; both stages were 4 - 8 chunks each, every chunk a dependent round trip: the
+        // one 42 us wave that a launch of 4 096 envs waited for in three launches of five (tools/wave_trace.py, the LAST wave
+        // of each launch).  The full stage alone finds the same closest hit if there is one (a hit at t <= 0.125 is in both).
+        for (int stage = any_chunk ? (after_a_miss ? 1 : 0) : 2; stage < 2; ++stage) {
             const double tmax = stage == 0 ? 0.125 : 1.0;
             if (stage == 1) WCNT(1, 1);
             const SegBox sb = stage == 0 ? seg_box(o3, d3, tmax) : sb_all;
@@ -481,25 +489,43 @@ __device__ int ray_closest_wave(PartRef P, const double o[3], const double e[3],
             for (int cbase = 0; cbase < P.n_col_chunks; cbase += 64) {
                 const f32x4 ca = ldg(chunk_boxes, 2 * (cbase + lane)), cb = ldg(chunk_boxes, 2 * (cbase + lane) + 1);
                 uint64_t cm = ballot64(box_overlap(sb, ca, cb));   // table is padded to 64 with empty boxes
-                while (cm) {
-                    WCNT(2, 1);
-                    const int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+                // (a chunk's triangle boxes are a dependent round trip: the next chunk's are asked for before this one's are
+                // looked at -- a ray that misses near the rim visits five of them)
+                if (cm) {
+                    int i = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
                     cm &= cm - 1;
-                    const f32x4 ba = ldg(boxes, 2 * i), bb = ldg(boxes, 2 * i + 1);
-                    const bool pass = box_overlap(sb, ba, bb);
-                    const uint64_t pm = ballot64(pass);
-                    if (pm == 0) continue;
-                    const int np = __popcll(pm);
-                    if (n_cand + np > 64) {                        // list full: test what is queued first
-                        __builtin_amdgcn_wave_barrier();
-                        mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
-                        __builtin_amdgcn_wave_barrier();
-                        n_cand = 0;
+                    f32x4 ba = ldg(boxes, 2 * i), bb = ldg(boxes, 2 * i + 1);
+                    for (;;) {
+                        WCNT(2, 1);
+                        const bool more = cm != 0;
+                        int i_n = i;
+                        f32x4 na = ba, nb = bb;
+                        if (more) {
+                            i_n = ((cbase + __builtin_ctzll(cm)) << 6) + lane;
+                            cm &= cm - 1;
+                            na = ldg(boxes, 2 * i_n);
+                            nb = ldg(boxes, 2 * i_n + 1);
+                        }
+                        const bool pass = box_overlap(sb, ba, bb);
+                        const uint64_t pm = ballot64(pass);
+                        if (pm != 0) {
+                            const int np = __popcll(pm);
+                            if (n_cand + np > 64) {                    // list full: test what is queued first
+                                __builtin_amdgcn_wave_barrier();
+                                mt_one(P, lane < n_cand ? cand[lane] : -1, o, d0, d1, d2, tmax, best_t, best_r, best_i, best_det);
+                                __builtin_amdgcn_wave_barrier();
+                                n_cand = 0;
+                            }
+                            if (pass)
+                                cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
+                            n_cand += np;
+                        }
+                        if (!more) break;
+                        i = i_n;
+                        ba = na;
+                        bb = nb;
                     }
-                    if (pass)
-                        cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))] = i;
-                    n_cand += np;
                 }
             }
             if (n_cand) {

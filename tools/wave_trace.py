@@ -50,6 +50,7 @@ def main():
         env.step_raw(acts[s])
     torch.cuda.synchronize()
     rows, rows16, rows_ph = [], [], []
+    poses = []
     have_phase = hasattr(lib, 'prl_debug_wave_phase')
     buf_ph = np.zeros((n, 16), dtype=np.uint32)
     buf = np.zeros((n, 4), dtype=np.uint64)
@@ -65,6 +66,10 @@ def main():
         rc = lib.prl_debug_wave_trace(buf.ctypes.data, n)
         assert rc == 0
         rows.append(buf.copy())
+        if os.environ.get('PRL_TRACE_STATE'):            # the motion state after the traced step, for the launch's last wave
+            st_ = env.state()
+            poses.append(np.concatenate([st_['pose'], st_['quat'], st_['terminate_counter'][:, None].astype(float),
+                                         st_['last_on_part'][:, None].astype(float)], axis=1))
         lib.prl_debug_wave_trace16(buf16.ctypes.data, n)
         rows16.append(buf16.copy())
         if have_phase:
@@ -134,6 +139,22 @@ def main():
     slow = life >= thr
     print('slowest 1 %% (life >= %.1f us): ' % thr + '  '.join('%s %.2f' % (nm, cnt[slow][:, k].mean()) for k, nm in enumerate(SLOTS)) +
           '  done %.2f' % done[slow].mean())
+    # the last wave of every launch: what it did, and how much later than the launch's 99.9th percentile it ended
+    last = end.argmax(axis=1)
+    rows_ = np.arange(end.shape[0])
+    print('the LAST wave of each launch (%d launches): life mean %.1f us, end mean %.1f us (launch p99.9 of ends mean %.1f); counters mean: ' %
+          (end.shape[0], life[rows_, last].mean(), end[rows_, last].mean(), np.percentile(end, 99.9, axis=1).mean()) +
+          '  '.join('%s %.2f' % (nm, cnt[rows_, last][:, k].mean()) for k, nm in enumerate(SLOTS)))
+    if poses:
+        lo_, hi_ = tables.sample_pos.min(0), tables.sample_pos.max(0)
+        print('   samples span', lo_, hi_)
+        for i in range(min(12, end.shape[0])):
+            print('   launch %2d last wave env %d: pose %s quat %s terminate_counter %d last_on_part %d' %
+                  (i, last[i], np.round(poses[i][last[i], :3], 4).tolist(), np.round(poses[i][last[i], 3:7], 4).tolist(),
+                   int(poses[i][last[i], 7]), int(poses[i][last[i], 8])))
+    for i in range(min(12, end.shape[0])):
+        print('   launch %2d: last wave ends %.1f us, life %.1f, counters %s, done %d; next-to-last end %.1f' %
+              (i, end[i, last[i]], life[i, last[i]], cnt[i, last[i]].tolist(), int(done[i, last[i]]), np.sort(end[i])[-2]))
     for k, nm in enumerate(SLOTS):
         vals = np.unique(cnt[..., k])
         if len(vals) > 12:
