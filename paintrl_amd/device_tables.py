@@ -171,7 +171,7 @@ class DeviceTables(object):
         facing = np.nan_to_num(facing)
         # chunks of 64: small facets bucketed by a coarse K x K grid over the principal plane (compact
         # chunk boxes), then large front-facing, large back-facing and large other facets, each group
-        # padded to a multiple of 64 so that no chunk mixes groups
+        # padded to a multiple of 64
         small_ids = np.nonzero(~large)[0]
         K = max(1, int(round(np.sqrt(max(small_ids.size, 1) / 48.0))))
         cen = corners.mean(axis=1)
@@ -180,8 +180,11 @@ class DeviceTables(object):
         k1 = np.clip(((cen[:, a1] - lo[:, a1].min()) / span1 * K).astype(np.int64), 0, K - 1)
         k2 = np.clip(((cen[:, a2] - lo[:, a2].min()) / span2 * K).astype(np.int64), 0, K - 1)
         buckets = [small_ids[(k2[small_ids] * K + k1[small_ids]) == c] for c in range(K * K)]
-        buckets += [np.nonzero(large & (facing > 0.5))[0], np.nonzero(large & (facing < -0.5))[0],
-                    np.nonzero(large & (np.abs(facing) <= 0.5))[0]]
+        big = [np.nonzero(large & (facing > 0.5))[0], np.nonzero(large & (facing < -0.5))[0],
+               np.nonzero(large & (np.abs(facing) <= 0.5))[0]]
+        # (their boxes span the part whichever way they face: every general search visits all three chunks, each a dependent
+        # round trip -- as one chunk where they fit one: the door's hull has 6 + 9 + 30 of them)
+        buckets += [np.concatenate(big)] if sum(b.size for b in big) <= 64 else big
         slots = []
         for ids in buckets:
             if ids.size:
