@@ -136,6 +136,8 @@ __device__ unsigned long long g_pol_stamps[8];          // policy_forward of wor
 #define PRIO_YOUNG_DECL() const int prio_slot = __builtin_amdgcn_s_getreg(63492) & 15
 #ifdef PRL_PRIO_ROTATE                   // A/B: the favoured pair of slots rotates with the phase (ph = 2 .. 6: shots 2-4, painting, observation)
 #define PRIO_IS_YOUNG(ph) (((prio_slot + (ph)) & 2) != 0)
+#elif defined(PRL_PRIO_MASK)             // A/B: the favoured slots as a bit mask (0xa: slots 1 and 3, 0x3: slots 0 and 1, ...)
+#define PRIO_IS_YOUNG(ph) (((PRL_PRIO_MASK) >> (prio_slot & 3)) & 1)
 #else
 #define PRIO_IS_YOUNG(ph) (prio_slot >= PRL_PRIO_SLOT)
 #endif
