@@ -37,8 +37,8 @@ constexpr int FRAG_WAVES = POLICY_WAVES;
 struct FragmentRows {
     const FragmentArgs CAS *f;
     int t, n, od;
-    __device__ __forceinline__ uint8_t *thick() const { return nullptr; }
-    __device__ __forceinline__ int mask_stride() const { return 0; }
+    __device__ __forceinline__ uint8_t *thick() const { return f->s.thick; }          // (COLOR_MODE 'HSI')
+    __device__ __forceinline__ int mask_stride() const { return f->s.mask_stride; }
     __device__ __forceinline__ double *obs() const { return f->obs + (size_t)(t + 1) * n * od; }
     __device__ __forceinline__ double *final_obs() const { return f->final_obs ? f->final_obs + (size_t)t * n * od : nullptr; }
     __device__ __forceinline__ double *reward() const { return f->reward + (size_t)t * n; }
@@ -91,7 +91,7 @@ __device__ __forceinline__ int opaque_s(int v) {
     return v;
 }
 
-template <int KW, bool KD, bool GRID>
+template <int KW, bool KD, bool GRID, bool HSI>
 __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(FragmentArgs) {
     extern __shared__ float lds[];
     const FragmentArgs CAS *f0 = (const FragmentArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
             __shared__ double s_kd[KD ? FRAG_WAVES : 1][KD ? KD_HEAP * 5 : 1];
             const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
             PROF_BEGIN();
-            const int dn = step_env<KW, false, true, false, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+            const int dn = step_env<KW, false, true, HSI, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                                 new_angle, row, wl PROF_PASS);
             store_state_live(state_rec, S, lane, dn != 0);
         }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * FRAG_WAVES, 4) void rollout_fragment_kernel(Fr
 }
 // The env step of act_step_kernel: everything is derived afresh from laundered lane / wave numbers and from the
 // kernel-argument segment, so that nothing of the policy phase is still held in registers (the step is at its ceiling).
-template <int KW, bool KD, bool GRID>
+template <int KW, bool KD, bool GRID, bool HSI>
 __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int act, int (*s_cand)[64],
                                              double (*s_centres)[PAINT_PER_ACTION * 3 + 1], double (*s_kd)[KD ? KD_HEAP * 5 : 1]) {
     const ActStepArgs CAS &f = *(const ActStepArgs CAS *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -187,7 +187,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
     decode_discrete_action(C, act, delta1, delta2, new_angle);
     const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
     PROF_BEGIN();
-    const int dn = step_env<KW, false, true, false, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,
+    const int dn = step_env<KW, false, true, HSI, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2, new_angle,
                                                         StepRows{&a}, wl PROF_PASS);
     store_state_live(state_rec, S, lane, dn != 0);
 }
@@ -197,7 +197,7 @@ __device__ __forceinline__ void act_step_env(int env, int lane, int wave, int ac
 // sixteen envs of a workgroup first run the policy on their observations together (prl_policy.hpp: three MFMA layers,
 // ~3 us, bound by the weight reads it issues up front), each wave then steps its own env with the sampled action.
 // No second launch and no ~2.5 us of dispatch gaps per step; rows as prl_policy_act + prl_batch_step write them.
-template <int KW, bool KD, bool GRID>
+template <int KW, bool KD, bool GRID, bool HSI>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs) {
     extern __shared__ float lds[];
     __shared__ int s_cand[POLICY_WAVES][64];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void act_step_kernel(ActStepArgs
     FRAG_COUNT();
     FRAG_FLUSH();
     if (env >= n_envs) return;
-    act_step_env<KW, KD, GRID>(opaque_s((int)blockIdx.x) * POLICY_WAVES + opaque_s(wave), opaque_v((int)(threadIdx.x & 63)), opaque_s(wave),
+    act_step_env<KW, KD, GRID, HSI>(opaque_s((int)blockIdx.x) * POLICY_WAVES + opaque_s(wave), opaque_v((int)(threadIdx.x & 63)), opaque_s(wave),
                          act, s_cand, s_centres, s_kd);
 }
 // ---------------------------------------------------------------- a whole fragment WITH the policy in one persistent launch
@@ -250,7 +250,7 @@ __device__ __forceinline__ const PolicyFragmentArgs CAS *opaque(const PolicyFrag
     return p;
 }
 
-template <int KW, bool KD, bool GRID>
+template <int KW, bool KD, bool GRID, bool HSI>
 __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(PolicyFragmentArgs) {
     extern __shared__ float lds[];
     __shared__ int s_cand[POLICY_WAVES][64];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * POLICY_WAVES) void rollout_policy_kernel(Polic
             const FragmentRows row{&h.f, t, a.n_envs, obs_dim_of(C.obs_mode, C.obs_grad)};
             const WaveLds wl{s_cand[wave], s_centres[wave], nullptr, s_kd[KD ? wave : 0], nullptr, nullptr, nullptr, 0};      // (sixteen waves' tree copies do not fit)
             PROF_BEGIN();
-            const int dn = step_env<KW, false, true, false, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
+            const int dn = step_env<KW, false, true, HSI, KD, GRID ? 1 : 0>(P, C, part_id, env, lane, S, state_rec, masks, delta1, delta2,
                                                                 new_angle, row, wl PROF_PASS);
             store_state_live(state_rec, S, lane, dn != 0);
         }
@@ -350,9 +350,11 @@ int launch_dyn(void (*kernel)(Args), const Args &args, int n_envs, int waves, si
 
 // flags: bit 0 = some part carries the stale kd-tree, bit 1 = OBS_MODE 'grid' (the kernels are built per observation family like
 // step_kernel: prl_observe.hpp observation_wave OBSM)
-#define PRL_ROLLOUT_PICK(kernel, flags)                                                                      \
-    (((flags)&2) ? (((flags)&1) ? kernel<PRL_KW, true, true> : kernel<PRL_KW, false, true>)                  \
-                 : (((flags)&1) ? kernel<PRL_KW, true, false> : kernel<PRL_KW, false, false>))
+#define PRL_ROLLOUT_PICK2(kernel, flags, H)                                                                  \
+    (((flags)&2) ? (((flags)&1) ? kernel<PRL_KW, true, true, H> : kernel<PRL_KW, false, true, H>)            \
+                 : (((flags)&1) ? kernel<PRL_KW, true, false, H> : kernel<PRL_KW, false, false, H>))
+// (bit 2 = COLOR_MODE 'HSI': the thickness painter, round 5)
+#define PRL_ROLLOUT_PICK(kernel, flags) (((flags)&4) ? PRL_ROLLOUT_PICK2(kernel, flags, true) : PRL_ROLLOUT_PICK2(kernel, flags, false))
 
 PRL_HIDDEN int KFN(act_step)(const void *act_step_args, size_t policy_lds, int flags, void *stream) {
     const ActStepArgs &f = *static_cast<const ActStepArgs *>(act_step_args);

@@ -1263,15 +1263,18 @@ static int check_rollout_batch(PrlBatch *b, const char *who) {
 }
 
 // The fused rollout kernels (k_rollout.hip) are built around the ball painter's step (masks in registers, or for parts beyond
-// 16 384 samples in HBM) and the 4-sector observation; every other configuration (cone beams, COLOR_MODE 'HSI', atan2
-// sectors) takes the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
+// 16 384 samples in HBM; COLOR_MODE 'RGB' or 'HSI') and the 4-sector / grid observation; the other configurations (cone beams,
+// atan2 sectors) take the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
 static bool fused_rollout(const PrlBatch *b) {
     const PrlConfig &c = b->cfg;
-    return c.color_mode == PRL_COLOR_RGB && c.paint_method == PRL_PAINT_FAST && !general_section(c);
+    return c.paint_method == PRL_PAINT_FAST && !general_section(c);
 }
 
-// which build of a fused rollout kernel a batch takes (k_rollout.hip): bit 0 the stale kd-tree, bit 1 OBS_MODE 'grid'
-static int rollout_flags(const PrlBatch *b) { return (b->kd ? 1 : 0) | (b->cfg.obs_mode == PRL_OBS_GRID ? 2 : 0); }
+// which build of a fused rollout kernel a batch takes (k_rollout.hip): bit 0 the stale kd-tree, bit 1 OBS_MODE 'grid',
+// bit 2 COLOR_MODE 'HSI'
+static int rollout_flags(const PrlBatch *b) {
+    return (b->kd ? 1 : 0) | (b->cfg.obs_mode == PRL_OBS_GRID ? 2 : 0) | (b->cfg.color_mode == PRL_COLOR_HSI ? 4 : 0);
+}
 
 static int check_policy(const PrlBatch *b, const PrlPolicyWeights *w, const char *who) {
     const PrlConfig &c = b->cfg;

@@ -172,9 +172,9 @@ def test_big_part_composes_with_cone_beams_and_thickness(kw, n, steps):
 
 @pytest.mark.parametrize('kw', [dict(), dict(color_mode='HSI'), dict(paint_method='normal', _small=True)])
 def test_rollout_entry_points_on_every_configuration(kw):
-    """prl_rollout_fragment (given actions, and with the policy) and prl_batch_act_step on batches the fused rollout kernels
-    are not built for -- a large part, COLOR_MODE 'HSI', cone beams: the library takes them launch by launch, rows bit for
-    bit those of prl_policy_act + prl_batch_step."""
+    """prl_rollout_fragment (given actions, and with the policy) and prl_batch_act_step on a large part (fused kernels on the
+    rows in HBM), with COLOR_MODE 'HSI' (their thickness builds, round 5) and under cone beams (which the library takes launch
+    by launch): rows bit for bit those of prl_policy_act + prl_batch_step."""
     import torch
     from paintrl_amd.rollout import MLPPolicy, RolloutWorker
     kw = dict(kw)

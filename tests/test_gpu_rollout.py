@@ -99,11 +99,13 @@ def _fragment_buffers(env, T):
                 logp=torch.zeros((T, n), **f32), value=torch.zeros((T, n), **f32), last_value=torch.zeros(n, **f32))
 
 
-@pytest.mark.parametrize('part,obs_mode,n', [('door_test', 'section', 203), ('square', 'grid', 64), ('door_test', 'grid', 130)])
+@pytest.mark.parametrize('part,obs_mode,n', [('door_test', 'section', 203), ('square', 'grid', 64), ('door_test', 'grid', 130),
+                                             ('door_test', 'section/HSI', 150), ('square', 'grid/HSI', 70)])
 def test_persistent_fragment_with_given_actions_equals_step_by_step(part, obs_mode, n):
     """prl_rollout_fragment without a policy (it reads the action rows): every trajectory row and the final env
     state equal T launches of prl_batch_step, including envs that finish and restart inside the fragment, batch
-    sizes that are not a multiple of the workgroup's four envs, and both mask widths (3 and 4 words per lane)."""
+    sizes that are not a multiple of the workgroup's four envs, and both mask widths (3 and 4 words per lane).
+    '/HSI': COLOR_MODE 'HSI' (thickness bytes; the fused kernels' thickness builds, round 5) -- the bytes too."""
     import torch
     from conftest import start_points_for, synthetic_tables
     from paintrl_amd.batched_env import BatchedPaintEnv
@@ -111,8 +113,10 @@ def test_persistent_fragment_with_given_actions_equals_step_by_step(part, obs_mo
     tables = synthetic_tables(part)
     sp = start_points_for(tables, 'all')
     T = 37
+    hsi = obs_mode.endswith('/HSI')
+    obs_mode = obs_mode.split('/')[0]
     kw = dict(auto_reset=True, seed=21, obs_mode=obs_mode, overlap_penalty=obs_mode == 'grid',
-              max_possible_point=14350 if part == 'square' else 9148)
+              max_possible_point=14350 if part == 'square' else 9148, **(dict(color_mode='HSI') if hsi else {}))
     env_a = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
     env_b = BatchedPaintEnv(DeviceTables(tables, start_points=sp), n, **kw)
     start = np.random.RandomState(1).randint(0, len(sp), size=n)
@@ -134,8 +138,10 @@ def test_persistent_fragment_with_given_actions_equals_step_by_step(part, obs_mo
         if bool(d.any()):
             assert torch.equal(buf['final_obs'][t][d], env_b.final_obs[d])
         n_done += int(d.sum())
-    assert n_done > n // 4
+    assert n_done > (0 if hsi else n // 4)
     assert torch.equal(env_a.painted_words(), env_b.painted_words())
+    if hsi:
+        assert np.array_equal(env_a.thickness(), env_b.thickness())
     sa, sb = env_a.state(), env_b.state()
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
