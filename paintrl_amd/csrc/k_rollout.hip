@@ -354,7 +354,11 @@ int launch_dyn(void (*kernel)(Args), const Args &args, int n_envs, int waves, si
     (((flags)&2) ? (((flags)&1) ? kernel<PRL_KW, true, true, H> : kernel<PRL_KW, false, true, H>)            \
                  : (((flags)&1) ? kernel<PRL_KW, true, false, H> : kernel<PRL_KW, false, false, H>))
 // (bit 2 = COLOR_MODE 'HSI': the thickness painter, round 5)
+#ifdef PRL_ROLLOUT_NO_HSI                  // (the forced-path variant libraries: half the builds; their host side serves HSI launch by launch)
+#define PRL_ROLLOUT_PICK(kernel, flags) PRL_ROLLOUT_PICK2(kernel, flags, false)
+#else
 #define PRL_ROLLOUT_PICK(kernel, flags) (((flags)&4) ? PRL_ROLLOUT_PICK2(kernel, flags, true) : PRL_ROLLOUT_PICK2(kernel, flags, false))
+#endif
 
 PRL_HIDDEN int KFN(act_step)(const void *act_step_args, size_t policy_lds, int flags, void *stream) {
     const ActStepArgs &f = *static_cast<const ActStepArgs *>(act_step_args);

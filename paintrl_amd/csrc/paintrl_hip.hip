@@ -1267,6 +1267,9 @@ static int check_rollout_batch(PrlBatch *b, const char *who) {
 // atan2 sectors) take the same entry points as their definition reads: prl_policy_act + prl_batch_step, launch by launch.
 static bool fused_rollout(const PrlBatch *b) {
     const PrlConfig &c = b->cfg;
+#ifdef PRL_ROLLOUT_NO_HSI                  // (variant libraries built without the thickness rollout kernels)
+    if (c.color_mode != PRL_COLOR_RGB) return false;
+#endif
     return c.paint_method == PRL_PAINT_FAST && !general_section(c);
 }
 
