@@ -36,6 +36,8 @@ echo "== COLOR_MODE 'HSI' (thickness bytes, bpw:384-434): the door, under the co
 $B --color-mode HSI --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_hsi.json" 2>> "$OUT/bench.err"
 $B --color-mode HSI --paint-method normal --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/bench_hsi_normal.json" 2>> "$OUT/bench.err"
 $B --color-mode HSI --part door_rr_big --tex 652 --steps 200 --warmup 40 --no-cpu-baseline > "$OUT/bench_hsi_part_door_rr_big.json" 2>> "$OUT/bench.err"
+$B --color-mode HSI --policy random-fragment --steps 300 --warmup 100 --no-cpu-baseline > "$OUT/bench_hsi_random_fragment.json" 2>> "$OUT/bench.err"
+$B --color-mode HSI --policy fragment --steps 300 --warmup 100 --no-cpu-baseline > "$OUT/bench_hsi_fragment.json" 2>> "$OUT/bench.err"
 echo "== the RCCL path on one rank (PAINTRL_FORCE_DIST=1)"
 PAINTRL_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29613 $B --steps 300 --warmup 50 --no-cpu-baseline > "$OUT/bench_rccl_world1.json" 2>> "$OUT/bench.err"
 echo "== batch-size sweep (one wave per CU ... four per SIMD: the step's latency chain against its throughput)"
