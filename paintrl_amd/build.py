@@ -162,7 +162,7 @@ VARIANTS = {
     # (+ round 5: every mask word loaded and written back instead of the tracked ones, the large parts' observation slot by
     # slot through the small parts' passes, the stale tree walked node by node through its queue instead of one lane per node)
     'force_paint_row_trips_wide_band': ['-DPRL_PAINT_ONE_ROW_PER_TRIP', '-DPRL_WIDE_PAINT_BAND', '-DPRL_LOAD_ALL_WORDS',
-                                        '-DPRL_STORE_ALL_WORDS', '-DPRL_BIG_OBS_BY_SLOTS', '-DPRL_KD_GENERAL_WALK', '-DPRL_ROLLOUT_NO_HSI'],
+                                        '-DPRL_STORE_ALL_WORDS', '-DPRL_BIG_OBS_BY_SLOTS', '-DPRL_KD_GENERAL_WALK', '-DPRL_OBS_ROW_BY_SAMPLES', '-DPRL_ROLLOUT_NO_HSI'],
     # (+ the general ray search without the outline's miss certificate, culling boxes by nextafterf, the determinant's
     # reciprocal as a plain division: the round-4 shortcuts against their plain forms)
     'force_general_search': ['-DPRL_FORCE_FULL_SCANS', '-DPRL_FORCE_GENERAL_RAY', '-DPRL_NO_OUTLINE_MISS', '-DPRL_EXACT_OUTWARD',

@@ -589,6 +589,25 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         }
         UP(word_info, info.data(), info.size());
         UP(word_x32, x32.data(), x32.size());
+        if (d.n_samples > 16384) {      // (observation_big's parts) the words' samples by ascending a2, and the suffix masks of that order
+            std::vector<double> ysort((size_t)d.n_words * 64, INFINITY);
+            std::vector<uint64_t> ymask((size_t)d.n_words * 65, 0);
+            for (int w = 0; w < d.n_words; ++w) {
+                const uint64_t vw = t->word_valid[w];
+                int order[64], nv = 0;
+                for (int j = 0; j < 64; ++j)
+                    if ((vw >> j) & 1) order[nv++] = j;
+                std::stable_sort(order, order + nv, [&](int a, int b) { return y[(size_t)w * 64 + a] < y[(size_t)w * 64 + b]; });
+                uint64_t m = 0;
+                for (int r = nv - 1; r >= 0; --r) {
+                    m |= 1ull << order[r];
+                    ymask[(size_t)w * 65 + r] = m;
+                    ysort[(size_t)w * 64 + r] = y[(size_t)w * 64 + order[r]];
+                }
+            }
+            UP(word_ysort, ysort.data(), ysort.size());
+            UP(word_ymask, ymask.data(), ymask.size());
+        }
     }
     {   // fine grid over the real samples for the lane-parallel nearest-sample query (prl_cone.hpp): ~2.6 samples a cell
         const double *x1 = t->sample_xyz[d.a1], *x2 = t->sample_xyz[d.a2];

@@ -60,6 +60,12 @@ struct PartDev {
                                   // (part_tables._sample_tie_rank; equal distances resolve to the lowest), pads = INT_MAX
     gu8_p samp_ub;                // in-word index one past the last sample with the same a1 coordinate (derived in part_fill)
     gdouble_p word_pivot;         // [n_words][8]: a1 coordinate of in-word samples 7, 15, .. 63 (derived in part_fill)
+    // large parts (more than 16 384 samples; derived in part_fill, else null): per word its valid samples' a2 coordinates in
+    // ascending order (64, padded with +inf) and, for r = 0 .. 64, the mask of the samples from sorted position r on -- with
+    // r = the number of samples below (or not above) the tool's a2 line the samples above it (or not below it) are one mask:
+    // the observation's pass over the tool's own cell row counts whole words instead of samples (section4_big, round 5)
+    gdouble_p word_ysort;         // [n_words][64]
+    gu64_p word_ymask;            // [n_words][65]
     gfloat_p samp_a2_f32;         // [n_samples_pad]: the a2 coordinate rounded to the nearest float (derived in part_fill)
     // large parts' observation (prl_observe.hpp section4_big; derived in part_fill):
     gint_p word_cells;            // [n_words]: the (at most four) grid-observation cells the word's valid samples lie in, one byte each,

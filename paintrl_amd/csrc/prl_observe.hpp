@@ -652,6 +652,44 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
             const uint64_t have = ballot64(v_i != 0), rightm = ballot64(right_i);
             uint64_t ym = ballot64(side_i) & have, bm = have & ~ym;
             constexpr int G3 = 8;
+#ifndef PRL_OBS_ROW_BY_SAMPLES                      // (A/B and parity switch: the per-sample loop below for every word)
+            if (P.word_ysort && ym) {
+                // Wholly left or right of the tool (all but one or two words of the row): the a2 coordinate decides, sample by
+                // sample -- 65 words of 64 samples at 70 654 samples, ~1 300 instructions a step in the loop below.  Each lane
+                // takes ITS word instead: the number of its samples below / not above the line by two binary searches in the
+                // word's a2 values in ascending order (PartDev::word_ysort, seven probes, all lanes' in flight together), the
+                // samples above / not below the line as ONE precomputed mask each (word_ymask), the sectors' counts by popcount.
+                const bool mine = (ym >> lane) & 1;
+                gdouble_p ys_w = P.word_ysort + (size_t)wc * 64;
+                int lo_lt = 0, hi_lt = 64, lo_le = 0, hi_le = 64;
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {                      // (lower / upper bound over 64 entries: at most seven halvings)
+                    const int m_lt = (lo_lt + hi_lt) >> 1, m_le = (lo_le + hi_le) >> 1;
+                    const double y_lt = ldg(ys_w, m_lt < 64 ? m_lt : 63), y_le = m_le == m_lt ? y_lt : ldg(ys_w, m_le < 64 ? m_le : 63);
+                    if (lo_lt < hi_lt) {
+                        if (y_lt < x2) lo_lt = m_lt + 1;
+                        else hi_lt = m_lt;
+                    }
+                    if (lo_le < hi_le) {
+                        if (y_le <= x2) lo_le = m_le + 1;
+                        else hi_le = m_le;
+                    }
+                }
+                const uint64_t ge = ldg(P.word_ymask, (size_t)wc * 65 + lo_lt), gt = ldg(P.word_ymask, (size_t)wc * 65 + lo_le);
+                if (mine) {
+                    const uint64_t u_i = v_i & ~p_i, lt = v_i & ~ge, eq = ge & ~gt;
+                    // bpw:1034-1043:  (>, >) -> 0, (<, >) -> 1, (<, <) -> 2, else 3
+                    if (right_i) {
+                        tot_l += (uint64_t)__popcll(gt) | ((uint64_t)__popcll(v_i & ~gt) << 48);
+                        und_l += (uint64_t)__popcll(gt & u_i) | ((uint64_t)__popcll(u_i & ~gt) << 48);
+                    } else {
+                        tot_l += ((uint64_t)__popcll(gt) << 16) | ((uint64_t)__popcll(lt) << 32) | ((uint64_t)__popcll(eq) << 48);
+                        und_l += ((uint64_t)__popcll(gt & u_i) << 16) | ((uint64_t)__popcll(lt & u_i) << 32) | ((uint64_t)__popcll(eq & u_i) << 48);
+                    }
+                }
+                ym = 0;
+            }
+#endif
             while (ym) {                                              // wholly left or right of the tool: the a2 coordinate decides
                 int L[G3];
                 float yf[G3];
