@@ -589,7 +589,11 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
         }
         UP(word_info, info.data(), info.size());
         UP(word_x32, x32.data(), x32.size());
+#ifdef PRL_OBS_YSORT
+        if (true) {                     // (A/B: the small parts' observation too)
+#else
         if (d.n_samples > 16384) {      // (observation_big's parts) the words' samples by ascending a2, and the suffix masks of that order
+#endif
             std::vector<double> ysort((size_t)d.n_words * 64, INFINITY);
             std::vector<uint64_t> ymask((size_t)d.n_words * 65, 0);
             for (int w = 0; w < d.n_words; ++w) {

@@ -141,11 +141,14 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
 #ifdef PRL_OBS_YPASS
     uint64_t ymask[KW_MAX] = {0, 0, 0, 0}, xgmask[KW_MAX] = {0, 0, 0, 0};      // pass 3a: straddles x2 only | of those: right of x1
 #endif
+#ifdef PRL_OBS_YSORT
+    uint32_t yo_bits = 0, xr_bits = 0;             // bit k: this lane's word of slot k straddles x2 only | lies right of x1
+#endif
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int w = lane + 64 * (slot0 + k);
         bool straddle = false;
-#ifdef PRL_OBS_YPASS
+#if defined(PRL_OBS_YPASS) || defined(PRL_OBS_YSORT)
         bool yonly = false, xright = false;
 #endif
         if constexpr (KW < 4) {
@@ -165,7 +168,7 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
             vline[k] = rest & (yg | yl);
             above[k] = yg;
             straddle = rest & !(yg | yl);
-#ifdef PRL_OBS_YPASS
+#if defined(PRL_OBS_YPASS) || defined(PRL_OBS_YSORT)
             yonly = straddle & (xg | xl);
             xright = xg;
 #endif
@@ -181,13 +184,17 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
                 vline[k] = yg | yl;
                 above[k] = yg;
                 straddle = !vline[k];
-#ifdef PRL_OBS_YPASS
+#if defined(PRL_OBS_YPASS) || defined(PRL_OBS_YSORT)
                 yonly = straddle & (xg | xl);
                 xright = xg;
 #endif
             }
         }
-#ifdef PRL_OBS_YPASS
+#if defined(PRL_OBS_YSORT)
+        yo_bits |= (yonly ? 1u : 0u) << k;
+        xr_bits |= (xright ? 1u : 0u) << k;
+        smask[k] = ballot64(straddle & !yonly);
+#elif defined(PRL_OBS_YPASS)
         ymask[k] = ballot64(yonly);
         xgmask[k] = ballot64(yonly & xright);
         smask[k] = ballot64(straddle & !yonly);
@@ -272,6 +279,43 @@ __device__ __forceinline__ void section4_accumulate(PartRef P, double x1, double
             }
         }
     }
+#ifdef PRL_OBS_YSORT
+    // [A/B switch] the words of the tool's row that lie wholly left or right of it, each by its own lane (section4_big's way):
+    // two binary searches in the word's a2 values in ascending order, two suffix masks, popcounts
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const bool mine = (yo_bits >> k) & 1;
+        if (ballot64(mine)) {
+            const int wc = mine ? lane + 64 * (slot0 + k) : 0;
+            gdouble_p ys_w = P.word_ysort + (size_t)wc * 64;
+            int lo_lt = 0, hi_lt = 64, lo_le = 0, hi_le = 64;
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const int m_lt = (lo_lt + hi_lt) >> 1, m_le = (lo_le + hi_le) >> 1;
+                const double y_lt = ldg(ys_w, m_lt < 64 ? m_lt : 63), y_le = m_le == m_lt ? y_lt : ldg(ys_w, m_le < 64 ? m_le : 63);
+                if (lo_lt < hi_lt) {
+                    if (y_lt < x2) lo_lt = m_lt + 1;
+                    else hi_lt = m_lt;
+                }
+                if (lo_le < hi_le) {
+                    if (y_le <= x2) lo_le = m_le + 1;
+                    else hi_le = m_le;
+                }
+            }
+            const uint64_t ge = ldg(P.word_ymask, (size_t)wc * 65 + lo_lt), gt = ldg(P.word_ymask, (size_t)wc * 65 + lo_le);
+            if (mine) {
+                const uint64_t v_i = valid[k], u_i = v_i & ~painted[k], lt = v_i & ~ge, eq = ge & ~gt;
+                if ((xr_bits >> k) & 1) {
+                    tot_l += (uint64_t)__popcll(gt) | ((uint64_t)__popcll(v_i & ~gt) << 48);
+                    und_l += (uint64_t)__popcll(gt & u_i) | ((uint64_t)__popcll(u_i & ~gt) << 48);
+                } else {
+                    tot_l += ((uint64_t)__popcll(gt) << 16) | ((uint64_t)__popcll(lt) << 32) | ((uint64_t)__popcll(eq) << 48);
+                    und_l += ((uint64_t)__popcll(gt & u_i) << 16) | ((uint64_t)__popcll(lt & u_i) << 32) | ((uint64_t)__popcll(eq & u_i) << 48);
+                }
+            }
+        }
+    }
+#endif
     // Pass 3: the words that straddle the tool on both axes or on x2 only, one sample per lane, four words per trip
     // (their loads travel together).  32-bit work only: the uniform valid / painted words become lane predicates
     // (inverse ballot) and the counters are four 8-bit fields (a lane sees at most 64 straddling words per call).
