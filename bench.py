@@ -263,6 +263,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--envs', type=int, default=ENVS_PER_GPU, help='envs per GPU (default: the BASELINE config)')
     ap.add_argument('--obs-mode', default='section', choices=['section', 'grid'])
+    ap.add_argument('--obs-grad', type=int, default=4, help="OBS_GRAD (rge:150): 4 = the four-quadrant rule, other values the atan2 sectors")
     ap.add_argument('--mixed', action='store_true', help='config 5: door/sheet alternate, START_POINT_MODE all')
     ap.add_argument('--actions', default='random', choices=['random', 'sweep'],
                     help="'sweep': every env follows an on-part serpentine with a random phase (SURVEY 8d item 2), so "
@@ -314,9 +315,9 @@ def main():
     # the headline door: _max_possible_point as the reference computes it (rge:240-252, 9 148 of 9 664); other parts: 95 %
     mpp = 9148 if not other_part else int(0.95 * tables.sample_pos.shape[0])
     start_mode = 'all' if (args.actions == 'sweep' or other_part) else 'anchor'      # the sweep starts anywhere on the part
-    dt = DeviceTables(tables, obs_grad=4, start_points=part_tables.start_points(tables, start_mode))
+    dt = DeviceTables(tables, obs_grad=args.obs_grad, start_points=part_tables.start_points(tables, start_mode))
     overlap = args.obs_mode == 'grid'
-    common = dict(device=device, obs_mode=args.obs_mode, obs_grad=4, auto_reset=True, overlap_penalty=overlap,
+    common = dict(device=device, obs_mode=args.obs_mode, obs_grad=args.obs_grad, auto_reset=True, overlap_penalty=overlap,
                   paint_method=args.paint_method, color_mode=args.color_mode)
     if args.mixed:
         if args.streams > 1:

@@ -36,19 +36,35 @@ __device__ __forceinline__ double py_floor_div(double vx, double wx) {
     return copysign(0.0, vx / wx);
 }
 
-// bpw:1026-1031, 1045-1061 with section != 4: every sample is classified by atan2 (not tuned: this
-// is the hand-selected OBS_GRAD variant; the default 4-sector rule takes the fast path below).
+// bpw:1026-1031, 1045-1061 with section != 4: every sample's sector is int(angle // (2 pi / g)) of its float64 atan2 angle about
+// the tool.  Until round 5 exactly that per sample (atan2, Python's floor division, two LDS atomics on g counters: 284 us a
+// step on the door, 1.9 ms at 70 654 samples -- first measured then).  Now a float atan2f decides wherever it can: its angle is
+// within 1e-6 rad of the true one (inputs rounded to float, a few units in the last place of the function), a sector is at least
+// 2 pi / 64 wide, so a sample whose float position inside its sector is more than SECTOR_BAND from both ends IS in that sector,
+// whatever the float64 arithmetic rounds to; the others (one in five thousand: a word in eighty has one) take the reference's
+// own expression.  The counters: one ballot a sector and word (g <= GENSEC_BALLOT_MAX), lane j keeps sector j's.
 // `lds_painted`: the mask row of a large part (LDS copy or the env's row in HBM), or nullptr (then the register slots `painted` are used).
+#define SECTOR_BAND 1.0e-4f
+constexpr int GENSEC_BALLOT_MAX = 16;
 template <int KW, typename PW>
 __device__ void section_general_wave(PartRef P, int g, double x1, double x2, const uint64_t painted[KW_MAX],
                                      PW lds_painted, int lane, int *cnt /* LDS: [2][64] for this wave */,
                                      double *out) {
     gdouble_p sx = P.samp_a1, sy = P.samp_a2;
-    cnt[lane] = 0;
-    cnt[64 + lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // zeroes before the atomics of other lanes
-    __builtin_amdgcn_wave_barrier();
+    const bool by_ballot = g <= GENSEC_BALLOT_MAX;
+    if (!by_ballot) {
+        cnt[lane] = 0;
+        cnt[64 + lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // zeroes before the atomics of other lanes
+        __builtin_amdgcn_wave_barrier();
+    }
     const double two_pi = 2 * PI, basis = two_pi / g;
+    const float two_pi_f = 6.2831855f, inv_basis_f = (float)g / 6.2831855f;
+    int tot_j = 0, und_j = 0;                                       // lane j: sector j's counts (by_ballot)
+    // g <= 8: this lane's own counts, sector i in the 16-bit field i & 3 of word i >> 2 (a lane counts one sample a word: at most
+    // n_words <= 4 096 a field), summed over the wave at the end -- ten instructions a word instead of a ballot a sector
+    const bool packed = g <= 8;
+    uint64_t tot_p[2] = {0, 0}, und_p[2] = {0, 0};
     for (int w = 0; w < P.n_words; ++w) {
         const uint64_t vw = P.word_valid[w];
         uint64_t pw = 0;
@@ -59,16 +75,57 @@ __device__ void section_general_wave(PartRef P, int g, double x1, double x2, con
             for (int k = 0; k < KW; ++k)
                 if (k == (w >> 6)) pw = bcast_u64(painted[k], w & 63);
         }
-        if (!((vw >> lane) & 1)) continue;
+        if (vw == 0) continue;                                        // (wave-uniform)
         const int s = (w << 6) + lane;
         const double rx = ldg(sx, s) - x1, ry = ldg(sy, s) - x2;
-        if (rx == 0 && ry == 0) continue;
-        double ang = atan2(ry, rx);
-        if (ang < 0) ang = two_pi + ang;
-        int idx = (int)py_floor_div(ang, basis);
-        idx = idx > g - 1 ? g - 1 : (idx < 0 ? 0 : idx);
-        atomicAdd(&cnt[idx], 1);
-        if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
+        const bool counted = ((vw >> lane) & 1) && !(rx == 0 && ry == 0);      // (bpw:1032: the tool's own sample is skipped)
+        // the float estimate, and whether it is safe
+        float af = atan2f((float)ry, (float)rx);
+        if (af < 0) af = two_pi_f + af;
+        const float pf = af * inv_basis_f, fl = floorf(pf), fr = pf - fl;
+        int idx = (int)fl;
+        const bool unsure = counted & !((fr > SECTOR_BAND) & (fr < 1.0f - SECTOR_BAND) & (idx >= 0) & (idx < g));
+        if (ballot64(unsure) != 0) {
+            if (unsure) {
+                double ang = atan2(ry, rx);
+                if (ang < 0) ang = two_pi + ang;
+                idx = (int)py_floor_div(ang, basis);
+                idx = idx > g - 1 ? g - 1 : (idx < 0 ? 0 : idx);
+            }
+        }
+        if (packed) {
+            const uint64_t one = counted ? 1ull << (16 * (idx & 3)) : 0, uno = ((pw >> lane) & 1) ? 0 : one;
+            const bool hi = idx >= 4;
+            tot_p[0] += hi ? 0 : one;
+            tot_p[1] += hi ? one : 0;
+            und_p[0] += hi ? 0 : uno;
+            und_p[1] += hi ? uno : 0;
+        } else if (by_ballot) {
+            for (int j = 0; j < g; ++j) {
+                const uint64_t m = ballot64(counted & (idx == j));
+                if (lane == j) {
+                    tot_j += (int)__popcll(m);
+                    und_j += (int)__popcll(m & ~pw);
+                }
+            }
+        } else if (counted) {
+            atomicAdd(&cnt[idx], 1);
+            if (!((pw >> lane) & 1)) atomicAdd(&cnt[64 + idx], 1);
+        }
+    }
+    if (packed) {
+        for (int j = 0; j < g; ++j) {
+            const uint32_t t = wave_sum_u32((uint32_t)(tot_p[j >> 2] >> (16 * (j & 3))) & 0xffffu);
+            const uint32_t u = wave_sum_u32((uint32_t)(und_p[j >> 2] >> (16 * (j & 3))) & 0xffffu);
+            if (lane == j) {
+                tot_j = (int)t;
+                und_j = (int)u;
+            }
+        }
+    }
+    if (by_ballot) {
+        if (lane < g) out[lane] = tot_j == 0 ? 0.0 : (double)und_j / (double)tot_j;
+        return;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // all atomics before the read-out
     __builtin_amdgcn_wave_barrier();
