@@ -459,3 +459,48 @@ def test_cone_beams_do_not_depend_on_the_batch_they_run_in():
     big.close()
     for h in halves:
         h.close()
+
+
+@pytest.mark.parametrize('part,tex,grad', [('door_test', 0, 2), ('door_test', 0, 3), ('door_test', 0, 5), ('door_test', 0, 7),
+                                          ('door_test', 0, 8), ('door_test', 0, 12), ('door_test', 0, 20), ('square', 0, 9),
+                                          ('door_rr_big', 320, 5), ('door_rr_big', 320, 12), ('door_rr_big', 320, 24)])
+def test_atan2_sectors_of_every_width(part, tex, grad):
+    """OBS_GRAD != 4 (bpw:1045-1061): a sample's sector is int(angle // (2 pi / g)) of its float64 atan2 angle about the tool.
+    The device counts a word whose box lies inside one wedge by popcount and lets a float atan2f decide the other samples
+    wherever it safely can (prl_observe.hpp section_general_wave); per-lane packed counters up to 8 sectors, a ballot a
+    sector up to 16, LDS atomics beyond -- every width against the oracle, tools also parked exactly on sample coordinates
+    (angles of exactly 0, pi / 2, pi: the ends of sectors for even g)."""
+    tables = synthetic_tables(part, tex_size=(tex, tex)) if tex else synthetic_tables(part)
+    sp = start_points_for(tables, 'all')
+    n, steps = 96, 10
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    kw = dict(obs_mode='section', obs_grad=grad, max_possible_point=mpp)
+    env = _env(tables, n, sp, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=8, **kw)
+    rng = np.random.RandomState(100 + grad)
+    start = rng.randint(0, len(sp), size=n)
+    assert np.array_equal(env.reset(start_idx=start).cpu().numpy(), orc.reset(start))
+    for k in range(steps):
+        a = rng.randint(0, 4, size=n)
+        o, r, d, i = env.step(a)
+        oo, rr, dd, ii = orc.step(a)
+        assert np.array_equal(o.cpu().numpy(), oo), 'obs, step %d' % k
+        assert np.array_equal(r.cpu().numpy(), rr) and np.array_equal(d.cpu().numpy(), dd), 'step %d' % k
+        if dd.any():
+            new = rng.randint(0, len(sp), size=n)
+            assert np.array_equal(env.reset(mask=dd, start_idx=new).cpu().numpy()[dd], orc.reset(new, mask=dd)[dd])
+    pos = tables.sample_pos
+    a0 = [k for k in range(3) if k not in (tables.a1, tables.a2)][0]
+    orn = [0.0, 0.0, 0.0]
+    orn[a0] = -1.0
+    pick = rng.randint(0, pos.shape[0], size=(n, 2))
+    for e in range(n):                                      # on a sample; its a1 with another's a2; a hair off
+        p = pos[pick[e, 0]].copy()
+        if e % 3 == 1:
+            p[tables.a2] = pos[pick[e, 1], tables.a2]
+        elif e % 3 == 2:
+            p[tables.a1] += 1e-12
+        env.set_pose(e, p, orn)
+        orc.set_pose(e, p, orn)
+    assert np.array_equal(env.observe().cpu().numpy(), orc.observe())
+    env.close()
