@@ -32,6 +32,9 @@ done
 $B --part door_rr_big --tex 652 --policy random-fragment --steps 300 --warmup 100 --no-cpu-baseline > "$OUT/bench_part_door_rr_big_random_fragment.json" 2>> "$OUT/bench.err"
 echo "== cone beams on a large part (772 beams a shot at 70 654 samples: the beam table grows with the sample density)"
 $B --paint-method normal --part door_rr_big --tex 652 --steps 60 --warmup 10 --no-cpu-baseline > "$OUT/bench_normal_part_door_rr_big.json" 2>> "$OUT/bench.err"
+echo "== the atan2-sector observation (OBS_GRAD 6, bpw:1045-1061): door and a 70 411-sample part"
+$B --obs-grad 6 --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_sectors6.json" 2>> "$OUT/bench.err"
+$B --obs-grad 6 --part door_rr_big --tex 652 --steps 200 --warmup 40 --no-cpu-baseline > "$OUT/bench_sectors6_part_door_rr_big.json" 2>> "$OUT/bench.err"
 echo "== COLOR_MODE 'HSI' (thickness bytes, bpw:384-434): the door, under the cone beams, a 70 654-sample part"
 $B --color-mode HSI --steps 600 --warmup 100 --no-cpu-baseline > "$OUT/bench_hsi.json" 2>> "$OUT/bench.err"
 $B --color-mode HSI --paint-method normal --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/bench_hsi_normal.json" 2>> "$OUT/bench.err"
