@@ -203,6 +203,23 @@ def test_thickness_mode_full_size_equals_oracle(tex, n, steps):
     env.close()
 
 
+@pytest.mark.parametrize('part,tex,grad,n,steps', [('door_test', 0, 6, 2048, 16), ('door_rr_big', 480, 6, 512, 8)])
+def test_atan2_sectors_with_auto_reset_equal_oracle(part, tex, grad, n, steps):
+    """OBS_GRAD != 4 (bpw:1045-1061) at a launch-sized batch: words inside one wedge counted by popcount, float atan2f
+    where it is safe, the reference's float64 expression at the sectors' ends (prl_observe.hpp section_general_wave) -- every
+    row against the oracle with the in-kernel auto-reset on, the door's register masks and a 38 224-sample part's rows in HBM."""
+    from paintrl_amd.batched_env import BatchedPaintEnv
+    tables = synthetic_tables(part, tex_size=(tex, tex)) if tex else synthetic_tables(part)
+    sp = start_points_for(tables, 'all')
+    mpp = int(0.95 * tables.sample_pos.shape[0])
+    kw = dict(obs_mode='section', obs_grad=grad, max_possible_point=mpp)
+    from paintrl_amd.device_tables import DeviceTables
+    env = BatchedPaintEnv(DeviceTables(tables, obs_grad=grad, start_points=sp), n, auto_reset=True, **kw)
+    orc = oracle.Oracle(tables, n, start_points=sp, threads=16, **kw)
+    _run(env, orc, np.full(n, len(sp)), steps, 2626, 0)
+    env.close()
+
+
 def test_cone_beams_full_size_8_steps_equals_oracle():
     """PAINT_METHOD 'normal' (rob:251-285, bpw:562-566) at the launch shape of the benchmark: 4 096 envs, 8 steps with
     auto-reset, anchor starts (off-part shots, the window and the rim of the door all occur)."""
