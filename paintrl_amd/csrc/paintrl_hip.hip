@@ -609,6 +609,10 @@ int part_fill(PrlPart *p, const PrlPartTables *t) {
                     ysort[(size_t)w * 64 + r] = y[(size_t)w * 64 + order[r]];
                 }
             }
+            std::vector<double> ypivot((size_t)d.n_words * 8);
+            for (int w = 0; w < d.n_words; ++w)
+                for (int j = 0; j < 8; ++j) ypivot[(size_t)w * 8 + j] = ysort[(size_t)w * 64 + 8 * j + 7];
+            UP(word_ypivot, ypivot.data(), ypivot.size());
             UP(word_ysort, ysort.data(), ysort.size());
             UP(word_ymask, ymask.data(), ymask.size());
         }

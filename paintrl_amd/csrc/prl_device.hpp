@@ -65,6 +65,7 @@ struct PartDev {
     // r = the number of samples below (or not above) the tool's a2 line the samples above it (or not below it) are one mask:
     // the observation's pass over the tool's own cell row counts whole words instead of samples (section4_big, round 5)
     gdouble_p word_ysort;         // [n_words][64]
+    gdouble_p word_ypivot;        // [n_words][8]: entries 7, 15, .. 63 of word_ysort (the group of eight that holds a given a2 in ONE probe)
     gu64_p word_ymask;            // [n_words][65]
     gfloat_p samp_a2_f32;         // [n_samples_pad]: the a2 coordinate rounded to the nearest float (derived in part_fill)
     // large parts' observation (prl_observe.hpp section4_big; derived in part_fill):

@@ -811,21 +811,25 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
                 // word's a2 values in ascending order (PartDev::word_ysort, seven probes, all lanes' in flight together), the
                 // samples above / not below the line as ONE precomputed mask each (word_ymask), the sectors' counts by popcount.
                 const bool mine = (ym >> lane) & 1;
-                gdouble_p ys_w = P.word_ysort + (size_t)wc * 64;
-                int lo_lt = 0, hi_lt = 64, lo_le = 0, hi_le = 64;
-#pragma unroll
-                for (int it = 0; it < 7; ++it) {                      // (lower / upper bound over 64 entries: at most seven halvings)
-                    const int m_lt = (lo_lt + hi_lt) >> 1, m_le = (lo_le + hi_le) >> 1;
-                    const double y_lt = ldg(ys_w, m_lt < 64 ? m_lt : 63), y_le = m_le == m_lt ? y_lt : ldg(ys_w, m_le < 64 ? m_le : 63);
-                    if (lo_lt < hi_lt) {
-                        if (y_lt < x2) lo_lt = m_lt + 1;
-                        else hi_lt = m_lt;
-                    }
-                    if (lo_le < hi_le) {
-                        if (y_le <= x2) lo_le = m_le + 1;
-                        else hi_le = m_le;
-                    }
+                // (two probes, as for a1 in pass 2: the word's eight pivots name the group of eight that holds the line, the group
+                // gives the position -- seven dependent probes of a binary search were most of this pass's time)
+                const f64x4 GAS *yp4 = reinterpret_cast<const f64x4 GAS *>(P.word_ypivot);
+                const f64x4 GAS *ys4 = reinterpret_cast<const f64x4 GAS *>(P.word_ysort);
+                const f64x4 pa = ldg(yp4, 2 * wc), pb = ldg(yp4, 2 * wc + 1);
+                const int grp_lt = (pa.x < x2) + (pa.y < x2) + (pa.z < x2) + (pa.w < x2) + (pb.x < x2) + (pb.y < x2) + (pb.z < x2) + (pb.w < x2);
+                const int grp_le = (pa.x <= x2) + (pa.y <= x2) + (pa.z <= x2) + (pa.w <= x2) + (pb.x <= x2) + (pb.y <= x2) + (pb.z <= x2) +
+                                   (pb.w <= x2);
+                const int g_lt = grp_lt < 8 ? grp_lt : 7, g_le = grp_le < 8 ? grp_le : 7;
+                const f64x4 la = ldg(ys4, 16 * wc + 2 * g_lt), lb = ldg(ys4, 16 * wc + 2 * g_lt + 1);
+                f64x4 ea = la, eb = lb;
+                if (ballot64(g_le != g_lt) != 0) {                       // (values equal to the line across a group's end: rare)
+                    ea = ldg(ys4, 16 * wc + 2 * g_le);
+                    eb = ldg(ys4, 16 * wc + 2 * g_le + 1);
                 }
+                const int in_lt = (la.x < x2) + (la.y < x2) + (la.z < x2) + (la.w < x2) + (lb.x < x2) + (lb.y < x2) + (lb.z < x2) + (lb.w < x2);
+                const int in_le = (ea.x <= x2) + (ea.y <= x2) + (ea.z <= x2) + (ea.w <= x2) + (eb.x <= x2) + (eb.y <= x2) + (eb.z <= x2) +
+                                  (eb.w <= x2);
+                const int lo_lt = grp_lt < 8 ? 8 * grp_lt + in_lt : 64, lo_le = grp_le < 8 ? 8 * grp_le + in_le : 64;
                 const uint64_t ge = ldg(P.word_ymask, (size_t)wc * 65 + lo_lt), gt = ldg(P.word_ymask, (size_t)wc * 65 + lo_le);
                 if (mine) {
                     const uint64_t u_i = v_i & ~p_i, lt = v_i & ~ge, eq = ge & ~gt;
