@@ -32,7 +32,11 @@ def test_parity_suites_on_forced_general_paths(variant):
     extra = []
     if variant == 'force_paint_row_trips_wide_band':      # its round-5 switches live in the large-part and stale-tree kernels
         suites += [os.path.join(REPO, 'tests', 'test_gpu_big_parts.py'), os.path.join(REPO, 'tests', 'test_gpu_stale_kdtree.py')]
-        extra = ['--deselect', 'tests/test_gpu_big_parts.py::test_reference_sized_part_with_the_stale_tree_fits_the_lds']
+        extra = ['--deselect', 'tests/test_gpu_big_parts.py::test_reference_sized_part_with_the_stale_tree_fits_the_lds',
+                 # (the rollout entry points run the same device code as the per-step kernels these suites already drive)
+                 '--deselect', 'tests/test_gpu_big_parts.py::test_rollout_entry_points_on_every_configuration',
+                 '--deselect', 'tests/test_gpu_big_parts.py::test_fused_rollout_on_a_large_part_with_the_stale_tree',
+                 '--deselect', 'tests/test_gpu_stale_kdtree.py::test_stale_tree_in_the_rollout_kernels']
     out = subprocess.run([sys.executable, '-m', 'pytest'] + suites + extra + ['-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'],
                          env=env, cwd=REPO, capture_output=True, text=True, timeout=1500)
     tail = out.stdout[-1500:] + out.stderr[-500:]
