@@ -719,7 +719,10 @@ __device__ void section4_big(PartRef P, double x1, double x2, PW painted, int la
         und_l += above ? (ug | (ul << 16) | (ue << 48)) : ((ul << 32) | ((ug + ue) << 48));
     };
     // (three slots a trip: their nine loads are issued together, one round trip)
-    constexpr int G1 = 3;
+#ifndef PRL_BIG_OBS_G1
+#define PRL_BIG_OBS_G1 3                  // (A/B: 2 / 4 / 6 slots a trip)
+#endif
+    constexpr int G1 = PRL_BIG_OBS_G1;
     for (int k0 = 0; k0 < n_slots; k0 += G1) {
         uint32_t info[G1];
         f32x2 xb[G1];
